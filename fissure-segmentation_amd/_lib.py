@@ -1,0 +1,44 @@
+"""ctypes binding of libfsg_hip.so (C ABI: include/fsg_hip.h).  No fallback: a missing library is an
+ImportError, a failing call is a RuntimeError carrying fsg_last_error()."""
+import ctypes
+import os
+
+import torch  # noqa: F401  -- must come first: brings torch's libamdhip64 into the process, which the
+#                              library's DT_NEEDED libamdhip64.so.7 then resolves to (one HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfsg_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      f"or `make -C {os.path.join(_HERE, 'csrc')}`; there is no CPU fallback.")
+
+lib = ctypes.CDLL(LIB_PATH)
+
+_P, _I, _L = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+SIGNATURES = {
+    "fsg_version": ([], _I),
+    "fsg_last_error": ([], ctypes.c_char_p),
+    "fsg_knn_dense_f32": ([_P, _I, _I, _L, _L, _I, _I, _I, _P, _P, _P], _I),
+    "fsg_edge_gather_fwd_f32": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "fsg_edge_gather_bwd_f32": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "fsg_chamfer_nn_f32": ([_P, _P, _I, _I, _I, _P, _P, _P], _I),
+    "fsg_chamfer_nn_bwd_f32": ([_P, _P, _P, _P, _I, _I, _I, _P, _P, _P], _I),
+    "fsg_knn_segment_f32": ([_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P], _I),
+    "fsg_fps_f32": ([_P, _P, _P, _I, _I, _P, _P, _P], _I),
+    "fsg_group_gather_fwd_f32": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "fsg_group_gather_bwd_f32": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "fsg_vec_attn_fwd_f32": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "fsg_vec_attn_bwd_f32": ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+}
+for _name, (_args, _res) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header and library out of sync
+    _fn.argtypes, _fn.restype = _args, _res
+
+KNN_FIX_DIAG, KNN_DROP_FIRST, KNN_MAX_K = 1, 2, 64
+
+
+def call(name, *args):
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (code {rc}): {lib.fsg_last_error().decode()}")

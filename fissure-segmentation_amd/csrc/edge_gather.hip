@@ -1,0 +1,85 @@
+// Edge features [x_j - x_i ; x_i] and their transpose -- include/fsg_hip.h: fsg_edge_gather_*_f32.
+// Replaces models/dgcnn.py:31-36 and models/dgcnn_opensrc.py:43-66 of the reference.
+//
+// HBM-bound: per point and layer the forward writes 2*C*k*4 bytes and reads 4*C + 4*k; lanes walk the
+// flattened (i, s) edge axis, which is the contiguous axis of both idx (B,N,k) and edge (B,2C,N,k), so
+// every index load and every edge store is a full 256-byte wave access; the x_j gathers hit L2 (one
+// cloud's (C,N) slab is <= 2 MB).
+#include "fsg_common.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int CCHUNK = 8;  // channels per workgroup: amortises the idx load, keeps the grid large
+
+__global__ __launch_bounds__(BLOCK) void edge_fwd_kernel(const float *__restrict__ x, const int32_t *__restrict__ idx,
+                                                          float *__restrict__ edge, int C, int N, int k) {
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * CCHUNK;
+    const long NK = (long)N * k;
+    const long e = (long)blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= NK) return;
+    const int i = (int)(e / k);
+    const int j = idx[(long)b * NK + e];
+    const float *xb = x + (long)b * C * N;
+    float *rel = edge + (long)b * 2 * C * NK + e;
+    const int cend = min(c0 + CCHUNK, C);
+    for (int c = c0; c < cend; ++c) {
+        const float xi = xb[(long)c * N + i];
+        const float xj = xb[(long)c * N + j];
+        rel[(long)c * NK] = xj - xi;
+        rel[(long)(C + c) * NK] = xi;
+    }
+}
+
+// grad_x[b,c,i] += sum_s (g_ctr - g_rel)[b,c,i,s] ; grad_x[b,c,idx[b,i,s]] += g_rel[b,c,i,s]
+__global__ __launch_bounds__(BLOCK) void edge_bwd_kernel(const float *__restrict__ g, const int32_t *__restrict__ idx,
+                                                          float *__restrict__ gx, int C, int N, int k) {
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * CCHUNK;
+    const long NK = (long)N * k;
+    const long e = (long)blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= NK) return;
+    const int i = (int)(e / k);
+    const int j = idx[(long)b * NK + e];
+    float *gxb = gx + (long)b * C * N;
+    const float *gr = g + (long)b * 2 * C * NK + e;
+    const int cend = min(c0 + CCHUNK, C);
+    for (int c = c0; c < cend; ++c) {
+        const float r = gr[(long)c * NK];
+        const float ct = gr[(long)(C + c) * NK];
+        atomicAdd(gxb + (long)c * N + j, r);
+        atomicAdd(gxb + (long)c * N + i, ct - r);
+    }
+}
+
+}  // namespace
+
+extern "C" int fsg_edge_gather_fwd_f32(const float *x, const int32_t *idx, float *edge, int B, int C, int N, int k,
+                                       fsg_stream_t stream) {
+    FSG_REQUIRE(x && idx && edge, "fsg_edge_gather_fwd_f32: NULL pointer");
+    FSG_REQUIRE(B >= 0 && C > 0 && N > 0 && k > 0, "fsg_edge_gather_fwd_f32: bad shape");
+    FSG_REQUIRE(B <= 65535 && fsg_cdiv(C, CCHUNK) <= 65535, "fsg_edge_gather_fwd_f32: grid too large");
+    if (B == 0) return FSG_OK;
+    dim3 grid(fsg_cdiv((long)N * k, BLOCK), fsg_cdiv(C, CCHUNK), B);
+    hipLaunchKernelGGL(edge_fwd_kernel, grid, dim3(BLOCK), 0, (hipStream_t)stream, x, idx, edge, C, N, k);
+    FSG_CHECK_LAUNCH("fsg_edge_gather_fwd_f32");
+    return FSG_OK;
+}
+
+extern "C" int fsg_edge_gather_bwd_f32(const float *grad_edge, const int32_t *idx, float *grad_x, int B, int C, int N,
+                                       int k, fsg_stream_t stream) {
+    FSG_REQUIRE(grad_edge && idx && grad_x, "fsg_edge_gather_bwd_f32: NULL pointer");
+    FSG_REQUIRE(B >= 0 && C > 0 && N > 0 && k > 0, "fsg_edge_gather_bwd_f32: bad shape");
+    FSG_REQUIRE(B <= 65535 && fsg_cdiv(C, CCHUNK) <= 65535, "fsg_edge_gather_bwd_f32: grid too large");
+    if (B == 0) return FSG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)B * C * N, st) != hipSuccess) {
+        fsg_set_error("fsg_edge_gather_bwd_f32: memset failed");
+        return FSG_ERR_HIP;
+    }
+    dim3 grid(fsg_cdiv((long)N * k, BLOCK), fsg_cdiv(C, CCHUNK), B);
+    hipLaunchKernelGGL(edge_bwd_kernel, grid, dim3(BLOCK), 0, st, grad_edge, idx, grad_x, C, N, k);
+    FSG_CHECK_LAUNCH("fsg_edge_gather_bwd_f32");
+    return FSG_OK;
+}

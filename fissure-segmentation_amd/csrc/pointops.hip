@@ -1,0 +1,241 @@
+// PointTransformer primitives on packed (n,3)/(n,c) clouds with cumulative segment offsets --
+// include/fsg_hip.h: fsg_knn_segment_f32, fsg_fps_f32, fsg_group_gather_*, fsg_vec_attn_*.
+// Replace pointops_cuda.{knnquery,furthestsampling,grouping,aggregation}_* behind
+// models/pointtransformer/pointops.py and the torch chain at models/pointtransformer/seg_model.py:50-52.
+//
+// v0: one lane per query (kNN), one workgroup per cloud (FPS), lanes along channels (gather /
+// aggregate).  Distances use the direct form d = fma(dz,dz, fma(dy,dy, dx*dx)) like oracle/fsg_oracle.c.
+#include "fsg_common.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+__device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+
+template <int NS>
+__global__ __launch_bounds__(BLOCK) void knn_segment_kernel(const float *__restrict__ xyz,
+                                                             const float *__restrict__ new_xyz,
+                                                             const int32_t *__restrict__ offset,
+                                                             const int32_t *__restrict__ new_offset, int b, int m,
+                                                             int nsample, int32_t *__restrict__ idx,
+                                                             float *__restrict__ dist2) {
+    const int q = blockIdx.x * BLOCK + threadIdx.x;
+    if (q >= m) return;
+    int s = 0;
+    while (s < b - 1 && q >= new_offset[s]) ++s;
+    const int st = s ? offset[s - 1] : 0, en = offset[s];
+    const float qx = new_xyz[3L * q], qy = new_xyz[3L * q + 1], qz = new_xyz[3L * q + 2];
+    float bd[NS];
+    int bi[NS];
+#pragma unroll
+    for (int p = 0; p < NS; ++p) { bd[p] = 1e10f; bi[p] = st; }
+    for (int j = st; j < en; ++j) {
+        const float d = sqdist3(qx, qy, qz, xyz[3L * j], xyz[3L * j + 1], xyz[3L * j + 2]);
+        if (d < bd[NS - 1]) {
+#pragma unroll
+            for (int p = NS - 1; p > 0; --p) {
+                const bool shift = d < bd[p - 1];
+                const bool here = d < bd[p];
+                const float nd = shift ? bd[p - 1] : (here ? d : bd[p]);
+                const int ni = shift ? bi[p - 1] : (here ? j : bi[p]);
+                bd[p] = nd;
+                bi[p] = ni;
+            }
+            if (d < bd[0]) { bd[0] = d; bi[0] = j; }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NS; ++p)
+        if (p < nsample) {
+            idx[(long)q * nsample + p] = bi[p];
+            dist2[(long)q * nsample + p] = bd[p];
+        }
+}
+
+__global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ offset,
+                                                     const int32_t *__restrict__ new_offset, float *__restrict__ md,
+                                                     int32_t *__restrict__ idx) {
+    __shared__ float wv[BLOCK / 64];
+    __shared__ int wj[BLOCK / 64];
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int st = s ? offset[s - 1] : 0, en = offset[s];
+    const int qs = s ? new_offset[s - 1] : 0, qe = new_offset[s];
+    if (qe <= qs || en <= st) return;
+    for (int j = st + tid; j < en; j += BLOCK) md[j] = 1e10f;
+    int cur = st;
+    if (tid == 0) idx[qs] = cur;
+    for (int t = qs + 1; t < qe; ++t) {
+        const float px = xyz[3L * cur], py = xyz[3L * cur + 1], pz = xyz[3L * cur + 2];
+        float bv = -1.f;
+        int bj = 0x7fffffff;
+        for (int j = st + tid; j < en; j += BLOCK) {
+            const float d = sqdist3(xyz[3L * j], xyz[3L * j + 1], xyz[3L * j + 2], px, py, pz);
+            const float v = fminf(d, md[j]);
+            md[j] = v;
+            if (v > bv) { bv = v; bj = j; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(bv, off);
+            const int oj = __shfl_xor(bj, off);
+            if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+        }
+        if (lane == 0) { wv[wave] = bv; wj[wave] = bj; }
+        __syncthreads();
+        bv = wv[0];
+        bj = wj[0];
+#pragma unroll
+        for (int w = 1; w < BLOCK / 64; ++w)
+            if (wv[w] > bv || (wv[w] == bv && wj[w] < bj)) { bv = wv[w]; bj = wj[w]; }
+        cur = bj;
+        if (tid == 0) idx[t] = cur;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void group_fwd_kernel(const float *__restrict__ feat, const int32_t *__restrict__ idx,
+                                                           float *__restrict__ out, int c, long total) {
+    for (long t = (long)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (long)gridDim.x * BLOCK) {
+        const long r = t / c;
+        const int ch = (int)(t - r * c);
+        out[t] = feat[(long)idx[r] * c + ch];
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void group_bwd_kernel(const float *__restrict__ go, const int32_t *__restrict__ idx,
+                                                           float *__restrict__ gf, int c, long total) {
+    for (long t = (long)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (long)gridDim.x * BLOCK) {
+        const long r = t / c;
+        const int ch = (int)(t - r * c);
+        atomicAdd(gf + (long)idx[r] * c + ch, go[t]);
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void vec_attn_fwd_kernel(const float *__restrict__ v, const float *__restrict__ pos,
+                                                              const float *__restrict__ w,
+                                                              const int32_t *__restrict__ idx, float *__restrict__ out,
+                                                              int ns, int c, int cw, long total) {
+    for (long t = (long)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (long)gridDim.x * BLOCK) {
+        const long i = t / c;
+        const int ch = (int)(t - i * c);
+        const int wc = ch % cw;
+        float acc = 0.f;
+        for (int j = 0; j < ns; ++j) {
+            const long e = i * ns + j;
+            acc = __builtin_fmaf(v[(long)idx[e] * c + ch] + pos[e * c + ch], w[e * cw + wc], acc);
+        }
+        out[t] = acc;
+    }
+}
+
+// one thread per (i, j, wc): walks the share planes s (ch = s*cw + wc)
+__global__ __launch_bounds__(BLOCK) void vec_attn_bwd_kernel(const float *__restrict__ v, const float *__restrict__ pos,
+                                                              const float *__restrict__ w,
+                                                              const int32_t *__restrict__ idx,
+                                                              const float *__restrict__ go, float *__restrict__ gv,
+                                                              float *__restrict__ gpos, float *__restrict__ gw,
+                                                              int ns, int c, int cw, long total) {
+    for (long t = (long)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (long)gridDim.x * BLOCK) {
+        const long e = t / cw;  // (i, j)
+        const int wc = (int)(t - e * cw);
+        const long i = e / ns;
+        const long src = idx[e];
+        const float wt = w[t];
+        float acc = 0.f;
+        for (int ch = wc; ch < c; ch += cw) {
+            const float g = go[i * c + ch];
+            acc = __builtin_fmaf(g, v[src * c + ch] + pos[e * c + ch], acc);
+            const float gp = g * wt;
+            gpos[e * c + ch] = gp;
+            atomicAdd(gv + src * c + ch, gp);
+        }
+        gw[t] = acc;
+    }
+}
+
+int grid_for(long total) { return (int)((total + BLOCK - 1) / BLOCK > 16384 ? 16384 : (total + BLOCK - 1) / BLOCK); }
+
+}  // namespace
+
+extern "C" int fsg_knn_segment_f32(const float *xyz, const float *new_xyz, const int32_t *offset,
+                                   const int32_t *new_offset, int b, int n, int m, int nsample, int32_t *idx,
+                                   float *dist2, fsg_stream_t stream) {
+    FSG_REQUIRE(xyz && new_xyz && offset && new_offset && idx && dist2, "fsg_knn_segment_f32: NULL pointer");
+    FSG_REQUIRE(b > 0 && n > 0 && m >= 0 && nsample >= 1 && nsample <= 64,
+                "fsg_knn_segment_f32: bad shape b=%d n=%d m=%d nsample=%d", b, n, m, nsample);
+    if (m == 0) return FSG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(fsg_cdiv(m, BLOCK)), block(BLOCK);
+#define FSG_KNNSEG(NS) \
+    hipLaunchKernelGGL(knn_segment_kernel<NS>, grid, block, 0, st, xyz, new_xyz, offset, new_offset, b, m, nsample, idx, dist2)
+    if (nsample <= 4) FSG_KNNSEG(4);
+    else if (nsample <= 8) FSG_KNNSEG(8);
+    else if (nsample <= 16) FSG_KNNSEG(16);
+    else if (nsample <= 32) FSG_KNNSEG(32);
+    else FSG_KNNSEG(64);
+#undef FSG_KNNSEG
+    FSG_CHECK_LAUNCH("fsg_knn_segment_f32");
+    return FSG_OK;
+}
+
+extern "C" int fsg_fps_f32(const float *xyz, const int32_t *offset, const int32_t *new_offset, int b, int n, float *tmp,
+                           int32_t *idx, fsg_stream_t stream) {
+    FSG_REQUIRE(xyz && offset && new_offset && tmp && idx, "fsg_fps_f32: NULL pointer");
+    FSG_REQUIRE(b > 0 && n > 0, "fsg_fps_f32: bad shape b=%d n=%d", b, n);
+    hipLaunchKernelGGL(fps_kernel, dim3(b), dim3(BLOCK), 0, (hipStream_t)stream, xyz, offset, new_offset, tmp, idx);
+    FSG_CHECK_LAUNCH("fsg_fps_f32");
+    return FSG_OK;
+}
+
+extern "C" int fsg_group_gather_fwd_f32(const float *feat, const int32_t *idx, float *out, int n, int c, int m, int ns,
+                                        fsg_stream_t stream) {
+    FSG_REQUIRE(feat && idx && out, "fsg_group_gather_fwd_f32: NULL pointer");
+    FSG_REQUIRE(n > 0 && c > 0 && m >= 0 && ns > 0, "fsg_group_gather_fwd_f32: bad shape");
+    const long total = (long)m * ns * c;
+    if (total == 0) return FSG_OK;
+    hipLaunchKernelGGL(group_fwd_kernel, dim3(grid_for(total)), dim3(BLOCK), 0, (hipStream_t)stream, feat, idx, out, c,
+                       total);
+    FSG_CHECK_LAUNCH("fsg_group_gather_fwd_f32");
+    return FSG_OK;
+}
+
+extern "C" int fsg_group_gather_bwd_f32(const float *grad_out, const int32_t *idx, float *grad_feat, int n, int c, int m,
+                                        int ns, fsg_stream_t stream) {
+    FSG_REQUIRE(grad_out && idx && grad_feat, "fsg_group_gather_bwd_f32: NULL pointer");
+    FSG_REQUIRE(n > 0 && c > 0 && m >= 0 && ns > 0, "fsg_group_gather_bwd_f32: bad shape");
+    const long total = (long)m * ns * c;
+    if (total == 0) return FSG_OK;
+    hipLaunchKernelGGL(group_bwd_kernel, dim3(grid_for(total)), dim3(BLOCK), 0, (hipStream_t)stream, grad_out, idx,
+                       grad_feat, c, total);
+    FSG_CHECK_LAUNCH("fsg_group_gather_bwd_f32");
+    return FSG_OK;
+}
+
+extern "C" int fsg_vec_attn_fwd_f32(const float *v, const float *pos, const float *w, const int32_t *idx, float *out,
+                                    int n, int ns, int c, int cw, fsg_stream_t stream) {
+    FSG_REQUIRE(v && pos && w && idx && out, "fsg_vec_attn_fwd_f32: NULL pointer");
+    FSG_REQUIRE(n >= 0 && ns > 0 && c > 0 && cw > 0 && c % cw == 0, "fsg_vec_attn_fwd_f32: bad shape c=%d cw=%d", c, cw);
+    const long total = (long)n * c;
+    if (total == 0) return FSG_OK;
+    hipLaunchKernelGGL(vec_attn_fwd_kernel, dim3(grid_for(total)), dim3(BLOCK), 0, (hipStream_t)stream, v, pos, w, idx,
+                       out, ns, c, cw, total);
+    FSG_CHECK_LAUNCH("fsg_vec_attn_fwd_f32");
+    return FSG_OK;
+}
+
+extern "C" int fsg_vec_attn_bwd_f32(const float *v, const float *pos, const float *w, const int32_t *idx,
+                                    const float *grad_out, float *grad_v, float *grad_pos, float *grad_w, int n, int ns,
+                                    int c, int cw, fsg_stream_t stream) {
+    FSG_REQUIRE(v && pos && w && idx && grad_out && grad_v && grad_pos && grad_w, "fsg_vec_attn_bwd_f32: NULL pointer");
+    FSG_REQUIRE(n >= 0 && ns > 0 && c > 0 && cw > 0 && c % cw == 0, "fsg_vec_attn_bwd_f32: bad shape c=%d cw=%d", c, cw);
+    const long total = (long)n * ns * cw;
+    if (total == 0) return FSG_OK;
+    hipLaunchKernelGGL(vec_attn_bwd_kernel, dim3(grid_for(total)), dim3(BLOCK), 0, (hipStream_t)stream, v, pos, w, idx,
+                       grad_out, grad_v, grad_pos, grad_w, ns, c, cw, total);
+    FSG_CHECK_LAUNCH("fsg_vec_attn_bwd_f32");
+    return FSG_OK;
+}

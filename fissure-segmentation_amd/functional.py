@@ -1,0 +1,210 @@
+"""Tensor-level entry points over the C ABI: argument checking, output allocation, stream/device
+plumbing and the autograd glue.  Every function requires CUDA (HIP) tensors -- no CPU path."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("fissure_segmentation_amd runs on the GPU only (got a CPU tensor); "
+                               "the CPU restatement lives in oracle/ and is test infrastructure")
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+# ------------------------------------------------------------------ dense kNN (utils/general_utils.py:315)
+def knn_graph(x, k, c_knn=None, fix_diag=True, drop_first=False, return_dist=False):
+    """x: (B,C,N) -> idx (B,N,k) int32 [, dist (B,N,k) fp32].  Channel slices are passed by stride."""
+    _need_gpu(x)
+    if x.dim() != 3:
+        raise ValueError(f"expected (B,C,N), got {tuple(x.shape)}")
+    x = x.detach()
+    if x.dtype != torch.float32:
+        x = x.float()  # the graph is always built in fp32 (precision)
+    if x.stride(2) != 1:
+        x = x.contiguous()
+    B, C, N = x.shape
+    c_knn = C if c_knn is None else c_knn
+    idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
+    dist = torch.empty(B, N, k, dtype=torch.float32, device=x.device) if return_dist else None
+    flags = (_lib.KNN_FIX_DIAG if fix_diag else 0) | (_lib.KNN_DROP_FIRST if drop_first else 0)
+    with torch.cuda.device(x.device):
+        _lib.call("fsg_knn_dense_f32", _p(x), B, N, x.stride(0), x.stride(1), c_knn, k, flags, _p(idx), _p(dist),
+                  _stream())
+    return (idx, dist) if return_dist else idx
+
+
+# ------------------------------------------------------------------ edge features (models/dgcnn.py:31-36)
+class _EdgeGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx):
+        B, C, N = x.shape
+        k = idx.shape[2]
+        xc = _f32c(x)
+        out = torch.empty(B, 2 * C, N, k, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.call("fsg_edge_gather_fwd_f32", _p(xc), _p(idx), _p(out), B, C, N, k, _stream())
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, C, N, k)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        B, C, N, k = ctx.shape
+        g = _f32c(g)
+        gx = torch.empty(B, C, N, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.call("fsg_edge_gather_bwd_f32", _p(g), _p(idx), _p(gx), B, C, N, k, _stream())
+        return gx, None
+
+
+def edge_features(x, idx):
+    """x (B,C,N) fp32, idx (B,N,k) int32/int64 -> (B,2C,N,k) = cat(x_j - x_i, x_i)."""
+    _need_gpu(x, idx)
+    if idx.dtype != torch.int32:
+        idx = idx.to(torch.int32)
+    return _EdgeGather.apply(x, idx.contiguous())
+
+
+# ------------------------------------------------------------------ Chamfer (losses/chamfer_loss.py:19)
+class _ChamferNN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        xc, yc = _f32c(x), _f32c(y)
+        B, N, _ = xc.shape
+        M = yc.shape[1]
+        d = torch.empty(B, N, dtype=torch.float32, device=x.device)
+        a = torch.empty(B, N, dtype=torch.int32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.call("fsg_chamfer_nn_f32", _p(xc), _p(yc), B, N, M, _p(d), _p(a), _stream())
+        ctx.save_for_backward(xc, yc, a)
+        ctx.mark_non_differentiable(a)
+        return d, a
+
+    @staticmethod
+    def backward(ctx, gd, _ga):
+        xc, yc, a = ctx.saved_tensors
+        B, N, _ = xc.shape
+        M = yc.shape[1]
+        gx, gy = torch.zeros_like(xc), torch.zeros_like(yc)
+        with torch.cuda.device(xc.device):
+            _lib.call("fsg_chamfer_nn_bwd_f32", _p(xc), _p(yc), _p(a), _p(_f32c(gd)), B, N, M, _p(gx), _p(gy),
+                      _stream())
+        return gx, gy
+
+
+def chamfer_nn(x, y):
+    """x (B,N,3), y (B,M,3) -> (min squared distance (B,N), argmin (B,N) int32); differentiable in x, y."""
+    _need_gpu(x, y)
+    if x.dim() != 3 or y.dim() != 3 or x.shape[2] != 3 or y.shape[2] != 3 or x.shape[0] != y.shape[0]:
+        raise ValueError(f"expected (B,N,3) and (B,M,3), got {tuple(x.shape)} and {tuple(y.shape)}")
+    return _ChamferNN.apply(x, y)
+
+
+# ------------------------------------------------------------------ packed clouds (pointops.py)
+def knn_segment(nsample, xyz, new_xyz, offset, new_offset):
+    """-> idx (m,nsample) int32, dist2 (m,nsample) squared distances."""
+    _need_gpu(xyz, new_xyz, offset, new_offset)
+    xyz, new_xyz = _f32c(xyz), _f32c(new_xyz)
+    offset, new_offset = offset.to(torch.int32).contiguous(), new_offset.to(torch.int32).contiguous()
+    m = new_xyz.shape[0]
+    idx = torch.empty(m, nsample, dtype=torch.int32, device=xyz.device)
+    d2 = torch.empty(m, nsample, dtype=torch.float32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _lib.call("fsg_knn_segment_f32", _p(xyz), _p(new_xyz), _p(offset), _p(new_offset), offset.shape[0],
+                  xyz.shape[0], m, nsample, _p(idx), _p(d2), _stream())
+    return idx, d2
+
+
+def fps(xyz, offset, new_offset, m):
+    """m = total number of samples (new_offset[-1], known on the host) -> idx (m) int32."""
+    _need_gpu(xyz, offset, new_offset)
+    xyz = _f32c(xyz)
+    offset, new_offset = offset.to(torch.int32).contiguous(), new_offset.to(torch.int32).contiguous()
+    n = xyz.shape[0]
+    idx = torch.zeros(m, dtype=torch.int32, device=xyz.device)
+    tmp = torch.empty(n, dtype=torch.float32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _lib.call("fsg_fps_f32", _p(xyz), _p(offset), _p(new_offset), offset.shape[0], n, _p(tmp), _p(idx), _stream())
+    return idx
+
+
+class _GroupGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, idx):
+        f = _f32c(feat)
+        n, c = f.shape
+        m, ns = idx.shape
+        out = torch.empty(m, ns, c, dtype=torch.float32, device=f.device)
+        with torch.cuda.device(f.device):
+            _lib.call("fsg_group_gather_fwd_f32", _p(f), _p(idx), _p(out), n, c, m, ns, _stream())
+        ctx.save_for_backward(idx)
+        ctx.nc = (n, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        n, c = ctx.nc
+        m, ns = idx.shape
+        g = _f32c(g)
+        gf = torch.zeros(n, c, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.call("fsg_group_gather_bwd_f32", _p(g), _p(idx), _p(gf), n, c, m, ns, _stream())
+        return gf, None
+
+
+def group_gather(feat, idx):
+    """feat (n,c), idx (m,ns) int32 -> (m,ns,c) = feat[idx]."""
+    _need_gpu(feat, idx)
+    return _GroupGather.apply(feat, idx.to(torch.int32).contiguous())
+
+
+class _VecAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, pos, w, idx):
+        v, pos, w = _f32c(v), _f32c(pos), _f32c(w)
+        n, c = v.shape
+        ns, cw = w.shape[1], w.shape[2]
+        out = torch.empty(n, c, dtype=torch.float32, device=v.device)
+        with torch.cuda.device(v.device):
+            _lib.call("fsg_vec_attn_fwd_f32", _p(v), _p(pos), _p(w), _p(idx), _p(out), n, ns, c, cw, _stream())
+        ctx.save_for_backward(v, pos, w, idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        v, pos, w, idx = ctx.saved_tensors
+        n, c = v.shape
+        ns, cw = w.shape[1], w.shape[2]
+        g = _f32c(g)
+        gv = torch.zeros_like(v)
+        gpos = torch.empty_like(pos)
+        gw = torch.empty_like(w)
+        with torch.cuda.device(v.device):
+            _lib.call("fsg_vec_attn_bwd_f32", _p(v), _p(pos), _p(w), _p(idx), _p(g), _p(gv), _p(gpos), _p(gw), n, ns, c,
+                      cw, _stream())
+        return gv, gpos, gw, None
+
+
+def vec_attn(v, pos, w, idx):
+    """out[i,ch] = sum_j (v[idx[i,j],ch] + pos[i,j,ch]) * w[i,j,ch % cw]  (seg_model.py:50-52)."""
+    _need_gpu(v, pos, w, idx)
+    if pos.shape != (v.shape[0], idx.shape[1], v.shape[1]) or w.shape[:2] != pos.shape[:2] or v.shape[1] % w.shape[2]:
+        raise ValueError(f"vec_attn: inconsistent shapes v{tuple(v.shape)} pos{tuple(pos.shape)} w{tuple(w.shape)}")
+    return _VecAttn.apply(v, pos, w, idx.to(torch.int32).contiguous())

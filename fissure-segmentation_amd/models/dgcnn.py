@@ -1,0 +1,207 @@
+"""DGCNN on the HIP path.  Same classes, constructor arguments, forward signatures and state_dict
+keys as the reference's models/dgcnn.py; the graph build, the neighbour gather and the edge tensor
+come from libfsg_hip.so (fsg_knn_dense_f32, fsg_edge_gather_*_f32)."""
+import torch
+from torch import nn
+
+from .. import functional as F_hip
+from ..utils.general_utils import knn
+from ..utils.model_utils import init_weights
+from .point_seg_net import PointSegmentationModelBase
+
+
+def create_neighbor_features(x, k, fixed_knn_graph=None, knn_only_over_coords=False):
+    """(B,C,N) -> (B,2C,N,k) = cat(x_j - x_i, x_i)   (reference: models/dgcnn.py:15-36).
+    Dynamic graphs include the point itself (self_loop=True, :26-27); the first layer builds the graph
+    over the coordinate channels only, passed to the kernel as a strided view (no copy)."""
+    if fixed_knn_graph is None:
+        graph = F_hip.knn_graph(x, k, c_knn=3 if knn_only_over_coords else None, fix_diag=True)
+    else:
+        graph = fixed_knn_graph
+    return F_hip.edge_features(x, graph)
+
+
+class ConvBlock(nn.Module):
+    """1x1 (or k x k) conv -> BatchNorm -> LeakyReLU, module names as models/dgcnn.py:282-315."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=True, dim=2,
+                 negative_slope=1e-2, bn=True, activation=True):
+        super().__init__()
+        try:
+            conv, norm = {1: (nn.Conv1d, nn.BatchNorm1d), 2: (nn.Conv2d, nn.BatchNorm2d),
+                          3: (nn.Conv3d, nn.BatchNorm3d)}[dim]
+        except KeyError:
+            raise ValueError(f'There is no Conv layer for dimensionality {dim}.')
+        mods = [conv(in_channels, out_channels, kernel_size, stride=stride, bias=not bn,
+                     padding=(kernel_size // 2) if padding else 0)]
+        if bn:
+            mods.append(norm(out_channels))
+        if activation:
+            mods.append(nn.LeakyReLU(negative_slope))
+        self.layers = nn.ModuleList(mods)
+
+    def forward(self, x):
+        for layer in self.layers:
+            x = layer(x)
+        return x
+
+
+class SharedFullyConnected(ConvBlock):
+    """models/dgcnn.py:318-323."""
+
+    def __init__(self, in_features, out_features, dim=2, last_layer=False):
+        super().__init__(in_features, out_features, dim=dim, kernel_size=1, padding=False,
+                         bn=not last_layer, activation=not last_layer, negative_slope=0.2)
+
+
+class EdgeConv(nn.Module):
+    """kNN graph -> edge features -> shared MLP -> max over neighbours (models/dgcnn.py:212-243)."""
+
+    def __init__(self, in_features, out_features_list, k, first_layer=False):
+        super().__init__()
+        self.k = k
+        self.first_layer = first_layer
+        widths = [2 * in_features, *out_features_list]
+        self.shared_mlp = nn.ModuleList(SharedFullyConnected(a, b) for a, b in zip(widths[:-1], widths[1:]))
+
+    def forward(self, x, fixed_knn_graph=None):
+        e = create_neighbor_features(x, self.k, fixed_knn_graph, knn_only_over_coords=self.first_layer)
+        for layer in self.shared_mlp:
+            e = layer(e)
+        return e.max(dim=-1)[0]
+
+
+class SpatialTransformer(nn.Module):
+    """models/dgcnn.py:246-279."""
+
+    def __init__(self, k):
+        super().__init__()
+        self.in_features = 3
+        self.ec = EdgeConv(3, [64, 128], k)
+        self.shared_fc = SharedFullyConnected(128, 1024, dim=1)
+        self.mlp = nn.Sequential(nn.Linear(1024, 512), nn.BatchNorm1d(512), nn.LeakyReLU(0.2),
+                                 nn.Linear(512, 256), nn.BatchNorm1d(256), nn.LeakyReLU(0.2))
+        self.transform = nn.Linear(256, 9)
+
+    def forward(self, x, fixed_knn_graph=None):
+        xyz = x[:, :3].contiguous()
+        t = self.shared_fc(self.ec(xyz, fixed_knn_graph)).max(dim=-1)[0]
+        t = self.transform(self.mlp(t)).view(-1, 3, 3)
+        xyz = torch.bmm(xyz.transpose(1, 2), t).transpose(1, 2)
+        return torch.cat([xyz, x[:, 3:]], dim=1)
+
+    def init_weights(self):
+        self.apply(init_weights)
+        nn.init.zeros_(self.transform.weight)
+        nn.init.eye_(self.transform.bias.view(3, 3))
+
+
+class ImageFeatures(nn.Module):
+    """models/dgcnn.py:326-343: point-wise MLP on the non-coordinate channels."""
+
+    def __init__(self, in_channels=6, out_channels=(6, 12), kernel_size=1):
+        super().__init__()
+        chans = [in_channels, *out_channels]
+        self.layers = nn.ModuleList(ConvBlock(a, b, kernel_size=kernel_size, dim=1)
+                                    for a, b in zip(chans[:-1], chans[1:]))
+
+    def forward(self, x):
+        f = x[:, 3:]
+        for layer in self.layers:
+            f = layer(f)
+        return torch.cat([x[:, :3], f], dim=1)
+
+
+class DGCNNBase(PointSegmentationModelBase):
+    """models/dgcnn.py:61-112."""
+
+    def __init__(self, k, in_features, num_classes, spatial_transformer=False, dynamic=True,
+                 image_feat_module=False):
+        super().__init__(in_features, num_classes, k=k, spatial_transformer=spatial_transformer,
+                         dynamic=dynamic, image_feat_module=image_feat_module)
+        self.k = k
+        self.dynamic = dynamic
+        self.knn_graph = None
+        if image_feat_module:
+            if in_features < 4:
+                raise ValueError('Number of In-Features for DGCNN too low if you want to use the image feature '
+                                 'module! Need at 3, as the first 3 are assumed to be the point coordinates.')
+            self.image_feature_module = ImageFeatures(in_channels=in_features - 3, out_channels=(6, 12))
+            self.in_features = 3 + 12
+        else:
+            self.image_feature_module = None
+        self.spatial_transformer = SpatialTransformer(k) if spatial_transformer else None
+        self.output_activation = nn.Identity()
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("DGCNN (HIP path) needs its input on the GPU")
+        if not self.dynamic:  # static graph over the coordinates, self excluded (:95-96)
+            self.knn_graph = F_hip.knn_graph(x, self.k, c_knn=3, fix_diag=True, drop_first=True)
+        if self.image_feature_module is not None:
+            x = self.image_feature_module(x)
+        if self.spatial_transformer is not None:
+            x = self.spatial_transformer(x)
+        return x
+
+    def init_weights(self):
+        self.apply(init_weights)
+        if self.spatial_transformer is not None:
+            self.spatial_transformer.init_weights()
+
+
+class DGCNNSeg(DGCNNBase):
+    """models/dgcnn.py:115-162."""
+
+    def __init__(self, k, in_features, num_classes, spatial_transformer=False, dynamic=True,
+                 image_feat_module=False):
+        super().__init__(k, in_features, num_classes, spatial_transformer, dynamic, image_feat_module)
+        self.ec1 = EdgeConv(self.in_features, [64, 64], k, first_layer=True)
+        self.ec2 = EdgeConv(64, [64], k)
+        self.ec3 = EdgeConv(64, [64], k)
+        self.global_feature = nn.Sequential(SharedFullyConnected(192, 1024, dim=1), nn.AdaptiveMaxPool1d(1))
+        self.segmentation = nn.Sequential(SharedFullyConnected(192 + 1024, 256, dim=1),
+                                          SharedFullyConnected(256, 256, dim=1),
+                                          SharedFullyConnected(256, 128, dim=1),
+                                          SharedFullyConnected(128, self.num_classes, dim=1, last_layer=True))
+        self.init_weights()
+
+    def forward(self, x):
+        x = super().forward(x)
+        x1 = self.ec1(x, self.knn_graph)
+        x2 = self.ec2(x1, self.knn_graph)
+        x3 = self.ec3(x2, self.knn_graph)
+        levels = torch.cat([x1, x2, x3], dim=1)
+        g = self.global_feature(levels)
+        return self.segmentation(torch.cat([levels, g.expand(-1, -1, levels.shape[-1])], dim=1))
+
+
+class DGCNNReg(DGCNNBase):
+    """models/dgcnn.py:165-209."""
+
+    def __init__(self, k, in_features, num_classes, spatial_transformer=False, dynamic=True,
+                 image_feat_module=False):
+        super().__init__(k, in_features, num_classes, spatial_transformer, dynamic, image_feat_module)
+        self.ec1 = EdgeConv(self.in_features, [64], k, first_layer=True)
+        self.ec2 = EdgeConv(64, [64], k)
+        self.ec3 = EdgeConv(64, [128], k)
+        self.ec4 = EdgeConv(128, [256], k)
+        self.global_feature = nn.Sequential(SharedFullyConnected(512, 1024, dim=1), nn.AdaptiveMaxPool1d(1))
+        self.regression = nn.Sequential(SharedFullyConnected(1024, 512, dim=1),
+                                        SharedFullyConnected(512, 256, dim=1),
+                                        SharedFullyConnected(256, self.num_classes, dim=1, last_layer=True))
+        self.init_weights()
+
+    def forward(self, x):
+        x = super().forward(x)
+        feats = []
+        for ec in (self.ec1, self.ec2, self.ec3, self.ec4):
+            x = ec(x, self.knn_graph)
+            feats.append(x)
+        return self.regression(self.global_feature(torch.cat(feats, dim=1)))
+
+    def predict_full_pointcloud(self, pc, sample_points=1024, n_runs_min=50):
+        acc = torch.zeros(pc.shape[0], self.num_classes, 1, device=pc.device)
+        for _ in range(n_runs_min):
+            acc += self(pc[..., torch.randperm(pc.shape[-1], device=pc.device)[:sample_points]])
+        return acc / n_runs_min

@@ -1,0 +1,155 @@
+"""Point-cloud auto-encoder (DGCNN encoder + folding / deforming decoder) on the HIP path.
+Same classes, arguments and state_dict keys as the reference's models/folding_net.py; the encoder's
+four graph builds + gathers run in libfsg_hip.so.  Mesh output (pytorch3d `Meshes`) is out of scope:
+`decode_mesh=True` uses the mesh-vertex grid of get_plane_mesh but returns the (B,3,m) vertices."""
+import torch
+from torch import nn
+
+from .. import functional as F_hip
+from ..shapes.shape_constructor import get_gaussian, get_plane, get_plane_mesh, get_sphere
+from .dgcnn import SharedFullyConnected
+from .dgcnn_opensrc import get_graph_feature
+from .modelio import LoadableModel, store_config_args
+
+SHAPE_TYPES = ['sphere', 'gaussian', 'plane']
+
+
+class DGCNN_Cls_Encoder(LoadableModel):
+    """folding_net.py:83-141 (the BatchNorms are registered twice there -- `bnX` and `convX.1` -- and
+    therefore appear under both names in the state_dict; kept)."""
+
+    @store_config_args
+    def __init__(self, k, n_embedding, static=False):
+        super().__init__()
+        self.static, self.k, self.n_embedding = static, k, n_embedding
+        self.bn1, self.bn2, self.bn3, self.bn4 = (nn.BatchNorm2d(c) for c in (64, 64, 128, 256))
+        self.bn5 = nn.BatchNorm1d(n_embedding)
+        act = lambda: nn.LeakyReLU(negative_slope=0.2)  # noqa: E731
+        self.conv1 = nn.Sequential(nn.Conv2d(6, 64, 1, bias=False), self.bn1, act())
+        self.conv2 = nn.Sequential(nn.Conv2d(128, 64, 1, bias=False), self.bn2, act())
+        self.conv3 = nn.Sequential(nn.Conv2d(128, 128, 1, bias=False), self.bn3, act())
+        self.conv4 = nn.Sequential(nn.Conv2d(256, 256, 1, bias=False), self.bn4, act())
+        self.conv5 = nn.Sequential(nn.Conv1d(512, n_embedding, 1, bias=False), self.bn5, act())
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("PC-AE encoder (HIP path) needs its input on the GPU")
+        graph = F_hip.knn_graph(x, self.k, c_knn=3, fix_diag=False) if self.static else None
+        feats = []
+        for conv in (self.conv1, self.conv2, self.conv3, self.conv4):
+            x = conv(get_graph_feature(x, k=self.k, idx=graph)).max(dim=-1)[0]
+            feats.append(x)
+        return self.conv5(torch.cat(feats, dim=1)).max(dim=-1)[0].unsqueeze(1)  # (B, 1, n_embedding)
+
+
+class Decoder(LoadableModel):
+    """folding_net.py:144-183."""
+
+    @store_config_args
+    def __init__(self, shape_type, m=1024, decode_mesh=True):
+        super().__init__()
+        self.m, self.shape_type, self.decode_mesh = m, shape_type, decode_mesh
+        self.folding_points = None
+        self.faces = None
+
+    def get_folding_points(self, batch_size):
+        if self.folding_points is None or self.folding_points.shape[0] != batch_size:
+            device = next(self.parameters()).device
+            if self.shape_type == 'plane':
+                if self.decode_mesh:
+                    pts, faces = get_plane_mesh(n=self.m, xrange=(-0.3, 0.3), yrange=(-0.3, 0.3))
+                    self.faces = faces.unsqueeze(0).expand(batch_size, -1, -1).to(device)
+                else:
+                    pts = torch.from_numpy(get_plane())
+            elif self.shape_type == 'sphere':
+                if self.decode_mesh:
+                    raise NotImplementedError('No sphere mesh defined yet')
+                pts = torch.from_numpy(get_sphere())
+            elif self.shape_type == 'gaussian':
+                if self.decode_mesh:
+                    raise ValueError('No gaussian mesh is possible.')
+                pts = torch.from_numpy(get_gaussian())
+            else:
+                raise ValueError(f'No shape named "{self.shape_type}". Use one of {SHAPE_TYPES}.')
+            self.folding_points = pts.unsqueeze(0).repeat(batch_size, 1, 1).to(device).float()
+        return self.folding_points
+
+
+def _fold_mlp(cin, width):
+    return nn.Sequential(nn.Conv1d(cin, width, 1), nn.ReLU(), nn.Conv1d(width, width, 1), nn.ReLU(),
+                         nn.Conv1d(width, 3, 1))
+
+
+class FoldingDecoder(Decoder):
+    """folding_net.py:186-228."""
+
+    @store_config_args
+    def __init__(self, n_embedding, shape_type, m=1024, decode_mesh=True):
+        super().__init__(shape_type, m, decode_mesh)
+        self.folding1 = _fold_mlp(n_embedding + (2 if shape_type == 'plane' else 3), n_embedding)
+        self.folding2 = _fold_mlp(n_embedding + 3, n_embedding)
+
+    def forward(self, x):
+        z = x.transpose(1, 2).expand(-1, -1, self.m)
+        grid = self.get_folding_points(x.shape[0]).transpose(1, 2).to(x.device)
+        first = self.folding1(torch.cat((z, grid), dim=1))
+        return self.folding2(torch.cat((z, first), dim=1))
+
+
+def _deform_mlp(width):
+    return nn.Sequential(SharedFullyConnected(width + 3, width, dim=1), SharedFullyConnected(width, width, dim=1),
+                         SharedFullyConnected(width, 3, dim=1, last_layer=True))
+
+
+class DeformingDecoder(Decoder):
+    """folding_net.py:231-288."""
+
+    @store_config_args
+    def __init__(self, n_embedding, shape_type, m=1024, decode_mesh=True, n_deforming_layers=2):
+        super().__init__(shape_type, m, decode_mesh)
+        if n_deforming_layers == 2:  # keeps the key names of older checkpoints (:236-250)
+            self.deforming1, self.deforming2 = _deform_mlp(n_embedding), _deform_mlp(n_embedding)
+            self.deforming_layers = nn.ModuleList([self.deforming1, self.deforming2])
+        else:
+            self.deforming_layers = nn.ModuleList(_deform_mlp(n_embedding) for _ in range(n_deforming_layers))
+
+    def get_folding_points(self, batch_size):
+        pts = super().get_folding_points(batch_size)
+        if pts.shape[2] == 2:
+            pts = torch.cat([pts, torch.zeros(*pts.shape[:2], 1, device=pts.device)], dim=2)
+        return pts
+
+    def forward(self, x):
+        z = x.transpose(1, 2).expand(-1, -1, self.m)
+        pts = self.get_folding_points(x.shape[0]).transpose(1, 2).to(x.device)
+        for layer in self.deforming_layers:
+            pts = pts + layer(torch.cat((z, pts), dim=1))
+        return pts
+
+
+class DGCNNFoldingNet(LoadableModel):
+    """folding_net.py:42-79."""
+
+    @store_config_args
+    def __init__(self, k, n_embedding, shape_type, n_input_points=1024, decode_mesh=True, deform=False,
+                 static=False, dec_depth=2):
+        super().__init__()
+        self.encoder = DGCNN_Cls_Encoder(k, n_embedding, static=static)
+        self.n_input_points = n_input_points
+        m = int(round(float(n_input_points) ** 0.5)) ** 2  # closest square number (:51)
+        if deform:
+            self.decoder = DeformingDecoder(n_embedding, shape_type, m, decode_mesh, n_deforming_layers=dec_depth)
+        else:
+            self.decoder = FoldingDecoder(n_embedding, shape_type, m, decode_mesh)
+
+    def forward(self, x, return_hidden=False):
+        h = self.encoder(x)
+        out = self.decoder(h)
+        return (out, h) if return_hidden else out
+
+    def predict_full_pointcloud(self, pc, sample_points=1024, n_runs=50):
+        acc = torch.zeros(pc.shape[0], self.decoder.m, 3, device=pc.device)
+        for _ in range(n_runs):
+            perm = torch.randperm(pc.shape[1], device=pc.device)[:sample_points]
+            acc += self(pc[:, perm].transpose(1, 2)).transpose(1, 2)
+        return acc / n_runs

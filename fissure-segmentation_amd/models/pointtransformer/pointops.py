@@ -1,0 +1,92 @@
+"""PointTransformer point operations on the HIP kernels -- the role `pointops_cuda` plays behind the
+reference's models/pointtransformer/pointops.py.  Packed layout: xyz (n,3), feat (n,c), `offset` (b)
+int32 cumulative segment ends.  Same function names and argument order as the reference."""
+import torch
+
+from ... import functional as F_hip
+
+_knn_memo = None  # {(xyz ptr, new_xyz ptr, offsets ptr, nsample): (idx, dist)}, alive inside knn_cache()
+
+
+class knn_cache:
+    """Within one forward the reference queries the same (points, nsample) graph again and again (twice
+    per layer, seg_model.py:38-39, and once per block of a level).  Inside this context the query
+    runs once per distinct (xyz, new_xyz, offset, nsample)."""
+
+    def __enter__(self):
+        global _knn_memo
+        self._outer, _knn_memo = _knn_memo, {}
+        return self
+
+    def __exit__(self, *exc):
+        global _knn_memo
+        _knn_memo = self._outer
+
+
+def host_offsets(o):
+    """Segment ends as a Python list without a device sync when the producer attached them."""
+    cached = getattr(o, "_fsg_host", None)
+    if cached is None:
+        cached = [int(v) for v in o.tolist()]
+        o._fsg_host = cached
+    return cached
+
+
+def with_host_offsets(o, values):
+    o._fsg_host = [int(v) for v in values]
+    return o
+
+
+def furthestsampling(xyz, offset, new_offset):
+    """pointops.py:16-39 -> idx (m) int32."""
+    assert xyz.is_contiguous()
+    return F_hip.fps(xyz, offset, new_offset, host_offsets(new_offset)[-1])
+
+
+def knnquery(nsample, xyz, new_xyz, offset, new_offset):
+    """pointops.py:42-62 -> (idx (m,nsample) int32, distance (m,nsample)); not differentiable."""
+    if new_xyz is None:
+        new_xyz = xyz
+    assert xyz.is_contiguous() and new_xyz.is_contiguous()
+    key = (xyz.data_ptr(), new_xyz.data_ptr(), offset.data_ptr(), new_offset.data_ptr(), xyz.shape[0],
+           new_xyz.shape[0], nsample)
+    if _knn_memo is not None and key in _knn_memo:
+        return _knn_memo[key]
+    idx, d2 = F_hip.knn_segment(nsample, xyz, new_xyz, offset, new_offset)
+    out = (idx, torch.sqrt(d2))
+    if _knn_memo is not None:
+        _knn_memo[key] = out
+    return out
+
+
+def grouping(input, idx):
+    """pointops.py:65-97: (n,c), (m,nsample) -> (m,nsample,c); backward scatter-adds."""
+    return F_hip.group_gather(input, idx)
+
+
+def queryandgroup(nsample, xyz, new_xyz, feat, idx, offset, new_offset, use_xyz=True):
+    """pointops.py:100-123 -> (m,nsample,3+c) or (m,nsample,c)."""
+    if new_xyz is None:
+        new_xyz = xyz
+    assert xyz.is_contiguous() and new_xyz.is_contiguous() and feat.is_contiguous()
+    if idx is None:
+        idx, _ = knnquery(nsample, xyz, new_xyz, offset, new_offset)
+    grouped_feat = grouping(feat, idx)
+    if not use_xyz:
+        return grouped_feat
+    grouped_xyz = grouping(xyz, idx) - new_xyz.unsqueeze(1)
+    return torch.cat((grouped_xyz, grouped_feat), -1)
+
+
+def aggregation(input, position, weight, idx):
+    """pointops.py:161-195: out[i,c] = sum_j (input[idx[i,j],c] + position[i,j,c]) * weight[i,j,c % c']."""
+    return F_hip.vec_attn(input, position, weight, idx)
+
+
+def interpolation(xyz, new_xyz, feat, offset, new_offset, k=3):
+    """pointops.py:198-215: inverse-distance interpolation from the k nearest coarse points."""
+    assert xyz.is_contiguous() and new_xyz.is_contiguous() and feat.is_contiguous()
+    idx, dist = knnquery(k, xyz, new_xyz, offset, new_offset)
+    w = 1.0 / (dist + 1e-8)
+    w = w / w.sum(dim=1, keepdim=True)
+    return (grouping(feat, idx) * w.unsqueeze(-1)).sum(dim=1)

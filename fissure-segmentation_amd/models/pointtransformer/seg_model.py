@@ -1,0 +1,201 @@
+"""PointTransformer segmentation net on the HIP path (reference: models/pointtransformer/seg_model.py).
+Same module tree / state_dict keys; kNN queries, farthest point sampling, neighbour grouping and the
+vector-attention aggregate run in libfsg_hip.so.  Host syncs of the reference (`.item()` loops at
+:71-75, :104-112) are gone: segment sizes travel with the offsets on the host."""
+import torch
+import torch.nn as nn
+
+from ..point_seg_net import PointSegmentationModelBase
+from . import pointops
+
+
+class PointTransformerLayer(nn.Module):
+    """Vector attention over the nsample nearest neighbours (seg_model.py:17-53)."""
+
+    def __init__(self, in_planes, out_planes, share_planes=8, nsample=16):
+        super().__init__()
+        self.mid_planes = mid_planes = out_planes // 1
+        self.out_planes, self.share_planes, self.nsample = out_planes, share_planes, nsample
+        self.linear_q = nn.Linear(in_planes, mid_planes)
+        self.linear_k = nn.Linear(in_planes, mid_planes)
+        self.linear_v = nn.Linear(in_planes, out_planes)
+        self.linear_p = nn.Sequential(nn.Linear(3, 3), nn.BatchNorm1d(3), nn.ReLU(inplace=True),
+                                      nn.Linear(3, out_planes))
+        self.linear_w = nn.Sequential(nn.BatchNorm1d(mid_planes), nn.ReLU(inplace=True),
+                                      nn.Linear(mid_planes, mid_planes // share_planes),
+                                      nn.BatchNorm1d(mid_planes // share_planes), nn.ReLU(inplace=True),
+                                      nn.Linear(out_planes // share_planes, out_planes // share_planes))
+        self.softmax = nn.Softmax(dim=1)
+
+    @staticmethod
+    def _bn_over_neighbours(bn, t):
+        # BatchNorm1d on the (n, channels, nsample) view == statistics over n*nsample rows (:42,:47)
+        n, ns, c = t.shape
+        return bn(t.reshape(n * ns, c)).view(n, ns, c)
+
+    def forward(self, pxo):
+        p, x, o = pxo
+        q, k, v = self.linear_q(x), self.linear_k(x), self.linear_v(x)
+        idx, _ = pointops.knnquery(self.nsample, p, p, o, o)  # one graph for keys and values
+        rel = pointops.grouping(p, idx) - p.unsqueeze(1)       # (n, ns, 3)
+        gk = pointops.grouping(k, idx)                         # (n, ns, c)
+        lin1, bn, act, lin2 = self.linear_p
+        pr = lin2(act(self._bn_over_neighbours(bn, lin1(rel))))
+        w = gk - q.unsqueeze(1) + pr
+        bn1, act1, lw1, bn2, act2, lw2 = self.linear_w
+        w = lw1(act1(self._bn_over_neighbours(bn1, w)))
+        w = lw2(act2(self._bn_over_neighbours(bn2, w)))
+        w = self.softmax(w)                                    # over the neighbours
+        return pointops.aggregation(v, pr, w, idx)             # (n, c)
+
+
+class TransitionDown(nn.Module):
+    """seg_model.py:56-84: FPS to n/stride points, group nsample neighbours, Linear-BN-ReLU-maxpool."""
+
+    def __init__(self, in_planes, out_planes, stride=1, nsample=16):
+        super().__init__()
+        self.stride, self.nsample = stride, nsample
+        if stride != 1:
+            self.linear = nn.Linear(3 + in_planes, out_planes, bias=False)
+            self.pool = nn.MaxPool1d(nsample)
+        else:
+            self.linear = nn.Linear(in_planes, out_planes, bias=False)
+        self.bn = nn.BatchNorm1d(out_planes)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, pxo):
+        p, x, o = pxo
+        if self.stride == 1:
+            return [p, self.relu(self.bn(self.linear(x))), o]
+        ends = pointops.host_offsets(o)
+        new_ends, prev, total = [], 0, 0
+        for e in ends:
+            total += (e - prev) // self.stride
+            new_ends.append(total)
+            prev = e
+        n_o = pointops.with_host_offsets(torch.tensor(new_ends, device=p.device, dtype=o.dtype), new_ends)
+        idx = pointops.furthestsampling(p, o, n_o)
+        n_p = p[idx.long(), :].contiguous()
+        g = pointops.queryandgroup(self.nsample, p, n_p, x, None, o, n_o, use_xyz=True)  # (m, ns, 3+c)
+        m, ns, c = g.shape
+        y = self.relu(self.bn(self.linear(g).reshape(m * ns, -1))).view(m, ns, -1)
+        return [n_p, y.max(dim=1)[0], n_o]
+
+
+class TransitionUp(nn.Module):
+    """seg_model.py:87-118."""
+
+    def __init__(self, in_planes, out_planes=None):
+        super().__init__()
+        if out_planes is None:
+            self.linear1 = nn.Sequential(nn.Linear(2 * in_planes, in_planes), nn.BatchNorm1d(in_planes),
+                                         nn.ReLU(inplace=True))
+            self.linear2 = nn.Sequential(nn.Linear(in_planes, in_planes), nn.ReLU(inplace=True))
+        else:
+            self.linear1 = nn.Sequential(nn.Linear(out_planes, out_planes), nn.BatchNorm1d(out_planes),
+                                         nn.ReLU(inplace=True))
+            self.linear2 = nn.Sequential(nn.Linear(in_planes, out_planes), nn.BatchNorm1d(out_planes),
+                                         nn.ReLU(inplace=True))
+
+    def forward(self, pxo1, pxo2=None):
+        if pxo2 is None:  # head: concat every point with its cloud's mean feature (:101-113)
+            _, x, o = pxo1
+            ends = pointops.host_offsets(o)
+            counts = torch.tensor([e - s for s, e in zip([0] + ends[:-1], ends)], device=x.device)
+            seg = torch.repeat_interleave(torch.arange(len(ends), device=x.device), counts, output_size=ends[-1])
+            mean = torch.zeros(len(ends), x.shape[1], device=x.device, dtype=x.dtype).index_add_(0, seg, x)
+            mean = mean / counts.unsqueeze(1).to(x.dtype)
+            return self.linear1(torch.cat((x, self.linear2(mean)[seg]), dim=1))
+        p1, x1, o1 = pxo1
+        p2, x2, o2 = pxo2
+        return self.linear1(x1) + pointops.interpolation(p2, p1, self.linear2(x2), o2, o1)
+
+
+class PointTransformerBlock(nn.Module):
+    """seg_model.py:121-142."""
+    expansion = 1
+
+    def __init__(self, in_planes, planes, share_planes=8, nsample=16):
+        super().__init__()
+        self.linear1 = nn.Linear(in_planes, planes, bias=False)
+        self.bn1 = nn.BatchNorm1d(planes)
+        self.transformer2 = PointTransformerLayer(planes, planes, share_planes, nsample)
+        self.bn2 = nn.BatchNorm1d(planes)
+        self.linear3 = nn.Linear(planes, planes * self.expansion, bias=False)
+        self.bn3 = nn.BatchNorm1d(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, pxo):
+        p, x, o = pxo
+        y = self.relu(self.bn1(self.linear1(x)))
+        y = self.relu(self.bn2(self.transformer2([p, y, o])))
+        return [p, self.relu(self.bn3(self.linear3(y)) + x), o]
+
+
+class PointTransformerSeg(nn.Module):
+    """U-Net of seg_model.py:145-207: planes 32/64/128/256/512, strides 1/4/4/4/4, nsample 8/16/16/16/16."""
+
+    def __init__(self, block, blocks, c=6, k=13):
+        super().__init__()
+        self.c = c
+        self.in_planes, planes = c, [32, 64, 128, 256, 512]
+        share_planes, stride, nsample = 8, [1, 4, 4, 4, 4], [8, 16, 16, 16, 16]
+        for lvl in range(5):
+            setattr(self, f'enc{lvl + 1}', self._make_enc(block, planes[lvl], blocks[lvl], share_planes,
+                                                          stride[lvl], nsample[lvl]))
+        for lvl in range(4, -1, -1):
+            setattr(self, f'dec{lvl + 1}', self._make_dec(block, planes[lvl], 2, share_planes, nsample[lvl],
+                                                          is_head=(lvl == 4)))
+        self.cls = nn.Sequential(nn.Linear(planes[0], planes[0]), nn.BatchNorm1d(planes[0]), nn.ReLU(inplace=True),
+                                 nn.Linear(planes[0], k))
+
+    def _make_enc(self, block, planes, blocks, share_planes=8, stride=1, nsample=16):
+        mods = [TransitionDown(self.in_planes, planes * block.expansion, stride, nsample)]
+        self.in_planes = planes * block.expansion
+        mods += [block(self.in_planes, self.in_planes, share_planes, nsample=nsample) for _ in range(1, blocks)]
+        return nn.Sequential(*mods)
+
+    def _make_dec(self, block, planes, blocks, share_planes=8, nsample=16, is_head=False):
+        mods = [TransitionUp(self.in_planes, None if is_head else planes * block.expansion)]
+        self.in_planes = planes * block.expansion
+        mods += [block(self.in_planes, self.in_planes, share_planes, nsample=nsample) for _ in range(1, blocks)]
+        return nn.Sequential(*mods)
+
+    def forward(self, pxo):
+        p0, x0, o0 = pxo
+        if not p0.is_cuda:
+            raise RuntimeError("PointTransformer (HIP path) needs its input on the GPU")
+        x0 = p0 if self.c == 3 else torch.cat((p0, x0), 1)
+        with pointops.knn_cache():
+            levels = [self.enc1([p0, x0, o0])]
+            for lvl in range(2, 6):
+                levels.append(getattr(self, f'enc{lvl}')(levels[-1]))
+            p, x, o = levels[4]
+            coarse = [p, self.dec5[1:]([p, self.dec5[0]([p, x, o]), o])[1], o]
+            for lvl in range(3, -1, -1):
+                p, x, o = levels[lvl]
+                dec = getattr(self, f'dec{lvl + 1}')
+                coarse = [p, dec[1:]([p, dec[0]([p, x, o], coarse), o])[1], o]
+        return self.cls(coarse[1])
+
+
+def pointtransformer_seg_repro(**kwargs):
+    return PointTransformerSeg(PointTransformerBlock, [2, 3, 4, 6, 3], **kwargs)
+
+
+class PointTransformerCompatibility(PointSegmentationModelBase):
+    """(B,C,N) <-> packed adaptor of seg_model.py:215-231; the first three channels are coordinates."""
+
+    def __init__(self, in_features, num_classes, **kwargs):
+        super().__init__(in_features, num_classes)
+        self.point_transformer = pointtransformer_seg_repro(c=in_features, k=num_classes)
+
+    def forward(self, x):
+        bs, n_feat, npts = x.shape
+        flat = x.transpose(1, 2).reshape(-1, n_feat)
+        coords = flat[:, :3].contiguous()
+        feat = flat[:, 3:].contiguous()
+        ends = [(i + 1) * npts for i in range(bs)]
+        offsets = pointops.with_host_offsets(torch.tensor(ends, dtype=torch.int32, device=x.device), ends)
+        out = self.point_transformer([coords, feat, offsets])
+        return out.reshape(bs, npts, -1).transpose(1, 2)

@@ -1,0 +1,122 @@
+/*
+ * fsg_hip.h -- C ABI of libfsg_hip.so: the MI355X (gfx950) hot path of kaftanski/fissure-segmentation.
+ *
+ * The reference has no FFI of its own: its seam is the Python nn.Module API.  This
+ * header is the boundary that sits UNDER that API; each entry point names the reference code it
+ * replaces (paths relative to the reference checkout).  Conventions:
+ *   - plain C, no torch types; every pointer is a DEVICE pointer owned by the caller (hipMalloc'd /
+ *     torch storage) unless marked "host"; nothing is allocated or freed inside the library;
+ *   - row-major contiguous tensors unless explicit element strides are passed;
+ *   - `stream` is a hipStream_t (NULL = default stream); calls are asynchronous on that stream and
+ *     keep no global state, so the library is re-entrant per stream (one process per GPU under DDP);
+ *   - return value: FSG_OK or an FSG_ERR_* code; fsg_last_error() gives the text for the calling
+ *     thread.  Nothing throws across the boundary.
+ */
+#ifndef FSG_HIP_H
+#define FSG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSG_OK 0
+#define FSG_ERR_ARG 1         /* bad shape / NULL pointer / unsupported size */
+#define FSG_ERR_HIP 2         /* a HIP runtime call or launch failed          */
+#define FSG_ERR_UNSUPPORTED 3 /* valid request this build cannot serve        */
+
+#define FSG_KNN_FIX_DIAG 1   /* force d(i,i) = 0          -- utils/general_utils.py:52            */
+#define FSG_KNN_DROP_FIRST 2 /* select k+1, drop column 0 -- utils/general_utils.py:317,320-322   */
+
+#define FSG_KNN_MAX_K 64
+
+typedef void *fsg_stream_t;
+
+int fsg_version(void);
+const char *fsg_last_error(void);
+
+/*
+ * Dense kNN graph build: replaces utils/general_utils.py:43-53 (pairwise_dist), :315-327 (knn) and
+ * models/dgcnn_opensrc.py:34-40 (knn; flags = 0).  The (B,N,N) distance matrix is never materialised.
+ *   x        (B, C, N) fp32, element strides (stride_b, stride_c, 1) -- a channel slice x[:, :3]
+ *            is passed without a copy; only channels [0, c_knn) enter the distance
+ *   idx_out  (B, N, k) int32, ascending (distance, index)
+ *   dist_out (B, N, k) fp32 or NULL
+ * Arithmetic: d = (xx_i - 2 * dot_ij) + xx_j, dot/xx as channel-ordered fp32 fma chains.
+ * Limits: 1 <= k, k + drop <= min(N, FSG_KNN_MAX_K); N <= 32768.
+ */
+int fsg_knn_dense_f32(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn,
+                      int k, int flags, int32_t *idx_out, float *dist_out, fsg_stream_t stream);
+
+/*
+ * Edge features: replaces models/dgcnn.py:31-36 (create_neighbor_features: take_along_dim, repeat,
+ * cat) and models/dgcnn_opensrc.py:43-66 (get_graph_feature).
+ *   x (B,C,N) fp32, idx (B,N,k) int32 -> edge (B,2C,N,k): [x_j - x_i ; x_i]
+ * _bwd is the autograd transpose: grad_edge (B,2C,N,k) -> grad_x (B,C,N), overwritten.
+ */
+int fsg_edge_gather_fwd_f32(const float *x, const int32_t *idx, float *edge, int B, int C, int N,
+                            int k, fsg_stream_t stream);
+int fsg_edge_gather_bwd_f32(const float *grad_edge, const int32_t *idx, float *grad_x, int B, int C,
+                            int N, int k, fsg_stream_t stream);
+
+/*
+ * Chamfer nearest neighbour, one direction: replaces the pytorch3d.loss.chamfer_distance call of
+ * losses/chamfer_loss.py:19 (and losses/mesh_loss.py:29-31, train_pc_ae.py:88).
+ *   x (B,N,3), y (B,M,3) fp32 -> dist (B,N) = min_j |x_i - y_j|^2, arg (B,N) int32 (lowest j on ties)
+ * _bwd: given g = dLoss/d dist (B,N) and arg, ACCUMULATES into grad_x (B,N,3) and grad_y (B,M,3)
+ *   grad_x[i] += 2 g_i (x_i - y_arg) ; grad_y[arg] -= 2 g_i (x_i - y_arg)      (caller zero-fills)
+ */
+int fsg_chamfer_nn_f32(const float *x, const float *y, int B, int N, int M, float *dist,
+                       int32_t *arg, fsg_stream_t stream);
+int fsg_chamfer_nn_bwd_f32(const float *x, const float *y, const int32_t *arg, const float *g_dist,
+                           int B, int N, int M, float *grad_x, float *grad_y, fsg_stream_t stream);
+
+/*
+ * Packed-segment kNN query: replaces pointops_cuda.knnquery_cuda behind
+ * models/pointtransformer/pointops.py:42-62.
+ *   xyz (n,3), new_xyz (m,3) fp32; offset / new_offset (b) int32 cumulative segment ends
+ *   idx (m,nsample) int32 global row numbers, dist2 (m,nsample) SQUARED distances, ascending
+ *   (the Python wrapper returns sqrt, as pointops.py:60 does).  Segments shorter than nsample are
+ *   padded with (first row of the segment, 1e10).   nsample <= 64.
+ */
+int fsg_knn_segment_f32(const float *xyz, const float *new_xyz, const int32_t *offset,
+                        const int32_t *new_offset, int b, int n, int m, int nsample, int32_t *idx,
+                        float *dist2, fsg_stream_t stream);
+
+/*
+ * Farthest point sampling per segment: replaces pointops_cuda.furthestsampling_cuda behind
+ * models/pointtransformer/pointops.py:16-39.   tmp: (n) fp32 scratch (the reference's `tmp`),
+ * idx: (new_offset[b-1]) int32.  First sample of a segment = its first row; ties -> lowest index.
+ */
+int fsg_fps_f32(const float *xyz, const int32_t *offset, const int32_t *new_offset, int b, int n,
+                float *tmp, int32_t *idx, fsg_stream_t stream);
+
+/*
+ * Row gather / scatter-add by neighbour index: replaces the fancy-index grouping of
+ * models/pointtransformer/pointops.py:114-118 (and pointops_cuda.grouping_*, :78,:94).
+ *   feat (n,c), idx (m,ns) -> out (m,ns,c) = feat[idx]       ; bwd ACCUMULATES into grad_feat (n,c)
+ */
+int fsg_group_gather_fwd_f32(const float *feat, const int32_t *idx, float *out, int n, int c, int m,
+                             int ns, fsg_stream_t stream);
+int fsg_group_gather_bwd_f32(const float *grad_out, const int32_t *idx, float *grad_feat, int n,
+                             int c, int m, int ns, fsg_stream_t stream);
+
+/*
+ * Vector-attention aggregate: replaces models/pointtransformer/seg_model.py:50-52 (and
+ * pointops_cuda.aggregation_*, pointops.py:161-195), fused with the value gather:
+ *   out[i, ch] = sum_j (v[idx[i,j], ch] + pos[i,j,ch]) * w[i, j, ch mod cw]        cw = c / share_planes
+ *   v (n,c), pos (n,ns,c), w (n,ns,cw), idx (n,ns) -> out (n,c)
+ * _bwd: grad_out (n,c) -> grad_v (n,c) ACCUMULATED (caller zero-fills), grad_pos (n,ns,c) and
+ *   grad_w (n,ns,cw) overwritten.
+ */
+int fsg_vec_attn_fwd_f32(const float *v, const float *pos, const float *w, const int32_t *idx,
+                         float *out, int n, int ns, int c, int cw, fsg_stream_t stream);
+int fsg_vec_attn_bwd_f32(const float *v, const float *pos, const float *w, const int32_t *idx,
+                         const float *grad_out, float *grad_v, float *grad_pos, float *grad_w, int n,
+                         int ns, int c, int cw, fsg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSG_HIP_H */

@@ -1,0 +1,77 @@
+"""CPU tests of the data-parallel harness with the gloo backend, world_size 2 (the N>1 path of bench.py
+minus the GPU): the averaged gradient equals the mean of the per-shard gradients, weights are identical
+after broadcast, batch shards tile the global batch."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _net():
+    return nn.Sequential(nn.Conv1d(3, 8, 1), nn.BatchNorm1d(8), nn.LeakyReLU(0.2), nn.Conv1d(8, 4, 1))
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from fissure_segmentation_amd import distributed as D
+    r, w, dev = D.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and dev.type == "cpu"
+    torch.manual_seed(100 + rank)           # different init per rank on purpose
+    model = _net()
+    D.broadcast_parameters(model)
+    avg = D.BucketedGradAverager(model, early=lambda n: n.startswith("3."))
+    torch.manual_seed(7)
+    x = torch.randn(6, 3, 32)
+    lo, hi = D.shard_batch(6, rank, world)
+    for _ in range(2):                       # second iteration checks zero_grad / hook re-arming
+        avg.zero_grad()
+        model(x[lo:hi]).square().mean().backward()
+        avg.finish()
+    out[rank] = {"w": [p.detach().clone() for p in model.parameters()],
+                 "g": [p.grad.detach().clone() for p in model.parameters()], "shard": (lo, hi)}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_gradient_average():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    a, b = out[0], out[1]
+    assert a["shard"] == (0, 3) and b["shard"] == (3, 6)
+    for wa, wb in zip(a["w"], b["w"]):
+        assert torch.equal(wa, wb)                              # broadcast made the replicas identical
+    for ga, gb in zip(a["g"], b["g"]):
+        assert torch.equal(ga, gb)                              # all-reduce: same averaged gradient
+    # expected: mean of the two per-shard gradients computed serially with rank 0's weights
+    torch.manual_seed(100)
+    ref = _net()
+    torch.manual_seed(7)
+    x = torch.randn(6, 3, 32)
+    grads = []
+    for lo, hi in ((0, 3), (3, 6)):
+        ref.zero_grad()
+        ref(x[lo:hi]).square().mean().backward()
+        grads.append([p.grad.clone() for p in ref.parameters()])
+    for ga, g0, g1 in zip(a["g"], *grads):
+        torch.testing.assert_close(ga, (g0 + g1) / 2, rtol=1e-6, atol=1e-7)
+
+
+def test_shard_batch_tiles():
+    from fissure_segmentation_amd import distributed as D
+    for gb in (1, 7, 8, 32):
+        for world in (1, 2, 3, 8):
+            spans = [D.shard_batch(gb, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == gb
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
