@@ -1,0 +1,181 @@
+"""Headline benchmark: points/sec, forward + loss + backward + Adam step, DGCNN-seg N=2048 k=20
+(BASELINE.json configs[1]) on N GPUs of one node, one process per GPU, batch sharded data-parallel with
+an RCCL gradient average.  Prints ONE JSON line on rank 0.
+
+    python bench.py [--gpus 1] [--steps 30] [--warmup 5] [--workload c2|c4]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import fissure_segmentation_amd as fsg  # noqa: E402
+from fissure_segmentation_amd import _lib, distributed as D  # noqa: E402
+from fissure_segmentation_amd.models.dgcnn import DGCNNSeg  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+WORKLOADS = {
+    # name: (clouds per GPU, points, k, description)
+    "c2": (8, 2048, 20, "DGCNN-seg N=2048 k=20, 8 clouds/GPU, dynamic graph, fp32 (BASELINE configs[1])"),
+    "c4": (4, 8192, 40, "DGCNN-seg N=8192 k=40, 4 clouds/GPU, dynamic graph (BASELINE configs[3] shape, fp32)"),
+}
+EDGE_LAYERS_C = (3, 64, 64)  # input channels of ec1/ec2/ec3 (models/dgcnn.py:130-132 of the reference)
+
+
+def synthetic_batch(B, N, classes, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, 3, N, generator=g) * 2 - 1          # coordinates U(-1,1), SURVEY 8(d)
+    y = torch.randint(0, classes, (B, N), generator=g)
+    return x.to(device), y.to(device)
+
+
+def knn_gather_bytes_per_point(k, s=4):
+    """reference-semantic kNN+gather, per point: sum over layers of 4C + 4k + 2*C*k*s (fwd)."""
+    return sum(4 * c + 4 * k + 2 * c * k * s for c in EDGE_LAYERS_C)
+
+
+def usable_cores():
+    """Threads the CPU baseline may use: CPU affinity, capped by the cgroup quota and by the 16-core share a
+    one-GPU box grants (more threads than the quota only adds throttling; FSG_CPU_THREADS overrides)."""
+    if os.environ.get("FSG_CPU_THREADS"):
+        return int(os.environ["FSG_CPU_THREADS"])
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(B, N, k, classes, steps=2):
+    """The oracle's pure-PyTorch CPU restatement (kind "port") on the host cores, same step definition."""
+    from oracle import ref_cpu
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    net = ref_cpu.DGCNNSeg(k=k, in_features=3, num_classes=classes).train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    x, y = synthetic_batch(B, N, classes, 1234, "cpu")
+
+    def step():
+        opt.zero_grad()
+        F.cross_entropy(net(x), y).backward()
+        opt.step()
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": B * N / dt, "unit": "points/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} steps of the same workload (B={B}, N={N}, k={k}) after 1 warm-up, "
+                      f"oracle/ref_cpu.DGCNNSeg fwd+CE+bwd+Adam, {dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, device = D.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if device.type != "cuda":
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    B, N, k, desc = WORKLOADS[args.workload]
+    classes = 4
+
+    torch.manual_seed(0)
+    net = DGCNNSeg(k=k, in_features=3, num_classes=classes).to(device).train()
+    D.broadcast_parameters(net)
+    averager = D.BucketedGradAverager(
+        net, early=lambda n: n.startswith("segmentation") or n.startswith("global_feature"))
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    x, y = synthetic_batch(B, N, classes, 1234 + rank, device)
+
+    def step():
+        averager.zero_grad()
+        loss = F.cross_entropy(net(x), y)
+        loss.backward()
+        averager.finish()
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    _lib.start_timing()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = _lib.stop_timing()
+    if not torch.isfinite(loss):
+        raise SystemExit("non-finite loss")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        points = B * N * world * args.steps
+        # --- roofline of the kNN + gather kernel group (forward), HIP-event timed inside the steps above
+        per_kernel = {}
+        for name, vals in kernel_ms.items():
+            per_kernel[name] = {"launches_per_step": len(vals) / args.steps, "avg_us": 1e3 * sum(vals) / len(vals)}
+        grp = ["fsg_knn_dense_f32", "fsg_edge_gather_fwd_f32"]
+        grp_ms_per_step = sum(sum(kernel_ms.get(n, [])) for n in grp) / args.steps
+        alg_bytes = knn_gather_bytes_per_point(k) * B * N      # per step and GPU (3 EdgeConv layers)
+        achieved = alg_bytes / (grp_ms_per_step * 1e-3) / 1e9 if grp_ms_per_step > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(args.workload)
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "kernel": "kNN graph + edge-feature gather, forward, 3 EdgeConv layers "
+                              "(fsg_knn_dense_f32 + fsg_edge_gather_fwd_f32)",
+                    "algorithmic_bytes_per_step": alg_bytes, "us_per_step": round(1e3 * grp_ms_per_step, 1),
+                    "kernels": {n: {k2: round(v, 2) for k2, v in d.items()} for n, d in sorted(per_kernel.items())}}
+        out = {"metric": "points/sec fwd+bwd DGCNN-seg N=2048 k=20", "value": round(points / elapsed, 1),
+               "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": desc, "clouds_per_gpu": B, "points_per_cloud": N, "k": k,
+                          "global_batch": B * world, "step": "fwd + cross-entropy + bwd + grad all-reduce + Adam",
+                          "parallelism": f"dp{world}"},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(B, N, k, classes)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

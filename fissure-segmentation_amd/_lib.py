@@ -38,7 +38,31 @@ for _name, (_args, _res) in SIGNATURES.items():
 KNN_FIX_DIAG, KNN_DROP_FIRST, KNN_MAX_K = 1, 2, 64
 
 
+_timing = None  # {entry point: [(start_event, end_event), ...]} while bench.py measures kernel durations
+
+
+def start_timing():
+    """Bracket every C-ABI call with HIP events on the stream it is launched on (torch's current stream)."""
+    global _timing
+    _timing = {}
+
+
+def stop_timing():
+    """-> {entry point: [milliseconds per call]} (synchronises)."""
+    global _timing
+    rec, _timing = _timing, None
+    torch.cuda.synchronize()
+    return {name: [s.elapsed_time(e) for s, e in evs] for name, evs in (rec or {}).items()}
+
+
 def call(name, *args):
-    rc = getattr(lib, name)(*args)
+    if _timing is None:
+        rc = getattr(lib, name)(*args)
+    else:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = getattr(lib, name)(*args)
+        e.record()
+        _timing.setdefault(name, []).append((s, e))
     if rc != 0:
         raise RuntimeError(f"{name} failed (code {rc}): {lib.fsg_last_error().decode()}")

@@ -5,6 +5,7 @@ import torch
 from torch import nn
 
 from .. import functional as F_hip
+from ..norm import BatchNorm1d, BatchNorm2d
 from ..utils.general_utils import knn
 from ..utils.model_utils import init_weights
 from .point_seg_net import PointSegmentationModelBase
@@ -28,7 +29,7 @@ class ConvBlock(nn.Module):
                  negative_slope=1e-2, bn=True, activation=True):
         super().__init__()
         try:
-            conv, norm = {1: (nn.Conv1d, nn.BatchNorm1d), 2: (nn.Conv2d, nn.BatchNorm2d),
+            conv, norm = {1: (nn.Conv1d, BatchNorm1d), 2: (nn.Conv2d, BatchNorm2d),
                           3: (nn.Conv3d, nn.BatchNorm3d)}[dim]
         except KeyError:
             raise ValueError(f'There is no Conv layer for dimensionality {dim}.')
@@ -79,8 +80,8 @@ class SpatialTransformer(nn.Module):
         self.in_features = 3
         self.ec = EdgeConv(3, [64, 128], k)
         self.shared_fc = SharedFullyConnected(128, 1024, dim=1)
-        self.mlp = nn.Sequential(nn.Linear(1024, 512), nn.BatchNorm1d(512), nn.LeakyReLU(0.2),
-                                 nn.Linear(512, 256), nn.BatchNorm1d(256), nn.LeakyReLU(0.2))
+        self.mlp = nn.Sequential(nn.Linear(1024, 512), BatchNorm1d(512), nn.LeakyReLU(0.2),
+                                 nn.Linear(512, 256), BatchNorm1d(256), nn.LeakyReLU(0.2))
         self.transform = nn.Linear(256, 9)
 
     def forward(self, x, fixed_knn_graph=None):

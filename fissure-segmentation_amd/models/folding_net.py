@@ -7,6 +7,7 @@ from torch import nn
 
 from .. import functional as F_hip
 from ..shapes.shape_constructor import get_gaussian, get_plane, get_plane_mesh, get_sphere
+from ..norm import BatchNorm1d, BatchNorm2d
 from .dgcnn import SharedFullyConnected
 from .dgcnn_opensrc import get_graph_feature
 from .modelio import LoadableModel, store_config_args
@@ -22,8 +23,8 @@ class DGCNN_Cls_Encoder(LoadableModel):
     def __init__(self, k, n_embedding, static=False):
         super().__init__()
         self.static, self.k, self.n_embedding = static, k, n_embedding
-        self.bn1, self.bn2, self.bn3, self.bn4 = (nn.BatchNorm2d(c) for c in (64, 64, 128, 256))
-        self.bn5 = nn.BatchNorm1d(n_embedding)
+        self.bn1, self.bn2, self.bn3, self.bn4 = (BatchNorm2d(c) for c in (64, 64, 128, 256))
+        self.bn5 = BatchNorm1d(n_embedding)
         act = lambda: nn.LeakyReLU(negative_slope=0.2)  # noqa: E731
         self.conv1 = nn.Sequential(nn.Conv2d(6, 64, 1, bias=False), self.bn1, act())
         self.conv2 = nn.Sequential(nn.Conv2d(128, 64, 1, bias=False), self.bn2, act())

@@ -4,6 +4,7 @@ no HIP kernel on this model; it runs wherever its tensors live."""
 import torch
 from torch import nn
 
+from ..norm import BatchNorm1d
 from ..utils.model_utils import init_weights
 from .point_seg_net import PointSegmentationModelBase
 
@@ -15,7 +16,7 @@ class MLPBlock(nn.Module):
         super().__init__()
         mods, prev = [], in_channel
         for width in num_neurons_list:
-            mods += [nn.Conv1d(prev, width, 1, bias=False), nn.BatchNorm1d(width), nn.LeakyReLU()]
+            mods += [nn.Conv1d(prev, width, 1, bias=False), BatchNorm1d(width), nn.LeakyReLU()]
             prev = width
         self.layers = nn.ModuleList(mods)
 

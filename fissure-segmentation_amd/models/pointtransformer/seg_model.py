@@ -5,6 +5,7 @@ vector-attention aggregate run in libfsg_hip.so.  Host syncs of the reference (`
 import torch
 import torch.nn as nn
 
+from ...norm import BatchNorm1d
 from ..point_seg_net import PointSegmentationModelBase
 from . import pointops
 
@@ -19,11 +20,11 @@ class PointTransformerLayer(nn.Module):
         self.linear_q = nn.Linear(in_planes, mid_planes)
         self.linear_k = nn.Linear(in_planes, mid_planes)
         self.linear_v = nn.Linear(in_planes, out_planes)
-        self.linear_p = nn.Sequential(nn.Linear(3, 3), nn.BatchNorm1d(3), nn.ReLU(inplace=True),
+        self.linear_p = nn.Sequential(nn.Linear(3, 3), BatchNorm1d(3), nn.ReLU(inplace=True),
                                       nn.Linear(3, out_planes))
-        self.linear_w = nn.Sequential(nn.BatchNorm1d(mid_planes), nn.ReLU(inplace=True),
+        self.linear_w = nn.Sequential(BatchNorm1d(mid_planes), nn.ReLU(inplace=True),
                                       nn.Linear(mid_planes, mid_planes // share_planes),
-                                      nn.BatchNorm1d(mid_planes // share_planes), nn.ReLU(inplace=True),
+                                      BatchNorm1d(mid_planes // share_planes), nn.ReLU(inplace=True),
                                       nn.Linear(out_planes // share_planes, out_planes // share_planes))
         self.softmax = nn.Softmax(dim=1)
 
@@ -60,7 +61,7 @@ class TransitionDown(nn.Module):
             self.pool = nn.MaxPool1d(nsample)
         else:
             self.linear = nn.Linear(in_planes, out_planes, bias=False)
-        self.bn = nn.BatchNorm1d(out_planes)
+        self.bn = BatchNorm1d(out_planes)
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, pxo):
@@ -88,13 +89,13 @@ class TransitionUp(nn.Module):
     def __init__(self, in_planes, out_planes=None):
         super().__init__()
         if out_planes is None:
-            self.linear1 = nn.Sequential(nn.Linear(2 * in_planes, in_planes), nn.BatchNorm1d(in_planes),
+            self.linear1 = nn.Sequential(nn.Linear(2 * in_planes, in_planes), BatchNorm1d(in_planes),
                                          nn.ReLU(inplace=True))
             self.linear2 = nn.Sequential(nn.Linear(in_planes, in_planes), nn.ReLU(inplace=True))
         else:
-            self.linear1 = nn.Sequential(nn.Linear(out_planes, out_planes), nn.BatchNorm1d(out_planes),
+            self.linear1 = nn.Sequential(nn.Linear(out_planes, out_planes), BatchNorm1d(out_planes),
                                          nn.ReLU(inplace=True))
-            self.linear2 = nn.Sequential(nn.Linear(in_planes, out_planes), nn.BatchNorm1d(out_planes),
+            self.linear2 = nn.Sequential(nn.Linear(in_planes, out_planes), BatchNorm1d(out_planes),
                                          nn.ReLU(inplace=True))
 
     def forward(self, pxo1, pxo2=None):
@@ -118,11 +119,11 @@ class PointTransformerBlock(nn.Module):
     def __init__(self, in_planes, planes, share_planes=8, nsample=16):
         super().__init__()
         self.linear1 = nn.Linear(in_planes, planes, bias=False)
-        self.bn1 = nn.BatchNorm1d(planes)
+        self.bn1 = BatchNorm1d(planes)
         self.transformer2 = PointTransformerLayer(planes, planes, share_planes, nsample)
-        self.bn2 = nn.BatchNorm1d(planes)
+        self.bn2 = BatchNorm1d(planes)
         self.linear3 = nn.Linear(planes, planes * self.expansion, bias=False)
-        self.bn3 = nn.BatchNorm1d(planes * self.expansion)
+        self.bn3 = BatchNorm1d(planes * self.expansion)
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, pxo):
@@ -146,7 +147,7 @@ class PointTransformerSeg(nn.Module):
         for lvl in range(4, -1, -1):
             setattr(self, f'dec{lvl + 1}', self._make_dec(block, planes[lvl], 2, share_planes, nsample[lvl],
                                                           is_head=(lvl == 4)))
-        self.cls = nn.Sequential(nn.Linear(planes[0], planes[0]), nn.BatchNorm1d(planes[0]), nn.ReLU(inplace=True),
+        self.cls = nn.Sequential(nn.Linear(planes[0], planes[0]), BatchNorm1d(planes[0]), nn.ReLU(inplace=True),
                                  nn.Linear(planes[0], k))
 
     def _make_enc(self, block, planes, blocks, share_planes=8, stride=1, nsample=16):

@@ -1,0 +1,108 @@
+"""CPU tests of the host side: the C ABI library loads and exports every symbol include/fsg_hip.h
+declares (no compute calls without a GPU), the module mirrors keep the reference's constructor / config /
+state_dict contract, BASELINE config 1 (PointNet, the reference's CPU case) matches its golden vector, and
+the HIP-only modules refuse CPU tensors instead of falling back."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import cloud, fill_state_dict, load
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from fissure_segmentation_amd import _lib
+    header = open(os.path.join(ROOT, "include", "fsg_hip.h")).read()
+    declared = set(re.findall(r"\b(fsg_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(_lib.lib, name), name
+    assert _lib.lib.fsg_version() >= 100
+    assert isinstance(_lib.lib.fsg_last_error(), bytes)
+
+
+def test_bad_arguments_are_reported_not_thrown():
+    """argument validation happens on the host before any launch, so it is testable without a GPU"""
+    from fissure_segmentation_amd import _lib
+    with pytest.raises(RuntimeError, match="NULL pointer"):
+        _lib.call("fsg_knn_dense_f32", None, 1, 16, 48, 16, 3, 4, 0, None, None, None)
+    with pytest.raises(RuntimeError, match="k="):
+        _lib.call("fsg_knn_dense_f32", 1, 1, 16, 48, 16, 3, 65, 0, 1, None, None)
+
+
+def test_no_cpu_fallback():
+    import fissure_segmentation_amd as fsg
+    from fissure_segmentation_amd.losses.chamfer_loss import ChamferLoss
+    from fissure_segmentation_amd.models.dgcnn import DGCNNSeg
+    from fissure_segmentation_amd.utils.general_utils import knn
+    x = torch.randn(1, 3, 32)
+    with pytest.raises(RuntimeError, match="GPU"):
+        knn(x, 4)
+    with pytest.raises(RuntimeError, match="GPU"):
+        DGCNNSeg(k=4, in_features=3, num_classes=2)(x)
+    with pytest.raises(RuntimeError, match="GPU"):
+        ChamferLoss()(x, x)
+    with pytest.raises(RuntimeError, match="GPU"):
+        fsg.functional.edge_features(x, torch.zeros(1, 32, 4, dtype=torch.int32))
+
+
+def test_module_contract_matches_reference_keys():
+    from fissure_segmentation_amd.models.access_models import get_point_seg_model_class
+    from fissure_segmentation_amd.models.folding_net import DGCNNFoldingNet
+    for fixture, name, kw in [("dgcnnseg_dyn", "DGCNN", dict(in_features=3)),
+                              ("dgcnnseg_stn", "DGCNN", dict(in_features=3, spatial_transformer=True)),
+                              ("dgcnnseg_img", "DGCNN", dict(in_features=9, image_feat_module=True)),
+                              ("pointnet_c1", "PointNet", dict(in_features=3))]:
+        cls = get_point_seg_model_class(name)
+        net = cls(num_classes=4, k=8, **kw)
+        assert list(net.state_dict().keys()) == [str(s) for s in load(fixture)["keys"]], fixture
+        clone = type(net)(**net.config)                 # train.py:505 of the reference
+        assert clone.config == net.config
+    for fixture, kw in [("ae_fold", {}), ("ae_deform_static", dict(deform=True, static=True))]:
+        net = DGCNNFoldingNet(k=8, n_embedding=64, shape_type="plane", n_input_points=2048, decode_mesh=False, **kw)
+        assert sorted(net.state_dict().keys()) == sorted(str(s) for s in load(fixture)["keys"])
+    with pytest.raises(NotImplementedError):
+        get_point_seg_model_class("nope")
+    with pytest.raises(ValueError):
+        get_point_seg_model_class("DGCNN")(k=4, in_features=3, num_classes=2, image_feat_module=True)
+
+
+def test_save_load_roundtrip_cpu(tmp_path):
+    from fissure_segmentation_amd.models.point_net import PointNetSeg
+    net = PointNetSeg(5, 3).eval()
+    path = str(tmp_path / "m.pth")
+    net.save(path)
+    assert set(torch.load(path).keys()) == {"config", "model_state"}
+    back = PointNetSeg.load(path, "cpu").eval()
+    x = torch.randn(2, 5, 40)
+    assert torch.equal(net(x), back(x))
+
+
+def test_pointnet_config1_cpu_vs_golden():
+    """BASELINE configs[0]: PointNet seg, 8 synthetic 1024-point clouds, 4 classes, fp32 CPU."""
+    from fissure_segmentation_amd.models.point_net import PointNetSeg
+    g = load("pointnet_c1")
+    net = fill_state_dict(PointNetSeg(3, 4), 501).train()
+    x = torch.from_numpy(cloud(1501, 8, 3, 1024)).requires_grad_(True)
+    y = net(x)
+    gr = np.random.default_rng(2501).standard_normal(tuple(y.shape)).astype(np.float32)
+    y.backward(torch.from_numpy(gr))
+    np.testing.assert_allclose(y.detach().numpy(), g["logits"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(x.grad.numpy(), g["grad_x"], rtol=1e-3, atol=1e-4)
+    for n, p in net.named_parameters():
+        ref = float(g["gnorm_" + n])
+        assert abs(float(p.grad.double().norm()) - ref) <= 1e-3 * ref + 1e-4, n
+
+
+def test_plane_grids_match_reference_geometry():
+    from fissure_segmentation_amd.shapes.shape_constructor import get_plane, get_plane_mesh
+    from oracle import ref_cpu
+    assert np.array_equal(get_plane(), ref_cpu.plane_grid_45())
+    pts, faces = get_plane_mesh(n=16, xrange=(-0.3, 0.3), yrange=(-0.3, 0.3))
+    assert pts.shape == (16, 2) and faces.shape == (18, 3)
+    assert faces[:2].tolist() == [[0, 1, 4], [1, 4, 5]] and int(faces.max()) == 15
