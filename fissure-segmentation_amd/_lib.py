@@ -19,14 +19,15 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 SIGNATURES = {
     "fsg_version": ([], _I),
     "fsg_last_error": ([], ctypes.c_char_p),
-    "fsg_knn_dense_f32": ([_P, _I, _I, _L, _L, _I, _I, _I, _P, _P, _P], _I),
+    "fsg_knn_dense_f32": ([_P, _I, _I, _L, _L, _I, _I, _I, _P, _P, _P, _P], _I),
     "fsg_edge_gather_fwd_f32": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
     "fsg_edge_gather_bwd_f32": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
     "fsg_graph_reverse_csr": ([_P, _I, _I, _I, _P, _P, _P], _I),
     "fsg_edgeconv1_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),
-    "fsg_edgeconv1_fwd_f32": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P], _I),
-    "fsg_edgeconv1_bwd_f32": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P],
+    "fsg_edgeconv1_fwd_f32": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
                               _I),
+    "fsg_edgeconv1_bwd_f32": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P,
+                               _P], _I),
     "fsg_chamfer_nn_f32": ([_P, _P, _I, _I, _I, _P, _P, _P], _I),
     "fsg_chamfer_nn_bwd_f32": ([_P, _P, _P, _P, _I, _I, _I, _P, _P, _P], _I),
     "fsg_knn_segment_f32": ([_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P], _I),
@@ -40,7 +41,7 @@ for _name, (_args, _res) in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here = header and library out of sync
     _fn.argtypes, _fn.restype = _args, _res
 
-KNN_FIX_DIAG, KNN_DROP_FIRST, KNN_MAX_K = 1, 2, 64
+KNN_FIX_DIAG, KNN_DROP_FIRST, KNN_FORCE_ROWS, KNN_FORCE_MFMA, KNN_MAX_K = 1, 2, 4, 8, 64
 
 
 _timing = None  # {entry point: [(start_event, end_event), ...]} while bench.py measures kernel durations

@@ -91,21 +91,33 @@ __global__ __launch_bounds__(256) void ec1_stats_select_kernel(const float *__re
     for (int t = 0; t < TP / 4; ++t) {
         const int i = tile * TP + wave * (TP / 4) + t;
         if (i >= N) break;
-        const int32_t *nb = idx + ((long)b * N + i) * k;
+        // one coalesced load brings the point's k neighbour ids into the wave; each id is then broadcast with
+        // v_readlane and the P-row gathers are issued four at a time (independent loads hide the L2 latency)
+        const int myj = lane < k ? idx[((long)b * N + i) * k + lane] : 0;
         const float q = Q[(long)i * ld + c];
         float best = -INFINITY, tot = 0.f;
         int barg = 0;
-        for (int s = 0; s < k; ++s) {
-            const int j = __builtin_amdgcn_readfirstlane(nb[s]);
-            const float y = P[(long)j * ld + c] + q;
-            tot += y;
-            const float v = sgn * y;
-            if (v > best) { best = v; barg = s; }
-            if (training) {
-                if (first) { shift = y; first = false; }
-                const float d = y - shift;
-                s1 += d;
-                s2 = __builtin_fmaf(d, d, s2);
+        for (int s0 = 0; s0 < k; s0 += 4) {
+            float y[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s = min(s0 + u, k - 1);
+                const int j = __builtin_amdgcn_readlane(myj, s);
+                y[u] = P[(long)j * ld + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (s0 + u >= k) break;
+                const float yy = y[u] + q;
+                tot += yy;
+                const float v = sgn * yy;
+                if (v > best) { best = v; barg = s0 + u; }
+                if (training) {
+                    if (first) { shift = yy; first = false; }
+                    const float d = yy - shift;
+                    s1 += d;
+                    s2 = __builtin_fmaf(d, d, s2);
+                }
             }
         }
         const long o = ((long)b * N + i) * Co + c;
@@ -146,40 +158,47 @@ __global__ __launch_bounds__(256) void ec1_stats_select_kernel(const float *__re
     }
 }
 
-// merges R records (n, mean, M2) per channel in fp64 -> mean, invstd (+ running statistics update)
-__global__ __launch_bounds__(256) void bn_merge_finalize_kernel(const float *__restrict__ partials, int R, int Co,
-                                                                 float eps, float momentum, float *__restrict__ mean_out,
-                                                                 float *__restrict__ invstd_out,
-                                                                 float *__restrict__ running_mean,
-                                                                 float *__restrict__ running_var) {
-    __shared__ double red[3][4][64];
+// merges R records (n, mean, M2) per channel in fp64 -> mean, invstd (+ running statistics update).
+// Two passes of plain sums (grand mean first, then M2 = sum M2_r + n_r (mean_r - mean)^2): no division per record.
+__global__ __launch_bounds__(1024) void bn_merge_finalize_kernel(const float *__restrict__ partials, int R, int Co,
+                                                                  float eps, float momentum, float *__restrict__ mean_out,
+                                                                  float *__restrict__ invstd_out,
+                                                                  float *__restrict__ running_mean,
+                                                                  float *__restrict__ running_var) {
+    __shared__ double red[2][16][64];
+    __shared__ double gmean[64];
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    double n = 0.0, mu = 0.0, M2 = 0.0;
-    for (int r = slice; r < R; r += 4) {
+    double sn = 0.0, sm = 0.0;
+    for (int r = slice; r < R; r += 16) {
         const float *pr = partials + (long)r * 3 * Co;
         const double nb = pr[c];
-        if (nb > 0.0) {
-            const double tot = n + nb, delta = (double)pr[Co + c] - mu;
-            mu += delta * (nb / tot);
-            M2 += (double)pr[2 * Co + c] + delta * delta * (n * nb / tot);
-            n = tot;
-        }
+        sn += nb;
+        sm += nb * (double)pr[Co + c];
     }
-    red[0][slice][lane] = n;
-    red[1][slice][lane] = mu;
-    red[2][slice][lane] = M2;
+    red[0][slice][lane] = sn;
+    red[1][slice][lane] = sm;
     __syncthreads();
     if (slice == 0) {
-        for (int w = 1; w < 4; ++w) {
-            const double nb = red[0][w][lane];
-            if (nb > 0.0) {
-                const double tot = n + nb, delta = red[1][w][lane] - mu;
-                mu += delta * (nb / tot);
-                M2 += red[2][w][lane] + delta * delta * (n * nb / tot);
-                n = tot;
-            }
-        }
+        double n = 0.0, m = 0.0;
+        for (int w = 0; w < 16; ++w) { n += red[0][w][lane]; m += red[1][w][lane]; }
+        gmean[lane] = n > 0.0 ? m / n : 0.0;
+        red[0][0][lane] = n;
+    }
+    __syncthreads();
+    const double mu = gmean[lane], n = red[0][0][lane];
+    __syncthreads();
+    double M2 = 0.0;
+    for (int r = slice; r < R; r += 16) {
+        const float *pr = partials + (long)r * 3 * Co;
+        const double d = (double)pr[Co + c] - mu;
+        M2 += (double)pr[2 * Co + c] + (double)pr[c] * d * d;
+    }
+    red[1][slice][lane] = M2;
+    __syncthreads();
+    if (slice == 0) {
+        M2 = 0.0;
+        for (int w = 0; w < 16; ++w) M2 += red[1][w][lane];
         const double var = n > 0.0 ? M2 / n : 0.0;
         mean_out[c] = (float)mu;
         invstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -195,7 +214,7 @@ __global__ __launch_bounds__(256) void bn_merge_finalize_kernel(const float *__r
 __global__ __launch_bounds__(256) void ec1_apply_kernel(const float *__restrict__ ysel, const float *__restrict__ gamma,
                                                          const float *__restrict__ beta, const float *__restrict__ mean,
                                                          const float *__restrict__ invstd, int N, int Co, float slope,
-                                                         float *__restrict__ out) {
+                                                         float *__restrict__ out, float *__restrict__ out_pm) {
     __shared__ float tile[64][65];
     const int b = blockIdx.x, i0 = blockIdx.y * 64, cg = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -204,7 +223,10 @@ __global__ __launch_bounds__(256) void ec1_apply_kernel(const float *__restrict_
     for (int p = wave; p < 64; p += 4) {
         const int i = i0 + p;
         float v = 0.f;
-        if (i < N) v = lrelu(__builtin_fmaf(ysel[((long)b * N + i) * Co + c], g, sh), slope);
+        if (i < N) {
+            v = lrelu(__builtin_fmaf(ysel[((long)b * N + i) * Co + c], g, sh), slope);
+            if (out_pm) out_pm[((long)b * N + i) * Co + c] = v;
+        }
         tile[lane][p] = v;
     }
     __syncthreads();
@@ -216,7 +238,8 @@ __global__ __launch_bounds__(256) void ec1_apply_kernel(const float *__restrict_
 
 // ------------------------------------------------------------------ backward
 // h = grad_out * f'(u) on the selected edge (point-major), per-workgroup partial sums of h and h*yhat
-__global__ __launch_bounds__(256) void ec1_bwd_point_kernel(const float *__restrict__ gout, const float *__restrict__ ysel,
+__global__ __launch_bounds__(256) void ec1_bwd_point_kernel(const float *__restrict__ gout, const float *__restrict__ gout_pm,
+                                                             const float *__restrict__ ysel,
                                                              const float *__restrict__ gamma,
                                                              const float *__restrict__ beta,
                                                              const float *__restrict__ mean,
@@ -228,7 +251,7 @@ __global__ __launch_bounds__(256) void ec1_bwd_point_kernel(const float *__restr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int cc = wave; cc < 64; cc += 4) {
         const int i = i0 + lane;
-        tile[cc][lane] = i < N ? gout[((long)b * Co + cg * 64 + cc) * N + i] : 0.f;
+        tile[cc][lane] = (gout && i < N) ? gout[((long)b * Co + cg * 64 + cc) * N + i] : 0.f;
     }
     __syncthreads();
     const int c = cg * 64 + lane;
@@ -240,7 +263,8 @@ __global__ __launch_bounds__(256) void ec1_bwd_point_kernel(const float *__restr
         const long o = ((long)b * N + i) * Co + c;
         const float yhat = (ysel[o] - mu) * r;
         const float u = __builtin_fmaf(ga, yhat, be);
-        const float hv = tile[lane][p] * (u > 0.f ? 1.f : slope);
+        const float gv = tile[lane][p] + (gout_pm ? gout_pm[o] : 0.f);
+        const float hv = gv * (u > 0.f ? 1.f : slope);
         h[o] = hv;
         sb += hv;
         sg = __builtin_fmaf(hv, yhat, sg);
@@ -287,13 +311,27 @@ __global__ __launch_bounds__(256) void ec1_bwd_gather_kernel(
     const int beg = rowptr[(long)b * (N + 1) + j], end = rowptr[(long)b * (N + 1) + j + 1];
     const int32_t *cb = col + (long)b * N * k;
     float ah = 0.f, aq = 0.f;
-    for (int t = beg; t < end; ++t) {
-        const int e = __builtin_amdgcn_readfirstlane(cb[t]);
-        const int i = e >> 6, s = e & 63;
-        const long o = ((long)b * N + i) * Co + c;
-        const float hv = h[o];
-        ah += (arg[o] == s) ? hv : 0.f;
-        if (training) aq += Q[(long)i * ld + c];
+    for (int t0 = beg; t0 < end; t0 += 64) {  // in-edges in chunks of 64: one coalesced load, then lane broadcasts
+        const int mye = (t0 + lane < end) ? cb[t0 + lane] : 0;
+        const int cnt = min(64, end - t0);
+        for (int t = 0; t < cnt; t += 2) {
+            const int e0 = __builtin_amdgcn_readlane(mye, t);
+            const int e1 = __builtin_amdgcn_readlane(mye, min(t + 1, cnt - 1));
+            const long o0 = ((long)b * N + (e0 >> 6)) * Co + c, o1 = ((long)b * N + (e1 >> 6)) * Co + c;
+            const float h0 = h[o0], h1 = h[o1];
+            const int a0 = arg[o0], a1 = arg[o1];
+            float q0 = 0.f, q1 = 0.f;
+            if (training) {
+                q0 = Q[(long)(e0 >> 6) * ld + c];
+                q1 = Q[(long)(e1 >> 6) * ld + c];
+            }
+            ah += (a0 == (e0 & 63)) ? h0 : 0.f;
+            aq += q0;
+            if (t + 1 < cnt) {
+                ah += (a1 == (e1 & 63)) ? h1 : 0.f;
+                aq += q1;
+            }
+        }
     }
     const float r = invstd[c], coef = r * gamma[c], mu = mean[c];
     const long oj = ((long)b * N + j) * Co + c;
@@ -338,8 +376,9 @@ extern "C" size_t fsg_edgeconv1_workspace_bytes(int B, int N, int Co) {
 
 extern "C" int fsg_edgeconv1_fwd_f32(const float *pq, const int32_t *idx, const float *gamma, const float *beta,
                                      float *running_mean, float *running_var, int B, int N, int k, int Co, int training,
-                                     float momentum, float eps, float slope, float *out, float *ysel, uint8_t *arg,
-                                     float *ssum, float *mean, float *invstd, float *workspace, fsg_stream_t stream) {
+                                     float momentum, float eps, float slope, float *out, float *out_pm, float *ysel,
+                                     uint8_t *arg, float *ssum, float *mean, float *invstd, float *workspace,
+                                     fsg_stream_t stream) {
     FSG_REQUIRE(pq && idx && gamma && beta && out && ysel && arg && mean && invstd, "fsg_edgeconv1_fwd_f32: NULL pointer");
     FSG_REQUIRE(B > 0 && N > 0 && k > 0 && k <= 64 && Co > 0 && Co % 64 == 0 && B <= 65535,
                 "fsg_edgeconv1_fwd_f32: bad shape B=%d N=%d k=%d Co=%d (Co must be a multiple of 64)", B, N, k, Co);
@@ -350,22 +389,22 @@ extern "C" int fsg_edgeconv1_fwd_f32(const float *pq, const int32_t *idx, const 
                        training, ysel, arg, ssum, workspace);
     FSG_CHECK_LAUNCH("fsg_edgeconv1_fwd_f32/stats");
     if (training) {
-        hipLaunchKernelGGL(bn_merge_finalize_kernel, dim3(Co / 64), dim3(256), 0, st, workspace, B * tiles, Co, eps,
+        hipLaunchKernelGGL(bn_merge_finalize_kernel, dim3(Co / 64), dim3(1024), 0, st, workspace, B * tiles, Co, eps,
                            momentum, mean, invstd, running_mean, running_var);
         FSG_CHECK_LAUNCH("fsg_edgeconv1_fwd_f32/finalize");
     }
     hipLaunchKernelGGL(ec1_apply_kernel, dim3(B, fsg_cdiv(N, 64), Co / 64), dim3(256), 0, st, ysel, gamma, beta, mean,
-                       invstd, N, Co, slope, out);
+                       invstd, N, Co, slope, out, out_pm);
     FSG_CHECK_LAUNCH("fsg_edgeconv1_fwd_f32/apply");
     return FSG_OK;
 }
 
-extern "C" int fsg_edgeconv1_bwd_f32(const float *grad_out, const float *pq, const int32_t *rowptr, const int32_t *col,
+extern "C" int fsg_edgeconv1_bwd_f32(const float *grad_out, const float *grad_out_pm, const float *pq, const int32_t *rowptr, const int32_t *col,
                                      const float *gamma, const float *beta, const float *mean, const float *invstd,
                                      const float *ysel, const uint8_t *arg, const float *ssum, int B, int N, int k,
                                      int Co, int training, float slope, float *grad_pq, float *grad_gamma,
                                      float *grad_beta, float *h_scratch, float *workspace, fsg_stream_t stream) {
-    FSG_REQUIRE(grad_out && pq && rowptr && col && gamma && beta && mean && invstd && ysel && arg && grad_pq &&
+    FSG_REQUIRE((grad_out || grad_out_pm) && pq && rowptr && col && gamma && beta && mean && invstd && ysel && arg && grad_pq &&
                     grad_gamma && grad_beta && h_scratch && workspace,
                 "fsg_edgeconv1_bwd_f32: NULL pointer");
     FSG_REQUIRE(!training || ssum, "fsg_edgeconv1_bwd_f32: training needs ssum");
@@ -373,7 +412,7 @@ extern "C" int fsg_edgeconv1_bwd_f32(const float *grad_out, const float *pq, con
                 "fsg_edgeconv1_bwd_f32: bad shape B=%d N=%d k=%d Co=%d", B, N, k, Co);
     hipStream_t st = (hipStream_t)stream;
     const int tiles64 = fsg_cdiv(N, 64);
-    hipLaunchKernelGGL(ec1_bwd_point_kernel, dim3(B, tiles64, Co / 64), dim3(256), 0, st, grad_out, ysel, gamma, beta,
+    hipLaunchKernelGGL(ec1_bwd_point_kernel, dim3(B, tiles64, Co / 64), dim3(256), 0, st, grad_out, grad_out_pm, ysel, gamma, beta,
                        mean, invstd, N, Co, slope, h_scratch, workspace);
     FSG_CHECK_LAUNCH("fsg_edgeconv1_bwd_f32/point");
     hipLaunchKernelGGL(sum_partials_kernel, dim3(Co / 64, 2), dim3(256), 0, st, workspace, B * tiles64, Co, 2, grad_beta,

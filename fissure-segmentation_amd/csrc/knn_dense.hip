@@ -111,9 +111,12 @@ __global__ __launch_bounds__(BLOCK) void knn_dense_rows_kernel(
 
 }  // namespace
 
+int fsg_knn_mfma_launch(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k, int flags,
+                        int32_t *idx_out, float *dist_out, float *xx_scratch, hipStream_t st);  // knn_mfma.hip
+
 extern "C" int fsg_knn_dense_f32(const float *x, int B, int N, int64_t stride_b, int64_t stride_c,
                                  int c_knn, int k, int flags, int32_t *idx_out, float *dist_out,
-                                 fsg_stream_t stream) {
+                                 float *xx_scratch, fsg_stream_t stream) {
     const int drop = (flags & FSG_KNN_DROP_FIRST) ? 1 : 0;
     FSG_REQUIRE(x && idx_out, "fsg_knn_dense_f32: NULL pointer");
     FSG_REQUIRE(B >= 0 && N > 0 && c_knn > 0, "fsg_knn_dense_f32: bad shape B=%d N=%d c_knn=%d", B, N, c_knn);
@@ -121,8 +124,15 @@ extern "C" int fsg_knn_dense_f32(const float *x, int B, int N, int64_t stride_b,
                 "fsg_knn_dense_f32: need 1 <= k and k+drop <= min(N, %d); got k=%d N=%d", FSG_KNN_MAX_K, k, N);
     FSG_REQUIRE(N <= 32768, "fsg_knn_dense_f32: N=%d > 32768 unsupported", N);
     if (B == 0) return FSG_OK;
-    const int Npad = (N + 255) & ~255;
     hipStream_t st = (hipStream_t)stream;
+    // measured on MI355X (tools/bench_kernels.py): the matrix-core kernel wins for few channels or long clouds, the
+    // rows kernel for C >= 64 at N = 2048 (the MFMA kernel is still latency-bound at one wave per SIMD)
+    const bool mfma_pays = c_knn <= 16 || N >= 4096;
+    if (!(flags & FSG_KNN_FORCE_ROWS) && (mfma_pays || (flags & FSG_KNN_FORCE_MFMA))) {
+        const int rc = fsg_knn_mfma_launch(x, B, N, stride_b, stride_c, c_knn, k, flags, idx_out, dist_out, xx_scratch, st);
+        if (rc != FSG_ERR_UNSUPPORTED) return rc;
+    }
+    const int Npad = (N + 255) & ~255;
     auto launch = [&](auto kern, int QB) -> int {
         const size_t lds = sizeof(float) * ((((size_t)c_knn * QB + QB + 3) & ~(size_t)3) + (size_t)QB * Npad);
         if (lds > 160 * 1024) {

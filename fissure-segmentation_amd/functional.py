@@ -27,7 +27,8 @@ def _f32c(t):
 
 
 # ------------------------------------------------------------------ dense kNN (utils/general_utils.py:315)
-def knn_graph(x, k, c_knn=None, fix_diag=True, drop_first=False, return_dist=False):
+def knn_graph(x, k, c_knn=None, fix_diag=True, drop_first=False, return_dist=False, force_rows_kernel=False,
+              _debug_flags=0):
     """x: (B,C,N) -> idx (B,N,k) int32 [, dist (B,N,k) fp32].  Channel slices are passed by stride."""
     _need_gpu(x)
     if x.dim() != 3:
@@ -41,9 +42,11 @@ def knn_graph(x, k, c_knn=None, fix_diag=True, drop_first=False, return_dist=Fal
     c_knn = C if c_knn is None else c_knn
     idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
     dist = torch.empty(B, N, k, dtype=torch.float32, device=x.device) if return_dist else None
-    flags = (_lib.KNN_FIX_DIAG if fix_diag else 0) | (_lib.KNN_DROP_FIRST if drop_first else 0)
+    flags = (_lib.KNN_FIX_DIAG if fix_diag else 0) | (_lib.KNN_DROP_FIRST if drop_first else 0) | \
+        (_lib.KNN_FORCE_ROWS if force_rows_kernel else 0) | _debug_flags
+    xx = torch.empty(B, N, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.call("fsg_knn_dense_f32", _p(x), B, N, x.stride(0), x.stride(1), c_knn, k, flags, _p(idx), _p(dist),
+        _lib.call("fsg_knn_dense_f32", _p(x), B, N, x.stride(0), x.stride(1), c_knn, k, flags, _p(idx), _p(dist), _p(xx),
                   _stream())
     return (idx, dist) if return_dist else idx
 
@@ -104,6 +107,7 @@ class _EdgeConv1(torch.autograd.Function):
         Co, k, dev = two_co // 2, idx.shape[2], pq.device
         gamma, beta = _f32c(gamma), _f32c(beta)
         out = torch.empty(B, Co, N, dtype=torch.float32, device=dev)
+        out_pm = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
         ysel = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
         arg = torch.empty(B, N, Co, dtype=torch.uint8, device=dev)
         if training:
@@ -118,18 +122,19 @@ class _EdgeConv1(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.call("fsg_edgeconv1_fwd_f32", _p(pq), _p(idx), _p(gamma), _p(beta),
                       _p(running_mean if training else None), _p(running_var if training else None), B, N, k, Co,
-                      int(training), momentum, eps, slope, _p(out), _p(ysel), _p(arg), _p(ssum), _p(mean), _p(invstd),
-                      _p(ws), _stream())
+                      int(training), momentum, eps, slope, _p(out), _p(out_pm), _p(ysel), _p(arg), _p(ssum), _p(mean),
+                      _p(invstd), _p(ws), _stream())
         ctx.save_for_backward(pq, idx, gamma, beta, mean, invstd, ysel, arg, ssum)
         ctx.meta = (B, N, k, Co, bool(training), slope)
-        return out
+        return out, out_pm
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_pm):
         pq, idx, gamma, beta, mean, invstd, ysel, arg, ssum = ctx.saved_tensors
         B, N, k, Co, training, slope = ctx.meta
         dev = pq.device
-        g = _f32c(g)
+        g = _f32c(g) if g is not None else None
+        g_pm = _f32c(g_pm) if g_pm is not None else None
         rowptr, col = reverse_graph(idx)
         gpq = torch.empty_like(pq)
         dgamma = torch.empty(Co, dtype=torch.float32, device=dev)
@@ -137,7 +142,7 @@ class _EdgeConv1(torch.autograd.Function):
         h = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
         ws = torch.empty(B * ((N + 63) // 64) * 2 * Co, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.call("fsg_edgeconv1_bwd_f32", _p(g), _p(pq), _p(rowptr), _p(col), _p(gamma), _p(beta), _p(mean),
+            _lib.call("fsg_edgeconv1_bwd_f32", _p(g), _p(g_pm), _p(pq), _p(rowptr), _p(col), _p(gamma), _p(beta), _p(mean),
                       _p(invstd), _p(ysel), _p(arg), _p(ssum), B, N, k, Co, int(training), slope, _p(gpq), _p(dgamma),
                       _p(dbeta), _p(h), _p(ws), _stream())
         return gpq, None, dgamma, dbeta, None, None, None, None, None, None
@@ -147,15 +152,18 @@ def edgeconv1_supported(out_channels, k):
     return out_channels % 64 == 0 and k <= 64
 
 
-def edgeconv1(x, idx, conv_weight, bn, slope):
+def edgeconv1(x, idx, conv_weight, bn, slope, x_pm=None, both=False):
     """Fused single-layer EdgeConv: x (B,C,N), idx (B,N,k) int32, conv_weight (Co,2C,1,1), bn a BatchNorm2d module
-    (its running statistics are updated in place like nn.BatchNorm2d does) -> (B,Co,N)."""
+    (its running statistics are updated in place like nn.BatchNorm2d does) -> (B,Co,N); with both=True also the
+    point-major copy (B,N,Co).  x_pm: optional point-major (B,N,C) copy of x (saves the transpose for the GEMM)."""
     _need_gpu(x, idx, conv_weight)
     Co, C2 = conv_weight.shape[0], conv_weight.shape[1]
     C = C2 // 2
-    W = conv_weight.reshape(Co, C2)
+    W = conv_weight.reshape(Co, C2).to(torch.float32)
     w_cat = torch.cat([W[:, :C], W[:, C:] - W[:, :C]], dim=0)                     # (2Co, C): [W_rel ; W_ctr - W_rel]
-    pq = torch.matmul(x.transpose(1, 2).to(torch.float32), w_cat.t().to(torch.float32))  # (B,N,2Co), plain GEMM
+    if x_pm is None:
+        x_pm = x.transpose(1, 2)
+    pq = torch.nn.functional.linear(x_pm.to(torch.float32), w_cat)               # (B,N,2Co): one plain GEMM
     training = bn.training or bn.running_mean is None
     momentum = 0.0
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
@@ -164,9 +172,11 @@ def edgeconv1(x, idx, conv_weight, bn, slope):
     track = training and bn.track_running_stats
     if idx.dtype != torch.int32:
         idx = idx.to(torch.int32)
-    return _EdgeConv1.apply(pq, idx.contiguous(), bn.weight, bn.bias, bn.running_mean if (track or not training) else None,
-                            bn.running_var if (track or not training) else None, training, float(momentum),
-                            float(bn.eps), float(slope))
+    out, out_pm = _EdgeConv1.apply(pq, idx.contiguous(), bn.weight, bn.bias,
+                                   bn.running_mean if (track or not training) else None,
+                                   bn.running_var if (track or not training) else None, training, float(momentum),
+                                   float(bn.eps), float(slope))
+    return (out, out_pm) if both else out
 
 
 # ------------------------------------------------------------------ Chamfer (losses/chamfer_loss.py:19)

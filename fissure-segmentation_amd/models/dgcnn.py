@@ -43,7 +43,16 @@ class ConvBlock(nn.Module):
 
     def forward(self, x):
         for layer in self.layers:
-            x = layer(x)
+            if isinstance(layer, nn.modules.conv._ConvNd) and layer.kernel_size[0] == 1 and x.is_cuda:
+                # a 1x1 conv is a plain GEMM over the channel axis: call it as one (rocBLAS) instead of going
+                # through MIOpen's convolution solver search
+                w = layer.weight.reshape(layer.out_channels, layer.in_channels)
+                y = torch.matmul(w, x.flatten(2))
+                if layer.bias is not None:
+                    y = y + layer.bias.view(1, -1, 1)
+                x = y.view(x.shape[0], layer.out_channels, *x.shape[2:])
+            else:
+                x = layer(x)
         return x
 
 
@@ -65,7 +74,9 @@ class EdgeConv(nn.Module):
         widths = [2 * in_features, *out_features_list]
         self.shared_mlp = nn.ModuleList(SharedFullyConnected(a, b) for a, b in zip(widths[:-1], widths[1:]))
 
-    def forward(self, x, fixed_knn_graph=None):
+    def forward(self, x, fixed_knn_graph=None, x_pm=None, both=False):
+        """x (B,C,N) -> (B,Cout,N) like the reference; `both=True` additionally returns the point-major copy
+        (B,N,Cout) that the point-wise head consumes, `x_pm` is an optional point-major copy of the input."""
         if len(self.shared_mlp) == 1 and len(self.shared_mlp[0].layers) == 3 and \
                 F_hip.edgeconv1_supported(self.shared_mlp[0].layers[0].out_channels, self.k):
             # fused path: no (B,2C,N,k) / (B,Cout,N,k) tensor is ever written (csrc/edgeconv.hip)
@@ -73,11 +84,22 @@ class EdgeConv(nn.Module):
             if graph is None:
                 graph = F_hip.knn_graph(x, self.k, c_knn=3 if self.first_layer else None, fix_diag=True)
             conv, bn, act = self.shared_mlp[0].layers
-            return F_hip.edgeconv1(x, graph, conv.weight, bn, act.negative_slope)
+            return F_hip.edgeconv1(x, graph, conv.weight, bn, act.negative_slope, x_pm=x_pm, both=both)
         e = create_neighbor_features(x, self.k, fixed_knn_graph, knn_only_over_coords=self.first_layer)
         for layer in self.shared_mlp:
             e = layer(e)
-        return e.max(dim=-1)[0]
+        out = e.max(dim=-1)[0]
+        return (out, out.transpose(1, 2).contiguous()) if both else out
+
+
+def pointwise_block(x_pm, block):
+    """A SharedFullyConnected(dim=1) block applied to point-major rows (M, Cin): the 1x1 Conv1d is one GEMM over all
+    B*N points, BatchNorm1d sees the same B*N samples per channel as on the (B,C,N) layout."""
+    conv = block.layers[0]
+    y = nn.functional.linear(x_pm, conv.weight.view(conv.out_channels, conv.in_channels), conv.bias)
+    for layer in list(block.layers)[1:]:
+        y = layer(y)
+    return y
 
 
 class SpatialTransformer(nn.Module):
@@ -177,12 +199,25 @@ class DGCNNSeg(DGCNNBase):
 
     def forward(self, x):
         x = super().forward(x)
-        x1 = self.ec1(x, self.knn_graph)
-        x2 = self.ec2(x1, self.knn_graph)
-        x3 = self.ec3(x2, self.knn_graph)
-        levels = torch.cat([x1, x2, x3], dim=1)
-        g = self.global_feature(levels)
-        return self.segmentation(torch.cat([levels, g.expand(-1, -1, levels.shape[-1])], dim=1))
+        B, _, N = x.shape
+        # EdgeConvs hand over both layouts: channel-major (B,C,N) feeds the next graph build, point-major (B,N,C)
+        # feeds the GEMMs; the head runs point-major, so every 1x1 conv is ONE GEMM over the B*N points
+        x1, p1 = self.ec1(x, self.knn_graph, both=True)
+        x2, p2 = self.ec2(x1, self.knn_graph, x_pm=p1, both=True)
+        _, p3 = self.ec3(x2, self.knn_graph, x_pm=p2, both=True)
+        levels = torch.cat([p1, p2, p3], dim=2).view(B * N, 192)
+        g = pointwise_block(levels, self.global_feature[0]).view(B, N, -1).max(dim=1)[0]      # (B,1024)
+        # first head layer on cat([levels, g.repeat(N)]) (models/dgcnn.py:159-160 of the reference): the global part
+        # is constant per cloud, so its product is computed once per cloud instead of once per point
+        seg0 = self.segmentation[0]
+        w0 = seg0.layers[0].weight.view(seg0.layers[0].out_channels, -1)
+        y = nn.functional.linear(levels, w0[:, :192]).view(B, N, -1) + nn.functional.linear(g, w0[:, 192:]).unsqueeze(1)
+        y = y.view(B * N, -1)
+        for layer in list(seg0.layers)[1:]:
+            y = layer(y)
+        for block in list(self.segmentation)[1:]:
+            y = pointwise_block(y, block)
+        return y.view(B, N, self.num_classes).transpose(1, 2).contiguous()
 
 
 class DGCNNReg(DGCNNBase):

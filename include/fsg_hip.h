@@ -30,6 +30,10 @@ extern "C" {
 #define FSG_KNN_FIX_DIAG 1   /* force d(i,i) = 0          -- utils/general_utils.py:52            */
 #define FSG_KNN_DROP_FIRST 2 /* select k+1, drop column 0 -- utils/general_utils.py:317,320-322   */
 
+#define FSG_KNN_FORCE_ROWS 4 /* use the general "rows in LDS" kernel even where the MFMA kernel applies (tests) */
+
+#define FSG_KNN_FORCE_MFMA 8 /* use the matrix-core kernel wherever it applies (tests, benchmarks)               */
+
 #define FSG_KNN_MAX_K 64
 
 typedef void *fsg_stream_t;
@@ -44,11 +48,13 @@ const char *fsg_last_error(void);
  *            is passed without a copy; only channels [0, c_knn) enter the distance
  *   idx_out  (B, N, k) int32, ascending (distance, index)
  *   dist_out (B, N, k) fp32 or NULL
+ *   xx_scratch (B, N) fp32 scratch for the squared norms, or NULL (then only the general kernel is used)
  * Arithmetic: d = (xx_i - 2 * dot_ij) + xx_j, dot/xx as channel-ordered fp32 fma chains.
  * Limits: 1 <= k, k + drop <= min(N, FSG_KNN_MAX_K); N <= 32768.
  */
 int fsg_knn_dense_f32(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn,
-                      int k, int flags, int32_t *idx_out, float *dist_out, fsg_stream_t stream);
+                      int k, int flags, int32_t *idx_out, float *dist_out, float *xx_scratch,
+                      fsg_stream_t stream);
 
 /*
  * Edge features: replaces models/dgcnn.py:31-36 (create_neighbor_features: take_along_dim, repeat,
@@ -74,19 +80,21 @@ int fsg_graph_reverse_csr(const int32_t *idx, int B, int N, int k, int32_t *rowp
  * LeakyReLU, max over k) and the get_graph_feature -> conv -> max blocks of models/folding_net.py:120-133.
  * The caller supplies the per-point rows of the decomposed conv (W = [W_rel | W_ctr]):
  *   pq (B,N,2*Co) = [ x^T W_rel^T | x^T (W_ctr - W_rel)^T ]      (one plain GEMM), Co % 64 == 0, k <= 64.
- * Forward outputs: out (B,Co,N); saved for backward: ysel (B,N,Co) selected pre-BN value, arg (B,N,Co) uint8
+ * Forward outputs: out (B,Co,N) and, if non-NULL, out_pm (B,N,Co) (the same values point-major, the layout the
+ *   point-wise head consumes); saved for backward: ysel (B,N,Co) selected pre-BN value, arg (B,N,Co) uint8
  *   selected slot, ssum (B,N,Co) = sum_s y (training only), mean/invstd (Co) (outputs when training, inputs
  *   -- running statistics -- otherwise).  running_mean/var (nullable) are updated in place when training.
  *   workspace: fsg_edgeconv1_workspace_bytes() floats-as-bytes (training only).
- * Backward: grad_out (B,Co,N) -> grad_pq (B,N,2*Co), grad_gamma, grad_beta (Co); h_scratch (B,N,Co) and
+ * Backward: grad_out (B,Co,N) and/or grad_out_pm (B,N,Co) (either may be NULL; both are summed) -> grad_pq (B,N,2*Co), grad_gamma, grad_beta (Co); h_scratch (B,N,Co) and
  *   workspace (2*Co*B*ceil(N/64) floats) are caller-provided scratch.
  */
 size_t fsg_edgeconv1_workspace_bytes(int B, int N, int Co);
 int fsg_edgeconv1_fwd_f32(const float *pq, const int32_t *idx, const float *gamma, const float *beta,
                           float *running_mean, float *running_var, int B, int N, int k, int Co, int training,
-                          float momentum, float eps, float slope, float *out, float *ysel, uint8_t *arg,
-                          float *ssum, float *mean, float *invstd, float *workspace, fsg_stream_t stream);
-int fsg_edgeconv1_bwd_f32(const float *grad_out, const float *pq, const int32_t *rowptr, const int32_t *col,
+                          float momentum, float eps, float slope, float *out, float *out_pm, float *ysel,
+                          uint8_t *arg, float *ssum, float *mean, float *invstd, float *workspace,
+                          fsg_stream_t stream);
+int fsg_edgeconv1_bwd_f32(const float *grad_out, const float *grad_out_pm, const float *pq, const int32_t *rowptr, const int32_t *col,
                           const float *gamma, const float *beta, const float *mean, const float *invstd,
                           const float *ysel, const uint8_t *arg, const float *ssum, int B, int N, int k, int Co,
                           int training, float slope, float *grad_pq, float *grad_gamma, float *grad_beta,

@@ -30,9 +30,9 @@ def test_bad_arguments_are_reported_not_thrown():
     """argument validation happens on the host before any launch, so it is testable without a GPU"""
     from fissure_segmentation_amd import _lib
     with pytest.raises(RuntimeError, match="NULL pointer"):
-        _lib.call("fsg_knn_dense_f32", None, 1, 16, 48, 16, 3, 4, 0, None, None, None)
+        _lib.call("fsg_knn_dense_f32", None, 1, 16, 48, 16, 3, 4, 0, None, None, None, None)
     with pytest.raises(RuntimeError, match="k="):
-        _lib.call("fsg_knn_dense_f32", 1, 1, 16, 48, 16, 3, 65, 0, 1, None, None)
+        _lib.call("fsg_knn_dense_f32", 1, 1, 16, 48, 16, 3, 65, 0, 1, None, None, None)
 
 
 def test_no_cpu_fallback():
