@@ -349,6 +349,52 @@ __global__ __launch_bounds__(256) void ec1_bwd_gather_kernel(
 
 }  // namespace
 
+// launch helpers shared with edgeconv2.hip
+int fsg_ec_stats1_records(int B, int N) { return B * fsg_cdiv(N, TP); }
+
+int fsg_ec_stats1_launch(const float *pq, const int32_t *idx, const float *gamma, int B, int N, int k, int Co,
+                         float *ysel, uint8_t *arg, float *ssum, float *partials, hipStream_t st) {
+    hipLaunchKernelGGL(ec1_stats_select_kernel, dim3(B, fsg_cdiv(N, TP), Co / 64), dim3(256), 0, st, pq, idx, gamma, N,
+                       k, Co, 1, ysel, arg, ssum, partials);
+    FSG_CHECK_LAUNCH("edgeconv/stats");
+    return FSG_OK;
+}
+
+int fsg_ec_finalize_launch(const float *partials, int R, int Co, float eps, float momentum, float *mean, float *invstd,
+                           float *running_mean, float *running_var, hipStream_t st) {
+    hipLaunchKernelGGL(bn_merge_finalize_kernel, dim3(Co / 64), dim3(1024), 0, st, partials, R, Co, eps, momentum, mean,
+                       invstd, running_mean, running_var);
+    FSG_CHECK_LAUNCH("edgeconv/finalize");
+    return FSG_OK;
+}
+
+int fsg_ec_apply_launch(const float *ysel, const float *gamma, const float *beta, const float *mean, const float *invstd,
+                        int B, int N, int Co, float slope, float *out, float *out_pm, hipStream_t st) {
+    hipLaunchKernelGGL(ec1_apply_kernel, dim3(B, fsg_cdiv(N, 64), Co / 64), dim3(256), 0, st, ysel, gamma, beta, mean,
+                       invstd, N, Co, slope, out, out_pm);
+    FSG_CHECK_LAUNCH("edgeconv/apply");
+    return FSG_OK;
+}
+
+int fsg_ec_bwd_point_launch(const float *gout, const float *gout_pm, const float *ysel, const float *gamma,
+                            const float *beta, const float *mean, const float *invstd, int B, int N, int Co, float slope,
+                            float *h, float *partials, float *dbeta, float *dgamma, hipStream_t st) {
+    const int tiles64 = fsg_cdiv(N, 64);
+    hipLaunchKernelGGL(ec1_bwd_point_kernel, dim3(B, tiles64, Co / 64), dim3(256), 0, st, gout, gout_pm, ysel, gamma,
+                       beta, mean, invstd, N, Co, slope, h, partials);
+    FSG_CHECK_LAUNCH("edgeconv/bwd_point");
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(Co / 64, 2), dim3(256), 0, st, partials, B * tiles64, Co, 2, dbeta,
+                       dgamma);
+    FSG_CHECK_LAUNCH("edgeconv/bwd_sum");
+    return FSG_OK;
+}
+
+int fsg_ec_sum_launch(const float *partials, int R, int L, int nvec, float *out0, float *out1, hipStream_t st) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(L / 64, nvec), dim3(256), 0, st, partials, R, L, nvec, out0, out1);
+    FSG_CHECK_LAUNCH("edgeconv/sum");
+    return FSG_OK;
+}
+
 extern "C" int fsg_graph_reverse_csr(const int32_t *idx, int B, int N, int k, int32_t *rowptr, int32_t *col,
                                      fsg_stream_t stream) {
     FSG_REQUIRE(idx && rowptr && col, "fsg_graph_reverse_csr: NULL pointer");

@@ -1,0 +1,611 @@
+// Fused EdgeConv with TWO shared-MLP layers (ec1 of DGCNNSeg: 2C -> 64 -> 64; the spatial transformer's
+// 6 -> 64 -> 128), forward and backward, no per-edge tensor in HBM on the forward and one (du1) on the backward.
+// include/fsg_hip.h: fsg_edgeconv2_{fwd,bwd}_f32.  Replaces models/dgcnn.py:234-241 for len(shared_mlp) == 2.
+//
+// Layer 1 is decomposed exactly like the one-layer kernel (edgeconv.hip): y1(i,s) = P_j + Q_i from per-point rows.
+// Layer 2 is a genuine per-edge contraction y2 = W2 z1, z1 = LeakyReLU(BN1(y1)): a (B N k) x 64 x C2 GEMM that
+// runs on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32 fma chains) out of LDS:
+//   a workgroup owns TP points = R = TP*k edge rows (padded to a multiple of 32, <= RMAX);
+//   phase 1  lanes = channels: gather P rows, y1 -> LDS tile Y1[R][65]
+//   phase 2  waves take (32-row, 32-column) output tiles; A operand z1 = f(a1*y1+b1) is formed on the fly from Y1,
+//            B operand W2 comes from an LDS copy; 32 MFMAs per tile
+//   phase 3  accumulators -> LDS tile Y2[R][C2+1] (aliases Y1 after a barrier)
+//   phase 4  lanes = channels: BN2 statistics (shifted sums), max/min selection over the k rows of each point.
+// BN2 + LeakyReLU are applied to the selected values by ec1_apply_kernel (monotonicity, see edgeconv.hip).
+// Backward recomputes y1, z1, y2 per tile, forms dy2 = a2 (h2[s = arg] - db2 - yhat2 dg2) in LDS, and runs two more
+// MFMA products per tile: dz1 = dy2 W2 (-> du1 = dz1 f'(u1), written once to HBM, and the dbeta1/dgamma1 sums) and
+// dW2 += dy2^T z1 (accumulated in registers over all tiles of the workgroup).  dP/dQ then come from the
+// reverse-graph gather over du1 (no float atomics anywhere).
+#include "fsg_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int C1 = 64;          // width of the first layer (all reference configurations)
+constexpr int LD1 = C1 + 1;     // padded LDS row: column reads by 32 lanes hit 32 banks
+constexpr int MAXPAIR = 3;      // output tiles per wave
+
+__device__ __forceinline__ float lrelu(float u, float slope) { return u > 0.f ? u : u * slope; }
+
+struct Tile {
+    int TP, R, Rpad;
+};
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int C2>
+__global__ __launch_bounds__(256) void ec2_fwd_kernel(const float *__restrict__ pq, const int32_t *__restrict__ idx,
+                                                       const float *__restrict__ w2, const float *__restrict__ gamma1,
+                                                       const float *__restrict__ beta1, const float *__restrict__ mean1,
+                                                       const float *__restrict__ invstd1,
+                                                       const float *__restrict__ gamma2, int N, int k, int TP, int Rpad,
+                                                       int training, float slope, float *__restrict__ ysel,
+                                                       uint8_t *__restrict__ arg, float *__restrict__ ssum,
+                                                       float *__restrict__ partials) {
+    constexpr int LD2 = C2 + 1;
+    constexpr int CT = C2 / 32;   // column tiles
+    constexpr int CG = C2 / 64;   // channel groups of 64 lanes
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *W = sm;                           // [C2][LD1]   W2 row-major, padded
+    float *Y = W + C2 * LD1;                 // [Rpad][max(LD1, LD2)]  y1, later y2
+    float *red = Y + Rpad * (LD2 > LD1 ? LD2 : LD1);  // [3][4][C2]
+
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ld = 2 * C1;
+    const float *P = pq + (long)b * N * ld;
+    const float *Q = P + C1;
+    const int R = TP * k;
+    const int ntiles = (N + TP - 1) / TP;
+
+    for (int t = threadIdx.x; t < C2 * C1; t += 256) W[(t / C1) * LD1 + (t % C1)] = w2[t];
+    const float a1 = gamma1[lane] * invstd1[lane], b1 = beta1[lane] - mean1[lane] * a1;  // lane = channel of layer 1
+    float sgn[CG], shift[CG], s1[CG], s2[CG];
+    bool first[CG];
+#pragma unroll
+    for (int g = 0; g < CG; ++g) {
+        sgn[g] = gamma2[g * 64 + lane] >= 0.f ? 1.f : -1.f;
+        shift[g] = s1[g] = s2[g] = 0.f;
+        first[g] = true;
+    }
+    float cnt = 0.f;
+    // per-lane constants of the MFMA phase
+    const int ql = lane & 31, half = lane >> 5;
+    __syncthreads();
+
+    for (int tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
+        const int i0 = tile * TP;
+        // ---- phase 1: z1 rows into LDS (lanes = layer-1 channels)
+        for (int p = wave; p < TP; p += 4) {
+            const int i = i0 + p;
+            if (i < N) {
+                const int myj = lane < k ? idx[((long)b * N + i) * k + lane] : 0;
+                const float q = Q[(long)i * ld + lane];
+                for (int s0 = 0; s0 < k; s0 += 4) {
+                    float y[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = __builtin_amdgcn_readlane(myj, min(s0 + u, k - 1));
+                        y[u] = P[(long)j * ld + lane];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)  // z1 = LeakyReLU(BN1(y1)), lane = layer-1 channel
+                        if (s0 + u < k) Y[(p * k + s0 + u) * LD1 + lane] = lrelu(__builtin_fmaf(y[u] + q, a1, b1), slope);
+                }
+            } else {
+                for (int s = 0; s < k; ++s) Y[(p * k + s) * LD1 + lane] = 0.f;
+            }
+        }
+        for (int r = R + wave; r < Rpad; r += 4) Y[r * LD1 + lane] = 0.f;
+        __syncthreads();
+
+        // ---- phase 2: y2 = z1 W2^T on the matrix cores; wave takes (row tile, column tile) pairs
+        const int npairs = (Rpad / 32) * CT;
+        f32x16 acc[MAXPAIR];
+#pragma unroll
+        for (int pi = 0; pi < MAXPAIR; ++pi) {
+            const int pr = wave + 4 * pi;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[pi][e] = 0.f;
+            if (pr < npairs) {
+                const int rt = pr / CT, ct = pr - rt * CT;
+                const float *yrow = Y + (rt * 32 + ql) * LD1 + half;
+                const float *wrow = W + (ct * 32 + ql) * LD1 + half;
+#pragma unroll 8
+                for (int s = 0; s < C1 / 2; ++s)
+                    acc[pi] = __builtin_amdgcn_mfma_f32_32x32x2f32(yrow[2 * s], wrow[2 * s], acc[pi], 0, 0, 0);
+            }
+        }
+        __syncthreads();  // every wave is done reading z1
+        // ---- phase 3: accumulators -> Y2[row][col]
+#pragma unroll
+        for (int pi = 0; pi < MAXPAIR; ++pi) {
+            const int pr = wave + 4 * pi;
+            if (pr < npairs) {
+                const int rt = pr / CT, ct = pr - rt * CT;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    Y[row * LD2 + ct * 32 + ql] = acc[pi][e];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase 4: statistics + selection (lanes = layer-2 channels)
+        for (int p = wave; p < TP; p += 4) {
+            const int i = i0 + p;
+            if (i >= N) break;
+#pragma unroll
+            for (int g = 0; g < CG; ++g) {
+                const int c = g * 64 + lane;
+                float best = -INFINITY, tot = 0.f;
+                int barg = 0;
+                for (int s = 0; s < k; ++s) {
+                    const float y = Y[(p * k + s) * LD2 + c];
+                    tot += y;
+                    const float v = sgn[g] * y;
+                    if (v > best) { best = v; barg = s; }
+                    if (training) {
+                        if (first[g]) { shift[g] = y; first[g] = false; }
+                        const float d = y - shift[g];
+                        s1[g] += d;
+                        s2[g] = __builtin_fmaf(d, d, s2[g]);
+                    }
+                }
+                const long o = ((long)b * N + i) * C2 + c;
+                ysel[o] = sgn[g] * best;
+                arg[o] = (uint8_t)barg;
+                if (ssum) ssum[o] = tot;
+            }
+            cnt += (float)k;
+        }
+        __syncthreads();  // Y is rewritten by the next tile
+    }
+    if (!training) return;
+#pragma unroll
+    for (int g = 0; g < CG; ++g) {
+        float mean = 0.f, m2 = 0.f;
+        if (cnt > 0.f) {
+            mean = shift[g] + s1[g] / cnt;
+            m2 = fmaxf(s2[g] - s1[g] * s1[g] / cnt, 0.f);
+        }
+        red[(0 * 4 + wave) * C2 + g * 64 + lane] = cnt;
+        red[(1 * 4 + wave) * C2 + g * 64 + lane] = mean;
+        red[(2 * 4 + wave) * C2 + g * 64 + lane] = m2;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C2; c += 256) {
+        float n = red[(0 * 4 + 0) * C2 + c], mu = red[(1 * 4 + 0) * C2 + c], M2 = red[(2 * 4 + 0) * C2 + c];
+        for (int w = 1; w < 4; ++w) {
+            const float nb = red[(0 * 4 + w) * C2 + c];
+            if (nb > 0.f) {
+                const float tot = n + nb, delta = red[(1 * 4 + w) * C2 + c] - mu;
+                mu += delta * (nb / tot);
+                M2 += red[(2 * 4 + w) * C2 + c] + delta * delta * (n * nb / tot);
+                n = tot;
+            }
+        }
+        const long rec = (long)b * gridDim.y + blockIdx.y;
+        float *pr = partials + rec * 3 * C2;
+        pr[c] = n;
+        pr[C2 + c] = mu;
+        pr[2 * C2 + c] = M2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+template <int C2>
+__global__ __launch_bounds__(256) void ec2_bwd_kernel(
+    const float *__restrict__ pq, const int32_t *__restrict__ idx, const float *__restrict__ w2,
+    const float *__restrict__ gamma1, const float *__restrict__ beta1, const float *__restrict__ mean1,
+    const float *__restrict__ invstd1, const float *__restrict__ gamma2, const float *__restrict__ mean2,
+    const float *__restrict__ invstd2, const float *__restrict__ dbeta2, const float *__restrict__ dgamma2,
+    const float *__restrict__ h2, const uint8_t *__restrict__ arg2, int N, int k, int TP, int Rpad, int training,
+    float invM, float slope, float *__restrict__ du1, float *__restrict__ dw2_part, float *__restrict__ part1) {
+    constexpr int LD2 = C2 + 1;
+    constexpr int CT2 = C2 / 32;          // column tiles of layer 2
+    constexpr int CT1 = C1 / 32;          // column tiles of layer 1 (2)
+    constexpr int NW = CT2 * CT1;         // dW2 tiles (4 or 8)
+    constexpr int WPW = (NW + 3) / 4;     // dW2 tiles per wave
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *W = sm;                         // [C2][LD1]
+    float *Y1 = W + C2 * LD1;              // [Rpad][LD1]  y1
+    float *D = Y1 + Rpad * LD1;            // [Rpad][LD2]  dy2
+    float *Hs = D + Rpad * LD2;            // [TP][C2]     h2 rows of the tile's points
+    float *A1s = Hs + TP * C2;             // [C1] a1, [C1] b1
+    float *red1 = A1s + 2 * C1;            // [2][C1]  sums of du1 and du1*yhat1
+    uint8_t *As = reinterpret_cast<uint8_t *>(red1 + 2 * C1);   // [TP][C2] arg2
+    uint8_t *rowp = As + TP * C2;                                // [Rpad] point of a row, [Rpad] slot of a row
+
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ql = lane & 31, half = lane >> 5;
+    const int ld = 2 * C1;
+    const float *P = pq + (long)b * N * ld;
+    const float *Q = P + C1;
+    const int R = TP * k;
+    const int ntiles = (N + TP - 1) / TP;
+
+    for (int t = threadIdx.x; t < C2 * C1; t += 256) W[(t / C1) * LD1 + (t % C1)] = w2[t];
+    if (threadIdx.x < C1) {
+        const float a = gamma1[threadIdx.x] * invstd1[threadIdx.x];
+        A1s[threadIdx.x] = a;
+        A1s[C1 + threadIdx.x] = beta1[threadIdx.x] - mean1[threadIdx.x] * a;
+    }
+    if (threadIdx.x < 2 * C1) red1[threadIdx.x] = 0.f;
+    for (int r = threadIdx.x; r < Rpad; r += 256) {
+        const int p = r / k;
+        rowp[r] = (uint8_t)p;
+        rowp[Rpad + r] = (uint8_t)(r - p * k);
+    }
+    f32x16 accw[WPW];
+#pragma unroll
+    for (int wi = 0; wi < WPW; ++wi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accw[wi][e] = 0.f;
+    __syncthreads();
+
+    for (int tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
+        const int i0 = tile * TP;
+        const int pvalid = min(TP, N - i0);   // valid points of this tile
+        const int rvalid = pvalid * k;        // valid rows
+        // ---- phase 1: y1 rows (lanes = layer-1 channels), h2/arg2 rows of the tile's points
+        for (int p = wave; p < TP; p += 4) {
+            const int i = i0 + p;
+            if (i < N) {
+                const int myj = lane < k ? idx[((long)b * N + i) * k + lane] : 0;
+                const float q = Q[(long)i * ld + lane];
+                for (int s0 = 0; s0 < k; s0 += 4) {
+                    float y[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = __builtin_amdgcn_readlane(myj, min(s0 + u, k - 1));
+                        y[u] = P[(long)j * ld + lane];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (s0 + u < k) Y1[(p * k + s0 + u) * LD1 + lane] = y[u] + q;
+                }
+            } else {
+                for (int s = 0; s < k; ++s) Y1[(p * k + s) * LD1 + lane] = 0.f;
+            }
+            for (int c = lane; c < C2; c += 64) {
+                Hs[p * C2 + c] = i < N ? h2[((long)b * N + i) * C2 + c] : 0.f;
+                As[p * C2 + c] = i < N ? arg2[((long)b * N + i) * C2 + c] : (uint8_t)255;
+            }
+        }
+        for (int r = R + wave; r < Rpad; r += 4) Y1[r * LD1 + lane] = 0.f;
+        __syncthreads();
+
+        // ---- phase 2+3: y2 = z1 W2^T (MFMA), then dy2 = a2 (h2[s=arg] - db2 - yhat2 dg2) -> D
+        const int npairs = (Rpad / 32) * CT2;
+        for (int pr = wave; pr < npairs; pr += 4) {
+            const int rt = pr / CT2, ct = pr - rt * CT2;
+            const float *yrow = Y1 + (rt * 32 + ql) * LD1 + half;
+            const float *wrow = W + (ct * 32 + ql) * LD1 + half;
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            const bool rowok = rt * 32 + ql < rvalid;  // padding rows must contribute z1 = 0, not f(b1)
+#pragma unroll 8
+            for (int s = 0; s < C1 / 2; ++s) {
+                const int ch = 2 * s + half;
+                float z = lrelu(__builtin_fmaf(yrow[2 * s], A1s[ch], A1s[C1 + ch]), slope);
+                z = rowok ? z : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z, wrow[2 * s], acc, 0, 0, 0);
+            }
+            const int col = ct * 32 + ql;
+            const float r2 = invstd2[col], a2 = gamma2[col] * r2, mu2 = mean2[col];
+            const float db2 = training ? dbeta2[col] * invM : 0.f, dg2 = training ? dgamma2[col] * invM : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                float dy = 0.f;
+                if (row < rvalid) {
+                    const int p = rowp[row], sl = rowp[Rpad + row];
+                    const float hsel = (As[p * C2 + col] == sl) ? Hs[p * C2 + col] : 0.f;
+                    const float yhat = (acc[e] - mu2) * r2;
+                    dy = a2 * (hsel - db2 - yhat * dg2);
+                }
+                D[row * LD2 + col] = dy;
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 4: dz1 = dy2 W2 (MFMA) -> du1 = dz1 f'(u1); sums for dbeta1 / dgamma1; du1 rows to HBM
+        const int npairs1 = (Rpad / 32) * CT1;
+        for (int pr = wave; pr < npairs1; pr += 4) {
+            const int rt = pr / CT1, ct = pr - rt * CT1;
+            const float *drow = D + (rt * 32 + ql) * LD2 + half;
+            const float *wcol = W + half * LD1 + ct * 32 + ql;
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll 8
+            for (int s = 0; s < C2 / 2; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(drow[2 * s], wcol[2 * s * LD1], acc, 0, 0, 0);
+            const int c1 = ct * 32 + ql;
+            const float a1 = A1s[c1], b1 = A1s[C1 + c1], mu1 = mean1[c1], r1 = invstd1[c1];
+            float sb = 0.f, sg = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (row < rvalid) {
+                    const float y1 = Y1[row * LD1 + c1];
+                    const float u1 = __builtin_fmaf(y1, a1, b1);
+                    const float du = acc[e] * (u1 > 0.f ? 1.f : slope);
+                    du1[(((long)b * N + i0) * k + row) * C1 + c1] = du;
+                    sb += du;
+                    sg = __builtin_fmaf(du, (y1 - mu1) * r1, sg);
+                }
+            }
+            atomicAdd(&red1[c1], sb);
+            atomicAdd(&red1[C1 + c1], sg);
+        }
+
+        // ---- phase 5: dW2 += dy2^T z1 (MFMA, K = rows); accumulators live across the tiles of this workgroup
+#pragma unroll
+        for (int wi = 0; wi < WPW; ++wi) {
+            const int tw = wave + 4 * wi;
+            if (tw < NW) {
+                const int ct2 = tw / CT1, ct1 = tw - ct2 * CT1;
+                const int c1 = ct1 * 32 + ql;
+                const float a1 = A1s[c1], b1 = A1s[C1 + c1];
+                const float *dcol = D + half * LD2 + ct2 * 32 + ql;
+                const float *ycol = Y1 + half * LD1 + c1;
+                for (int s = 0; s < Rpad / 2; ++s) {
+                    const int row = 2 * s + half;
+                    float z = lrelu(__builtin_fmaf(ycol[2 * s * LD1], a1, b1), slope);
+                    z = row < rvalid ? z : 0.f;
+                    accw[wi] = __builtin_amdgcn_mfma_f32_32x32x2f32(dcol[2 * s * LD2], z, accw[wi], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();  // Y1 / D / Hs are rewritten by the next tile
+    }
+    // ---- epilogue: dW2 partial tile(s) and the dbeta1/dgamma1 partial sums of this workgroup
+    const long rec = (long)b * gridDim.y + blockIdx.y;
+#pragma unroll
+    for (int wi = 0; wi < WPW; ++wi) {
+        const int tw = wave + 4 * wi;
+        if (tw < NW) {
+            const int ct2 = tw / CT1, ct1 = tw - ct2 * CT1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c2 = ct2 * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                dw2_part[(rec * C2 + c2) * C1 + ct1 * 32 + ql] = accw[wi][e];
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * C1) part1[rec * 2 * C1 + threadIdx.x] = red1[threadIdx.x];
+}
+
+// one wave per destination point j: dP_j from the in-edges' du1 rows (reverse graph), dQ_j from its own k rows
+__global__ __launch_bounds__(256) void ec2_bwd_gather_kernel(
+    const float *__restrict__ pq, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ du1, const float *__restrict__ ssum1, const float *__restrict__ gamma1,
+    const float *__restrict__ mean1, const float *__restrict__ invstd1, const float *__restrict__ dbeta1,
+    const float *__restrict__ dgamma1, int N, int k, int training, float invM, float *__restrict__ grad_pq) {
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.y * 4 + wave;
+    if (j >= N) return;
+    const int c = lane;
+    const int ld = 2 * C1;
+    const float *P = pq + (long)b * N * ld;
+    const float *Q = P + C1;
+    const int beg = rowptr[(long)b * (N + 1) + j], end = rowptr[(long)b * (N + 1) + j + 1];
+    const int32_t *cb = col + (long)b * N * k;
+    float ad = 0.f, aq = 0.f;
+    for (int t0 = beg; t0 < end; t0 += 64) {
+        const int mye = (t0 + lane < end) ? cb[t0 + lane] : 0;
+        const int cnt = min(64, end - t0);
+        for (int t = 0; t < cnt; t += 2) {
+            const int e0 = __builtin_amdgcn_readlane(mye, t);
+            const int e1 = __builtin_amdgcn_readlane(mye, min(t + 1, cnt - 1));
+            const long r0 = ((long)b * N + (e0 >> 6)) * k + (e0 & 63), r1 = ((long)b * N + (e1 >> 6)) * k + (e1 & 63);
+            const float d0 = du1[r0 * C1 + c], d1 = du1[r1 * C1 + c];
+            float q0 = 0.f, q1 = 0.f;
+            if (training) {
+                q0 = Q[(long)(e0 >> 6) * ld + c];
+                q1 = Q[(long)(e1 >> 6) * ld + c];
+            }
+            ad += d0;
+            aq += q0;
+            if (t + 1 < cnt) {
+                ad += d1;
+                aq += q1;
+            }
+        }
+    }
+    float own = 0.f;
+    const float *dj = du1 + (((long)b * N + j) * k) * C1 + c;
+    for (int s = 0; s < k; ++s) own += dj[(long)s * C1];
+    const float r = invstd1[c], coef = r * gamma1[c], mu = mean1[c];
+    float dp = ad, dq = own;
+    if (training) {
+        const float db = dbeta1[c] * invM, dg = dgamma1[c] * invM * r;
+        const float deg = (float)(end - beg);
+        dp -= deg * db + dg * (deg * (P[(long)j * ld + c] - mu) + aq);
+        dq -= (float)k * db + dg * (ssum1[((long)b * N + j) * C1 + c] - (float)k * mu);
+    }
+    float *gp = grad_pq + ((long)b * N + j) * ld;
+    gp[c] = coef * dp;
+    gp[C1 + c] = coef * dq;
+}
+
+}  // namespace
+
+// shared with edgeconv.hip
+int fsg_ec_stats1_launch(const float *pq, const int32_t *idx, const float *gamma, int B, int N, int k, int Co,
+                         float *ysel, uint8_t *arg, float *ssum, float *partials, hipStream_t st);
+int fsg_ec_finalize_launch(const float *partials, int R, int Co, float eps, float momentum, float *mean, float *invstd,
+                           float *running_mean, float *running_var, hipStream_t st);
+int fsg_ec_apply_launch(const float *ysel, const float *gamma, const float *beta, const float *mean, const float *invstd,
+                        int B, int N, int Co, float slope, float *out, float *out_pm, hipStream_t st);
+int fsg_ec_stats1_records(int B, int N);
+
+static void ec2_tiling(int k, int C2, int &TP, int &Rpad, int &G, int B, int N) {
+    const int rmax = C2 == 64 ? 192 : 96;
+    TP = rmax / k;
+    if (TP < 1) TP = 1;
+    Rpad = (TP * k + 31) & ~31;
+    const int ntiles = (N + TP - 1) / TP;
+    G = 768 / (B > 0 ? B : 1);  // about three workgroups per CU in flight
+    if (G < 1) G = 1;
+    if (G > ntiles) G = ntiles;
+}
+
+extern "C" size_t fsg_edgeconv2_workspace_bytes(int B, int N, int k, int C2) {
+    int TP, Rpad, G;
+    ec2_tiling(k, C2, TP, Rpad, G, B, N);
+    const size_t rec1 = (size_t)fsg_ec_stats1_records(B, N) * 3 * C1;
+    const size_t rec2 = (size_t)B * G * 3 * C2;
+    // layer-1 scratch: ysel1 (unused output of the shared stats kernel), arg1
+    const size_t scratch1 = (size_t)B * N * C1 * sizeof(float) + (size_t)B * N * C1;
+    return sizeof(float) * (rec1 + rec2) + scratch1 + 256;
+}
+
+extern "C" int fsg_edgeconv2_fwd_f32(const float *pq, const int32_t *idx, const float *w2, const float *gamma1,
+                                     const float *beta1, float *running_mean1, float *running_var1, const float *gamma2,
+                                     const float *beta2, float *running_mean2, float *running_var2, int B, int N, int k,
+                                     int C2, int training, float momentum1, float momentum2, float eps1, float eps2,
+                                     float slope, float *out, float *out_pm, float *ssum1, float *mean1, float *invstd1,
+                                     float *ysel2, uint8_t *arg2, float *ssum2, float *mean2, float *invstd2,
+                                     void *workspace, fsg_stream_t stream) {
+    FSG_REQUIRE(pq && idx && w2 && gamma1 && beta1 && gamma2 && beta2 && out && mean1 && invstd1 && ysel2 && arg2 &&
+                    mean2 && invstd2 && workspace,
+                "fsg_edgeconv2_fwd_f32: NULL pointer");
+    FSG_REQUIRE(B > 0 && N > 0 && k > 0 && k <= 64 && (C2 == 64 || C2 == 128) && B <= 65535,
+                "fsg_edgeconv2_fwd_f32: bad shape B=%d N=%d k=%d C2=%d (layer widths 64 -> 64|128 only)", B, N, k, C2);
+    FSG_REQUIRE(!training || (ssum1 && ssum2), "fsg_edgeconv2_fwd_f32: training needs ssum1/ssum2");
+    hipStream_t st = (hipStream_t)stream;
+    int TP, Rpad, G;
+    ec2_tiling(k, C2, TP, Rpad, G, B, N);
+    const int rec1 = fsg_ec_stats1_records(B, N);
+    float *part1 = (float *)workspace;
+    float *part2 = part1 + (size_t)rec1 * 3 * C1;
+    float *ysel1 = part2 + (size_t)B * G * 3 * C2;
+    uint8_t *arg1 = (uint8_t *)(ysel1 + (size_t)B * N * C1);
+    int rc;
+    if (training) {  // BN1 statistics over all edges of y1 = P_j + Q_i (shared kernel; its selection output is unused)
+        if ((rc = fsg_ec_stats1_launch(pq, idx, gamma1, B, N, k, C1, ysel1, arg1, ssum1, part1, st)) != FSG_OK) return rc;
+        if ((rc = fsg_ec_finalize_launch(part1, rec1, C1, eps1, momentum1, mean1, invstd1, running_mean1, running_var1,
+                                         st)) != FSG_OK)
+            return rc;
+    }
+    const size_t lds = sizeof(float) * ((size_t)C2 * LD1 + (size_t)Rpad * (C2 + 1) + 3 * 4 * C2);
+    if (C2 == 64) {
+        static bool granted = false;
+        if (!granted) {
+            if (hipFuncSetAttribute((const void *)ec2_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) {
+                fsg_set_error("fsg_edgeconv2_fwd_f32: cannot raise dynamic LDS");
+                return FSG_ERR_HIP;
+            }
+            granted = true;
+        }
+        hipLaunchKernelGGL(ec2_fwd_kernel<64>, dim3(B, G), dim3(256), lds, st, pq, idx, w2, gamma1, beta1, mean1, invstd1,
+                           gamma2, N, k, TP, Rpad, training, slope, ysel2, arg2, ssum2, part2);
+    } else {
+        static bool granted = false;
+        if (!granted) {
+            if (hipFuncSetAttribute((const void *)ec2_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) {
+                fsg_set_error("fsg_edgeconv2_fwd_f32: cannot raise dynamic LDS");
+                return FSG_ERR_HIP;
+            }
+            granted = true;
+        }
+        hipLaunchKernelGGL(ec2_fwd_kernel<128>, dim3(B, G), dim3(256), lds, st, pq, idx, w2, gamma1, beta1, mean1,
+                           invstd1, gamma2, N, k, TP, Rpad, training, slope, ysel2, arg2, ssum2, part2);
+    }
+    FSG_CHECK_LAUNCH("fsg_edgeconv2_fwd_f32/mlp");
+    if (training) {
+        if ((rc = fsg_ec_finalize_launch(part2, B * G, C2, eps2, momentum2, mean2, invstd2, running_mean2, running_var2,
+                                         st)) != FSG_OK)
+            return rc;
+    }
+    return fsg_ec_apply_launch(ysel2, gamma2, beta2, mean2, invstd2, B, N, C2, slope, out, out_pm, st);
+}
+
+int fsg_ec_bwd_point_launch(const float *gout, const float *gout_pm, const float *ysel, const float *gamma,
+                            const float *beta, const float *mean, const float *invstd, int B, int N, int Co, float slope,
+                            float *h, float *partials, float *dbeta, float *dgamma, hipStream_t st);
+int fsg_ec_sum_launch(const float *partials, int R, int L, int nvec, float *out0, float *out1, hipStream_t st);
+
+static void ec2_bwd_tiling(int k, int C2, int &TP, int &Rpad, int &G, int B, int N) {
+    const int rmax = C2 == 64 ? 96 : 64;
+    TP = rmax / k;
+    if (TP < 1) TP = 1;
+    Rpad = (TP * k + 31) & ~31;
+    const int ntiles = (N + TP - 1) / TP;
+    G = 512 / (B > 0 ? B : 1);
+    if (G < 1) G = 1;
+    if (G > ntiles) G = ntiles;
+}
+
+extern "C" size_t fsg_edgeconv2_bwd_workspace_bytes(int B, int N, int k, int C2) {
+    int TP, Rpad, G;
+    ec2_bwd_tiling(k, C2, TP, Rpad, G, B, N);
+    const size_t point_rec = (size_t)B * fsg_cdiv(N, 64) * 2 * C2;       // ec1_bwd_point partials
+    const size_t dw = (size_t)B * G * C2 * C1, p1 = (size_t)B * G * 2 * C1;
+    const size_t du = (size_t)B * N * k * C1;
+    return sizeof(float) * (point_rec + dw + p1 + du + (size_t)B * N * C2) + 256;
+}
+
+extern "C" int fsg_edgeconv2_bwd_f32(const float *grad_out, const float *grad_out_pm, const float *pq, const int32_t *idx,
+                                     const int32_t *rowptr, const int32_t *col, const float *w2, const float *gamma1,
+                                     const float *beta1, const float *mean1, const float *invstd1, const float *ssum1,
+                                     const float *gamma2, const float *beta2, const float *mean2, const float *invstd2,
+                                     const float *ysel2, const uint8_t *arg2, int B, int N, int k, int C2, int training,
+                                     float slope, float *grad_pq, float *grad_w2, float *grad_gamma1, float *grad_beta1,
+                                     float *grad_gamma2, float *grad_beta2, void *workspace, fsg_stream_t stream) {
+    FSG_REQUIRE((grad_out || grad_out_pm) && pq && idx && rowptr && col && w2 && gamma1 && beta1 && mean1 && invstd1 &&
+                    gamma2 && beta2 && mean2 && invstd2 && ysel2 && arg2 && grad_pq && grad_w2 && grad_gamma1 &&
+                    grad_beta1 && grad_gamma2 && grad_beta2 && workspace,
+                "fsg_edgeconv2_bwd_f32: NULL pointer");
+    FSG_REQUIRE(!training || ssum1, "fsg_edgeconv2_bwd_f32: training needs ssum1");
+    FSG_REQUIRE(B > 0 && N > 0 && k > 0 && k <= 64 && (C2 == 64 || C2 == 128) && B <= 65535,
+                "fsg_edgeconv2_bwd_f32: bad shape B=%d N=%d k=%d C2=%d", B, N, k, C2);
+    hipStream_t st = (hipStream_t)stream;
+    int TP, Rpad, G;
+    ec2_bwd_tiling(k, C2, TP, Rpad, G, B, N);
+    float *point_part = (float *)workspace;
+    float *dw_part = point_part + (size_t)B * fsg_cdiv(N, 64) * 2 * C2;
+    float *p1_part = dw_part + (size_t)B * G * C2 * C1;
+    float *du1 = p1_part + (size_t)B * G * 2 * C1;
+    float *h2 = du1 + (size_t)B * N * k * C1;
+    int rc;
+    // h2 = grad_out f'(u2) on the selected edge, dbeta2 / dgamma2
+    if ((rc = fsg_ec_bwd_point_launch(grad_out, grad_out_pm, ysel2, gamma2, beta2, mean2, invstd2, B, N, C2, slope, h2,
+                                      point_part, grad_beta2, grad_gamma2, st)) != FSG_OK)
+        return rc;
+    const float invM = 1.0f / ((float)B * (float)N * (float)k);
+    const size_t lds = sizeof(float) * ((size_t)C2 * LD1 + (size_t)Rpad * LD1 + (size_t)Rpad * (C2 + 1) + (size_t)TP * C2 +
+                                        2 * C1 + 2 * C1) + (size_t)TP * C2 + 2 * (size_t)Rpad + 16;
+#define FSG_EC2_BWD(CC)                                                                                                  \
+    do {                                                                                                                 \
+        static bool granted = false;                                                                                     \
+        if (!granted) {                                                                                                  \
+            if (hipFuncSetAttribute((const void *)ec2_bwd_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                                    160 * 1024 - 512) != hipSuccess) {                                                   \
+                fsg_set_error("fsg_edgeconv2_bwd_f32: cannot raise dynamic LDS");                                        \
+                return FSG_ERR_HIP;                                                                                      \
+            }                                                                                                            \
+            granted = true;                                                                                              \
+        }                                                                                                                \
+        hipLaunchKernelGGL(ec2_bwd_kernel<CC>, dim3(B, G), dim3(256), lds, st, pq, idx, w2, gamma1, beta1, mean1, invstd1, \
+                           gamma2, mean2, invstd2, grad_beta2, grad_gamma2, h2, arg2, N, k, TP, Rpad, training, invM,    \
+                           slope, du1, dw_part, p1_part);                                                                \
+    } while (0)
+    if (C2 == 64) FSG_EC2_BWD(64);
+    else FSG_EC2_BWD(128);
+#undef FSG_EC2_BWD
+    FSG_CHECK_LAUNCH("fsg_edgeconv2_bwd_f32/mlp");
+    if ((rc = fsg_ec_sum_launch(dw_part, B * G, C2 * C1, 1, grad_w2, nullptr, st)) != FSG_OK) return rc;
+    if ((rc = fsg_ec_sum_launch(p1_part, B * G, C1, 2, grad_beta1, grad_gamma1, st)) != FSG_OK) return rc;
+    hipLaunchKernelGGL(ec2_bwd_gather_kernel, dim3(B, fsg_cdiv(N, 4)), dim3(256), 0, st, pq, rowptr, col, du1, ssum1,
+                       gamma1, mean1, invstd1, grad_beta1, grad_gamma1, N, k, training, invM, grad_pq);
+    FSG_CHECK_LAUNCH("fsg_edgeconv2_bwd_f32/gather");
+    return FSG_OK;
+}

@@ -179,6 +179,93 @@ def edgeconv1(x, idx, conv_weight, bn, slope, x_pm=None, both=False):
     return (out, out_pm) if both else out
 
 
+class _EdgeConv2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pq, idx, w2, g1, b1, rm1, rv1, g2, b2, rm2, rv2, training, mom1, mom2, eps1, eps2, slope):
+        pq, w2 = _f32c(pq), _f32c(w2)
+        g1, b1, g2, b2 = _f32c(g1), _f32c(b1), _f32c(g2), _f32c(b2)
+        B, N, _ = pq.shape
+        C2, k, dev = w2.shape[0], idx.shape[2], pq.device
+
+        def new(*shape, dtype=torch.float32):
+            return torch.empty(*shape, dtype=dtype, device=dev)
+        out, out_pm = new(B, C2, N), new(B, N, C2)
+        ysel2, arg2 = new(B, N, C2), new(B, N, C2, dtype=torch.uint8)
+        if training:
+            ssum1, ssum2 = new(B, N, 64), new(B, N, C2)
+            mean1, invstd1, mean2, invstd2 = new(64), new(64), new(C2), new(C2)
+        else:
+            ssum1 = ssum2 = None
+            mean1, invstd1 = rm1.detach().float().contiguous(), torch.rsqrt(rv1.detach().float() + eps1).contiguous()
+            mean2, invstd2 = rm2.detach().float().contiguous(), torch.rsqrt(rv2.detach().float() + eps2).contiguous()
+        ws = new(_lib.lib.fsg_edgeconv2_workspace_bytes(B, N, k, C2), dtype=torch.uint8)
+        t = bool(training)
+        with torch.cuda.device(dev):
+            _lib.call("fsg_edgeconv2_fwd_f32", _p(pq), _p(idx), _p(w2), _p(g1), _p(b1), _p(rm1 if t else None),
+                      _p(rv1 if t else None), _p(g2), _p(b2), _p(rm2 if t else None), _p(rv2 if t else None), B, N, k, C2,
+                      int(t), mom1, mom2, eps1, eps2, slope, _p(out), _p(out_pm), _p(ssum1), _p(mean1), _p(invstd1),
+                      _p(ysel2), _p(arg2), _p(ssum2), _p(mean2), _p(invstd2), _p(ws), _stream())
+        ctx.save_for_backward(pq, idx, w2, g1, b1, mean1, invstd1, ssum1, g2, b2, mean2, invstd2, ysel2, arg2)
+        ctx.meta = (B, N, k, C2, t, slope)
+        return out, out_pm
+
+    @staticmethod
+    def backward(ctx, g, g_pm):
+        pq, idx, w2, g1, b1, mean1, invstd1, ssum1, g2, b2, mean2, invstd2, ysel2, arg2 = ctx.saved_tensors
+        B, N, k, C2, training, slope = ctx.meta
+        dev = pq.device
+        g = _f32c(g) if g is not None else None
+        g_pm = _f32c(g_pm) if g_pm is not None else None
+        rowptr, col = reverse_graph(idx)
+        gpq, gw2 = torch.empty_like(pq), torch.empty_like(w2)
+        dg1, db1 = torch.empty_like(g1), torch.empty_like(b1)
+        dg2, db2 = torch.empty_like(g2), torch.empty_like(b2)
+        ws = torch.empty(_lib.lib.fsg_edgeconv2_bwd_workspace_bytes(B, N, k, C2), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("fsg_edgeconv2_bwd_f32", _p(g), _p(g_pm), _p(pq), _p(idx), _p(rowptr), _p(col), _p(w2), _p(g1),
+                      _p(b1), _p(mean1), _p(invstd1), _p(ssum1), _p(g2), _p(b2), _p(mean2), _p(invstd2), _p(ysel2),
+                      _p(arg2), B, N, k, C2, int(training), slope, _p(gpq), _p(gw2), _p(dg1), _p(db1), _p(dg2), _p(db2),
+                      _p(ws), _stream())
+        return (gpq, None, gw2, dg1, db1, None, None, dg2, db2) + (None,) * 8
+
+
+def edgeconv2_supported(c_mid, c_out, k):
+    return c_mid == 64 and c_out in (64, 128) and k <= 64
+
+
+def _bn_step(bn):
+    """training flag + momentum of one BatchNorm module for this call (bumps num_batches_tracked like torch)."""
+    training = bn.training or bn.running_mean is None
+    momentum = 0.0
+    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        momentum = (1.0 / float(bn.num_batches_tracked)) if bn.momentum is None else bn.momentum
+    return training, float(momentum)
+
+
+def edgeconv2(x, idx, conv1_weight, bn1, conv2_weight, bn2, slope, x_pm=None, both=False):
+    """Fused two-layer EdgeConv (2C -> 64 -> 64|128): see csrc/edgeconv2.hip."""
+    _need_gpu(x, idx, conv1_weight, conv2_weight)
+    C1, CC = conv1_weight.shape[0], conv1_weight.shape[1]
+    C = CC // 2
+    W = conv1_weight.reshape(C1, CC).to(torch.float32)
+    w_cat = torch.cat([W[:, :C], W[:, C:] - W[:, :C]], dim=0)
+    if x_pm is None:
+        x_pm = x.transpose(1, 2)
+    pq = torch.nn.functional.linear(x_pm.to(torch.float32), w_cat)               # (B,N,128)
+    w2 = conv2_weight.reshape(conv2_weight.shape[0], C1)
+    t1, m1 = _bn_step(bn1)
+    t2, m2 = _bn_step(bn2)
+    if t1 != t2:
+        raise RuntimeError("edgeconv2: both BatchNorm layers must be in the same mode")
+    if idx.dtype != torch.int32:
+        idx = idx.to(torch.int32)
+    out, out_pm = _EdgeConv2.apply(pq, idx.contiguous(), w2, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
+                                   bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, t1, m1, m2, float(bn1.eps),
+                                   float(bn2.eps), float(slope))
+    return (out, out_pm) if both else out
+
+
 # ------------------------------------------------------------------ Chamfer (losses/chamfer_loss.py:19)
 class _ChamferNN(torch.autograd.Function):
     @staticmethod

@@ -85,6 +85,15 @@ class EdgeConv(nn.Module):
                 graph = F_hip.knn_graph(x, self.k, c_knn=3 if self.first_layer else None, fix_diag=True)
             conv, bn, act = self.shared_mlp[0].layers
             return F_hip.edgeconv1(x, graph, conv.weight, bn, act.negative_slope, x_pm=x_pm, both=both)
+        if len(self.shared_mlp) == 2 and all(len(m.layers) == 3 for m in self.shared_mlp) and \
+                F_hip.edgeconv2_supported(self.shared_mlp[0].layers[0].out_channels,
+                                          self.shared_mlp[1].layers[0].out_channels, self.k):
+            graph = fixed_knn_graph
+            if graph is None:
+                graph = F_hip.knn_graph(x, self.k, c_knn=3 if self.first_layer else None, fix_diag=True)
+            (conv1, bn1, act), (conv2, bn2, _) = self.shared_mlp[0].layers, self.shared_mlp[1].layers
+            return F_hip.edgeconv2(x, graph, conv1.weight, bn1, conv2.weight, bn2, act.negative_slope, x_pm=x_pm,
+                                   both=both)
         e = create_neighbor_features(x, self.k, fixed_knn_graph, knn_only_over_coords=self.first_layer)
         for layer in self.shared_mlp:
             e = layer(e)

@@ -101,6 +101,32 @@ int fsg_edgeconv1_bwd_f32(const float *grad_out, const float *grad_out_pm, const
                           float *h_scratch, float *workspace, fsg_stream_t stream);
 
 /*
+ * Fused EdgeConv with TWO shared-MLP layers (2C -> 64 -> C2, C2 = 64 or 128): replaces models/dgcnn.py:234-241 for
+ * len(shared_mlp) == 2 (ec1 of DGCNNSeg, the EdgeConv of the SpatialTransformer).  Layer 1 arrives decomposed as
+ * pq (B,N,128) = [P | Q] like fsg_edgeconv1; w2 (C2,64) is the second 1x1 conv; *1 / *2 are the two BatchNorms.
+ * Forward saves ssum1 (B,N,64), mean1/invstd1, ysel2/arg2/ssum2 (B,N,C2), mean2/invstd2 for the backward
+ * (mean/invstd are INPUTS -- running statistics -- when training == 0).  Backward returns grad_pq (B,N,128),
+ * grad_w2 (C2,64) and the four BatchNorm parameter gradients.  Workspaces: fsg_edgeconv2_workspace_bytes /
+ * fsg_edgeconv2_bwd_workspace_bytes (the backward one holds the only per-edge tensor, du1 (B*N*k, 64)).
+ */
+size_t fsg_edgeconv2_workspace_bytes(int B, int N, int k, int C2);
+size_t fsg_edgeconv2_bwd_workspace_bytes(int B, int N, int k, int C2);
+int fsg_edgeconv2_fwd_f32(const float *pq, const int32_t *idx, const float *w2, const float *gamma1,
+                          const float *beta1, float *running_mean1, float *running_var1, const float *gamma2,
+                          const float *beta2, float *running_mean2, float *running_var2, int B, int N, int k, int C2,
+                          int training, float momentum1, float momentum2, float eps1, float eps2, float slope,
+                          float *out, float *out_pm, float *ssum1, float *mean1, float *invstd1, float *ysel2,
+                          uint8_t *arg2, float *ssum2, float *mean2, float *invstd2, void *workspace,
+                          fsg_stream_t stream);
+int fsg_edgeconv2_bwd_f32(const float *grad_out, const float *grad_out_pm, const float *pq, const int32_t *idx,
+                          const int32_t *rowptr, const int32_t *col, const float *w2, const float *gamma1,
+                          const float *beta1, const float *mean1, const float *invstd1, const float *ssum1,
+                          const float *gamma2, const float *beta2, const float *mean2, const float *invstd2,
+                          const float *ysel2, const uint8_t *arg2, int B, int N, int k, int C2, int training,
+                          float slope, float *grad_pq, float *grad_w2, float *grad_gamma1, float *grad_beta1,
+                          float *grad_gamma2, float *grad_beta2, void *workspace, fsg_stream_t stream);
+
+/*
  * Chamfer nearest neighbour, one direction: replaces the pytorch3d.loss.chamfer_distance call of
  * losses/chamfer_loss.py:19 (and losses/mesh_loss.py:29-31, train_pc_ae.py:88).
  *   x (B,N,3), y (B,M,3) fp32 -> dist (B,N) = min_j |x_i - y_j|^2, arg (B,N) int32 (lowest j on ties)

@@ -37,7 +37,7 @@ if "knnablate" in which:
             print(f"knn C={C} {name:16s}: median {med:8.1f} us")
 if "edgeconv" in which:
     from fissure_segmentation_amd.models.dgcnn import EdgeConv
-    for (B, C, N, k, couts) in [(8, 64, 2048, 20, [64]), (8, 3, 2048, 20, [64, 64]), (4, 64, 8192, 40, [64])]:
+    for (B, C, N, k, couts) in [(8, 64, 2048, 20, [64]), (8, 3, 2048, 20, [64, 64]), (4, 64, 8192, 40, [64]), (4, 3, 8192, 40, [64, 64])]:
         ec = EdgeConv(C, couts, k, first_layer=(C == 3)).to(dev).train()
         x = torch.from_numpy(cloud(1, B, C, N)).to(dev).requires_grad_(True)
         idx = F.knn_graph(x, k, c_knn=3 if C == 3 else None)
