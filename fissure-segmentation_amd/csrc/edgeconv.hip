@@ -170,6 +170,7 @@ __global__ __launch_bounds__(1024) void bn_merge_finalize_kernel(const float *__
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     double sn = 0.0, sm = 0.0;
+#pragma unroll 8
     for (int r = slice; r < R; r += 16) {
         const float *pr = partials + (long)r * 3 * Co;
         const double nb = pr[c];
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(1024) void bn_merge_finalize_kernel(const float *__
     const double mu = gmean[lane], n = red[0][0][lane];
     __syncthreads();
     double M2 = 0.0;
+#pragma unroll 8
     for (int r = slice; r < R; r += 16) {
         const float *pr = partials + (long)r * 3 * Co;
         const double d = (double)pr[Co + c] - mu;
@@ -287,6 +289,7 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float *__restri
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane, v = blockIdx.y;
     double acc = 0.0;
+#pragma unroll 8
     for (int r = slice; r < R; r += 4) acc += partials[((long)r * nvec + v) * Co + c];
     red[slice][lane] = acc;
     __syncthreads();

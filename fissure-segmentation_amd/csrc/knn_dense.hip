@@ -111,6 +111,8 @@ __global__ __launch_bounds__(BLOCK) void knn_dense_rows_kernel(
 
 }  // namespace
 
+int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k,
+                             int flags, int32_t *idx_out, float *dist_out, float *xx_scratch, hipStream_t st);
 int fsg_knn_mfma_launch(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k, int flags,
                         int32_t *idx_out, float *dist_out, float *xx_scratch, hipStream_t st);  // knn_mfma.hip
 
@@ -125,11 +127,11 @@ extern "C" int fsg_knn_dense_f32(const float *x, int B, int N, int64_t stride_b,
     FSG_REQUIRE(N <= 32768, "fsg_knn_dense_f32: N=%d > 32768 unsupported", N);
     if (B == 0) return FSG_OK;
     hipStream_t st = (hipStream_t)stream;
-    // measured on MI355X (tools/bench_kernels.py): the matrix-core kernel wins for few channels or long clouds, the
-    // rows kernel for C >= 64 at N = 2048 (the MFMA kernel is still latency-bound at one wave per SIMD)
-    const bool mfma_pays = c_knn <= 16 || N >= 4096;
-    if (!(flags & FSG_KNN_FORCE_ROWS) && (mfma_pays || (flags & FSG_KNN_FORCE_MFMA))) {
+    if (flags & FSG_KNN_FORCE_MFMA) {  // the first matrix-core design (per-lane filter + sorting network), kept for tests
         const int rc = fsg_knn_mfma_launch(x, B, N, stride_b, stride_c, c_knn, k, flags, idx_out, dist_out, xx_scratch, st);
+        if (rc != FSG_ERR_UNSUPPORTED) return rc;
+    } else if (!(flags & FSG_KNN_FORCE_ROWS)) {  // production path
+        const int rc = fsg_knn_rows_mfma_launch(x, B, N, stride_b, stride_c, c_knn, k, flags, idx_out, dist_out, xx_scratch, st);
         if (rc != FSG_ERR_UNSUPPORTED) return rc;
     }
     const int Npad = (N + 255) & ~255;

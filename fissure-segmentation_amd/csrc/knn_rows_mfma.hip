@@ -1,0 +1,319 @@
+// Dense kNN graph build, production kernel behind fsg_knn_dense_f32 (c_knn <= 128, N <= 65535, k+drop <= 64).
+//
+// A 512-thread workgroup owns 32 query points of one cloud and sweeps the candidates in chunks of 1024:
+//   phase A  the 32 x 1024 distance block of the chunk is produced on the matrix cores
+//            (v_mfma_f32_16x16x4_f32: rows = queries, columns = 16 candidates, K = channels four at a time -- an
+//            exact channel-ordered fp32 fma chain, bit-identical to the oracle's fmaf loop), finished as
+//            d = (xx_q - 2 dot) + xx_c on the VALU and parked in LDS (131 KB, row stride 1028 floats so that the
+//            accumulator stores are bank-conflict-free).  The (B,N,N) matrix never reaches HBM.
+//   phase B  one wave per query row, wave-cooperative exact selection:
+//            (1) every lane scans its 16 values (4 x ds_read_b128) and keeps its two smallest;
+//            (2) the K-th smallest of these 128 lane minima (K = k + drop; bitonic sort across lanes) is an upper
+//                bound tau of the row's K-th smallest distance, because at least K row values are <= it -- and it
+//                is tight: about K .. 1.3 K row values survive `key <= tau`; later chunks reuse the K-th best
+//                distance found so far, which is tighter still;
+//            (3) survivors are compacted (wave prefix sum) behind the carried best list of the previous chunks and
+//                sorted as (distance key, index) uint64 across the lanes; the first K are the new best list.
+//            Rows with more than 128 survivors (massive ties) take a slow exact path (K rounds of wave arg-min).
+// Keys: order-preserving uint32 image of the fp32 distance in the high word, candidate index in the low word, so
+// ties go to the lower index exactly like oracle/fsg_oracle.c.
+#include "fsg_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+
+constexpr int QB = 32;            // queries per workgroup (two 16-row MFMA blocks)
+constexpr int CH = 1024;          // candidates per chunk
+constexpr int STRIDE = CH + 4;    // LDS row stride (floats): 4*STRIDE = 16 (mod 32) -> conflict-free accumulator stores
+constexpr int WAVES = 8;
+constexpr int VPL = CH / 64;      // values per lane in phase B (16)
+
+__device__ __forceinline__ unsigned f2o(float d) {
+    const unsigned u = __float_as_uint(d);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float o2f(unsigned k) {
+    return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(v, off);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+// bitonic sort, ascending, of 128 values spread as element (slot*64 + lane); T = unsigned or u64
+template <typename T>
+__device__ __forceinline__ void sort128(T &v0, T &v1, int lane) {
+#pragma unroll
+    for (int kk = 2; kk <= 128; kk <<= 1) {
+#pragma unroll
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            if (j == 64) {
+                const T lo = v0 < v1 ? v0 : v1, hi = v0 < v1 ? v1 : v0;
+                v0 = lo;
+                v1 = hi;
+            } else {
+                const bool lower = (lane & j) == 0;
+                const bool up0 = (lane & kk) == 0 || kk == 128;            // slot 0: index = lane
+                const bool up1 = ((64 + lane) & kk) == 0 || kk == 128;     // slot 1: index = 64 + lane
+                const T o0 = __shfl_xor(v0, j), o1 = __shfl_xor(v1, j);
+                const T mn0 = v0 < o0 ? v0 : o0, mx0 = v0 < o0 ? o0 : v0;
+                const T mn1 = v1 < o1 ? v1 : o1, mx1 = v1 < o1 ? o1 : v1;
+                v0 = (lower == up0) ? mn0 : mx0;
+                v1 = (lower == up1) ? mn1 : mx1;
+            }
+        }
+    }
+}
+
+// bitonic sort, ascending, of 64 values, one per lane
+template <typename T>
+__device__ __forceinline__ void sort64(T &v, int lane) {
+#pragma unroll
+    for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            const bool lower = (lane & j) == 0;
+            const bool up = (lane & kk) == 0 || kk == 64;
+            const T o = __shfl_xor(v, j);
+            const T mn = v < o ? v : o, mx = v < o ? o : v;
+            v = (lower == up) ? mn : mx;
+        }
+    }
+}
+
+template <int KS>
+__global__ __launch_bounds__(512) void knn_rows_mfma_kernel(const float *__restrict__ x, const float *__restrict__ xx,
+                                                             int N, long sb, long sc, int c_knn, int k, int flags,
+                                                             int32_t *__restrict__ idx_out,
+                                                             float *__restrict__ dist_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *rows = reinterpret_cast<float *>(smem);                                        // [QB][STRIDE]
+    u64 *carry = reinterpret_cast<u64 *>(smem + sizeof(float) * QB * STRIDE);             // [QB][64] best list so far
+    u64 *surv = carry + QB * 64;                                                          // [WAVES][128]
+    int *ccount = reinterpret_cast<int *>(surv + WAVES * 128);                            // [QB]
+
+    const int b = blockIdx.y, q0 = blockIdx.x * QB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const float *xb = x + (long)b * sb;
+    const float *xxb = xx + (long)b * N;
+    const int drop = (flags & FSG_KNN_DROP_FIRST) ? 1 : 0;
+    const int KK = k + drop;
+
+    if (tid < QB) ccount[tid] = 0;
+
+    // A operand: queries, rows l15 of the two 16-row blocks, channel 4s + l4; resident for the whole sweep
+    float qa[2][KS];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int ch = 4 * s + l4, q = q0 + blk * 16 + l15;
+            qa[blk][s] = (ch < c_knn && q < N) ? xb[ch * sc + q] : 0.f;
+        }
+    // squared norms of the 4 accumulator rows of this lane: row = l4*4 + e
+    float xxq[2][4];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int q = q0 + blk * 16 + l4 * 4 + e;
+            xxq[blk][e] = q < N ? xxb[q] : 0.f;
+        }
+    const bool fix_diag = (flags & FSG_KNN_FIX_DIAG) != 0;
+
+    for (int c0 = 0; c0 < N; c0 += CH) {
+        const int len = min(CH, N - c0);
+        const int ntile = (len + 15) >> 4;
+        // ---------------------------------------------------------------- phase A: distance block into LDS
+        for (int t = wave; t < CH / 16; t += WAVES) {
+            const int j0 = c0 + t * 16;
+            if (t >= ntile) {  // beyond the cloud: +inf so that phase B never selects it
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rows[(blk * 16 + l4 * 4 + e) * STRIDE + t * 16 + l15] = INFINITY;
+                continue;
+            }
+            const int jc = j0 + l15;  // candidate column of this lane
+            float bv[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int ch = 4 * s + l4;
+                bv[s] = (ch < c_knn && jc < N) ? xb[ch * sc + jc] : 0.f;
+            }
+            const float xc = jc < N ? xxb[jc] : 0.f;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[blk][s], bv[s], acc, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int qr = blk * 16 + l4 * 4 + e;
+                    const float tt = xxq[blk][e] - 2.0f * acc[e];
+                    float d = tt + xc;
+                    if (fix_diag && jc == q0 + qr) d = 0.f;
+                    if (jc >= N) d = INFINITY;
+                    rows[qr * STRIDE + t * 16 + l15] = d;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---------------------------------------------------------------- phase B: exact selection, one wave per row
+        for (int qi = wave; qi < QB; qi += WAVES) {
+            if (q0 + qi >= N) break;
+            const float *row = rows + qi * STRIDE;
+            u64 *sv = surv + wave * 128;
+            unsigned key[VPL];
+#pragma unroll
+            for (int s = 0; s < VPL / 4; ++s) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(row + s * 256 + 4 * lane);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) key[4 * s + e] = f2o(v[e]);
+            }
+            const int cc = ccount[qi];
+            unsigned tau;
+            if (cc >= KK) {
+                tau = (unsigned)(carry[qi * 64 + KK - 1] >> 32);   // K-th best so far: tighter than any chunk estimate
+            } else {
+                unsigned m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;       // two smallest keys of this lane
+#pragma unroll
+                for (int e = 0; e < VPL; ++e) {
+                    const unsigned kx = key[e];
+                    const unsigned hi = kx > m1 ? kx : m1;
+                    m1 = kx < m1 ? kx : m1;
+                    m2 = hi < m2 ? hi : m2;
+                }
+                // carried entries (fewer than KK) also count as candidates of the bound
+                if (lane < cc) {
+                    const unsigned kx = (unsigned)(carry[qi * 64 + lane] >> 32);
+                    const unsigned hi = kx > m1 ? kx : m1;
+                    m1 = kx < m1 ? kx : m1;
+                    m2 = hi < m2 ? hi : m2;
+                }
+                sort128<unsigned>(m1, m2, lane);
+                tau = KK <= 64 ? (unsigned)__shfl((int)m1, KK - 1) : 0xFFFFFFFFu;
+            }
+            // count + compact the survivors behind the carried list
+            int mine = 0;
+#pragma unroll
+            for (int e = 0; e < VPL; ++e) {
+                const int j = c0 + (e >> 2) * 256 + 4 * lane + (e & 3);
+                mine += (key[e] <= tau && j < N) ? 1 : 0;
+            }
+            const int incl = wave_incl_scan(mine, lane);
+            const int total_new = __shfl(incl, 63);
+            const int total = cc + total_new;
+            if (total <= 128) {
+                if (lane < cc) sv[lane] = carry[qi * 64 + lane];
+                int pos = cc + incl - mine;
+#pragma unroll
+                for (int e = 0; e < VPL; ++e) {
+                    const int j = c0 + (e >> 2) * 256 + 4 * lane + (e & 3);
+                    if (key[e] <= tau && j < N) sv[pos++] = ((u64)key[e] << 32) | (unsigned)j;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (total <= 64) {
+                    u64 v = lane < total ? sv[lane] : ~0ull;
+                    sort64<u64>(v, lane);
+                    if (lane < KK) carry[qi * 64 + lane] = v;
+                } else {
+                    u64 v0 = sv[lane], v1 = (64 + lane) < total ? sv[64 + lane] : ~0ull;
+                    sort128<u64>(v0, v1, lane);
+                    if (lane < KK) carry[qi * 64 + lane] = v0;
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                // slow exact path (massive ties): KK rounds of wave arg-min over the 16 row values + carried entry
+                u64 mykeys[VPL + 1];
+#pragma unroll
+                for (int e = 0; e < VPL; ++e) {
+                    const int j = c0 + (e >> 2) * 256 + 4 * lane + (e & 3);
+                    mykeys[e] = (key[e] <= tau && j < N) ? (((u64)key[e] << 32) | (unsigned)j) : ~0ull;
+                }
+                mykeys[VPL] = lane < cc ? carry[qi * 64 + lane] : ~0ull;
+                for (int r = 0; r < KK; ++r) {
+                    u64 best = mykeys[0];
+#pragma unroll
+                    for (int e = 1; e <= VPL; ++e) best = mykeys[e] < best ? mykeys[e] : best;
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) {
+                        const u64 o = __shfl_xor(best, off);
+                        best = o < best ? o : best;
+                    }
+#pragma unroll
+                    for (int e = 0; e <= VPL; ++e) mykeys[e] = mykeys[e] == best ? ~0ull : mykeys[e];
+                    if (lane == 0) carry[qi * 64 + r] = best;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (lane == 0) ccount[qi] = min(total, KK);
+        }
+        __syncthreads();  // rows are rewritten by the next chunk; carry/ccount visible
+    }
+    // ---------------------------------------------------------------- output: rank r of row qi -> lane r
+    for (int qi = wave; qi < QB; qi += WAVES) {
+        const int q = q0 + qi;
+        if (q >= N) break;
+        if (lane >= drop && lane < KK) {
+            const u64 v = carry[qi * 64 + lane];
+            const long o = ((long)b * N + q) * k + (lane - drop);
+            idx_out[o] = (int)(unsigned)(v & 0xFFFFFFFFull);
+            if (dist_out) dist_out[o] = o2f((unsigned)(v >> 32));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void knn_sqnorm2_kernel(const float *__restrict__ x, int N, long sb, long sc, int c_knn,
+                                                           float *__restrict__ xx) {
+    const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const float *xb = x + (long)b * sb;
+    float a = 0.f;
+    for (int c = 0; c < c_knn; ++c) a = __builtin_fmaf(xb[c * sc + j], xb[c * sc + j], a);
+    xx[(long)b * N + j] = a;
+}
+
+}  // namespace
+
+// returns FSG_ERR_UNSUPPORTED when the shape is outside this kernel's envelope (caller falls back)
+int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k, int flags,
+                             int32_t *idx_out, float *dist_out, float *xx_scratch, hipStream_t st) {
+    const int drop = (flags & FSG_KNN_DROP_FIRST) ? 1 : 0;
+    if (c_knn > 128 || k + drop > 64 || N > 65535 * 16 || xx_scratch == nullptr) return FSG_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(knn_sqnorm2_kernel, dim3(fsg_cdiv(N, 256), B), dim3(256), 0, st, x, N, (long)stride_b,
+                       (long)stride_c, c_knn, xx_scratch);
+    FSG_CHECK_LAUNCH("fsg_knn_dense_f32/sqnorm");
+    const size_t lds = sizeof(float) * QB * STRIDE + sizeof(u64) * (QB * 64 + WAVES * 128) + sizeof(int) * QB;
+    dim3 grid(fsg_cdiv(N, QB), B);
+#define FSG_KNN_RM(KS)                                                                                                 \
+    do {                                                                                                               \
+        static bool granted = false;                                                                                   \
+        if (!granted) {                                                                                                \
+            if (hipFuncSetAttribute((const void *)knn_rows_mfma_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds) != hipSuccess) {                                                         \
+                fsg_set_error("fsg_knn_dense_f32: cannot raise dynamic LDS to %zu", lds);                              \
+                return FSG_ERR_HIP;                                                                                    \
+            }                                                                                                          \
+            granted = true;                                                                                            \
+        }                                                                                                              \
+        hipLaunchKernelGGL(knn_rows_mfma_kernel<KS>, grid, dim3(512), lds, st, x, xx_scratch, N, (long)stride_b,       \
+                           (long)stride_c, c_knn, k, flags, idx_out, dist_out);                                        \
+    } while (0)
+    if (c_knn <= 4) FSG_KNN_RM(1);
+    else if (c_knn <= 16) FSG_KNN_RM(4);
+    else if (c_knn <= 64) FSG_KNN_RM(16);
+    else FSG_KNN_RM(32);
+#undef FSG_KNN_RM
+    FSG_CHECK_LAUNCH("fsg_knn_dense_f32/rows_mfma");
+    return FSG_OK;
+}

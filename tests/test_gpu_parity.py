@@ -47,17 +47,27 @@ def test_knn_dense_bit_exact_vs_c_oracle(fsg, device, B, C, Np, k, c_knn, fix, d
 @pytest.mark.parametrize("B,C,Np,k,c_knn,fix,drop", [
     (8, 64, 2048, 20, None, True, False), (8, 3, 2048, 20, None, True, False), (8, 3, 2048, 20, None, True, True),
     (4, 64, 8192, 40, None, True, False), (4, 3, 8192, 40, None, True, True), (2, 128, 2048, 20, None, False, False),
-    (2, 15, 1000, 47, 3, True, True), (1, 100, 4097, 33, None, False, False)])
+    (2, 15, 1000, 47, 3, True, True), (1, 100, 4097, 33, None, False, False), (3, 3, 1025, 20, None, True, False)])
 def test_knn_mfma_kernel_equals_rows_kernel_at_full_size(fsg, device, B, C, Np, k, c_knn, fix, drop):
     """BASELINE config 2 / 4 sizes: the matrix-core kernel against the independent "rows in LDS" kernel (which is
     bit-exact with the C oracle on every size the oracle can reach): same indices, same distance bits."""
     x = G(cloud(5000 + Np + C, B, C, Np), device)
-    a = fsg.functional.knn_graph(x, k, c_knn=c_knn, fix_diag=fix, drop_first=drop, return_dist=True,
-                                 _debug_flags=8)  # FSG_KNN_FORCE_MFMA
     r = fsg.functional.knn_graph(x, k, c_knn=c_knn, fix_diag=fix, drop_first=drop, return_dist=True,
                                  force_rows_kernel=True)
-    assert torch.equal(a[0], r[0])
-    assert torch.equal(a[1].view(torch.int32), r[1].view(torch.int32))
+    for dbg in (0, 8):  # production kernel (knn_rows_mfma.hip), first matrix-core design (knn_mfma.hip, FSG_KNN_FORCE_MFMA)
+        a = fsg.functional.knn_graph(x, k, c_knn=c_knn, fix_diag=fix, drop_first=drop, return_dist=True, _debug_flags=dbg)
+        assert torch.equal(a[0], r[0]), dbg
+        assert torch.equal(a[1].view(torch.int32), r[1].view(torch.int32)), dbg
+
+
+def test_knn_massive_ties_take_the_slow_exact_path(fsg, device):
+    """2000 identical points + a few distinct ones: every distance ties, far more than 128 survivors per row."""
+    x = np.zeros((2, 3, 2100), np.float32)
+    x[:, :, 2000:] = np.random.default_rng(0).uniform(-1, 1, (2, 3, 100)).astype(np.float32)
+    for k, drop in ((20, False), (40, True), (63, True)):
+        idx, dist = fsg.functional.knn_graph(G(x, device), k, drop_first=drop, return_dist=True)
+        ridx, rdist = c_api.knn_dense(x, k, drop_first=drop)
+        assert np.array_equal(N(idx), ridx) and np.array_equal(N(dist).view(np.uint32), rdist.view(np.uint32))
 
 
 def test_knn_dense_ties_and_duplicates(fsg, device):
