@@ -135,7 +135,7 @@ __global__ __launch_bounds__(512) void knn_rows_mfma_kernel(const float *__restr
         // ---------------------------------------------------------------- phase A: distance block into LDS
         for (int t = wave; t < CH / 16; t += WAVES) {
             const int j0 = c0 + t * 16;
-            if (t >= ntile) {  // beyond the cloud: +inf so that phase B never selects it
+            if (t >= ntile || (flags & 512)) {  // beyond the cloud (flag 512: timing ablation of phase A): +inf so that phase B never selects it
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(512) void knn_rows_mfma_kernel(const float *__restr
 
         // ---------------------------------------------------------------- phase B: exact selection, one wave per row
         for (int qi = wave; qi < QB; qi += WAVES) {
-            if (q0 + qi >= N) break;
+            if (q0 + qi >= N || (flags & 256)) break;  // flag 256: timing ablation of phase B
             const float *row = rows + qi * STRIDE;
             u64 *sv = surv + wave * 128;
             unsigned key[VPL];
@@ -200,8 +200,16 @@ __global__ __launch_bounds__(512) void knn_rows_mfma_kernel(const float *__restr
                     m1 = kx < m1 ? kx : m1;
                     m2 = hi < m2 ? hi : m2;
                 }
-                sort128<unsigned>(m1, m2, lane);
-                tau = KK <= 64 ? (unsigned)__shfl((int)m1, KK - 1) : 0xFFFFFFFFu;
+                // K-th smallest of the 128 lane minima by binary search on the key bits: 32 rounds of two wave-wide
+                // compares + population counts (no cross-lane data movement, unlike a bitonic sort)
+                unsigned prefix = 0u;
+#pragma unroll 4
+                for (int bit = 31; bit >= 0; --bit) {
+                    const unsigned t = prefix | ((1u << bit) - 1u);
+                    const int c = __popcll(__ballot(m1 <= t)) + __popcll(__ballot(m2 <= t));
+                    if (c < KK) prefix |= 1u << bit;
+                }
+                tau = prefix;
             }
             // count + compact the survivors behind the carried list
             int mine = 0;
@@ -222,15 +230,19 @@ __global__ __launch_bounds__(512) void knn_rows_mfma_kernel(const float *__restr
                     if (key[e] <= tau && j < N) sv[pos++] = ((u64)key[e] << 32) | (unsigned)j;
                 }
                 __builtin_amdgcn_wave_barrier();
-                if (total <= 64) {
-                    u64 v = lane < total ? sv[lane] : ~0ull;
-                    sort64<u64>(v, lane);
-                    if (lane < KK) carry[qi * 64 + lane] = v;
-                } else {
-                    u64 v0 = sv[lane], v1 = (64 + lane) < total ? sv[64 + lane] : ~0ull;
-                    sort128<u64>(v0, v1, lane);
-                    if (lane < KK) carry[qi * 64 + lane] = v0;
+                // rank by counting: every lane holds up to two survivors and counts how many of the `total` entries are
+                // smaller (entries are distinct: the index is part of the key); rank < K goes to slot `rank`
+                const u64 e0 = lane < total ? sv[lane] : ~0ull;
+                const u64 e1 = (64 + lane) < total ? sv[64 + lane] : ~0ull;
+                int r0 = 0, r1 = 0;
+#pragma unroll 8
+                for (int t = 0; t < total; ++t) {
+                    const u64 xk = sv[t];  // same address in every lane: LDS broadcast
+                    r0 += xk < e0 ? 1 : 0;
+                    r1 += xk < e1 ? 1 : 0;
                 }
+                if (lane < total && r0 < KK) carry[qi * 64 + r0] = e0;
+                if ((64 + lane) < total && r1 < KK) carry[qi * 64 + r1] = e1;
                 __builtin_amdgcn_wave_barrier();
             } else {
                 // slow exact path (massive ties): KK rounds of wave arg-min over the 16 row values + carried entry

@@ -266,6 +266,56 @@ def edgeconv2(x, idx, conv1_weight, bn1, conv2_weight, bn2, slope, x_pm=None, bo
     return (out, out_pm) if both else out
 
 
+# ------------------------------------------------------------------ BatchNorm + LeakyReLU on (M, C) rows
+class _BNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, gamma, beta, rm, rv, training, momentum, eps, slope):
+        y, gamma, beta = _f32c(y), _f32c(gamma), _f32c(beta)
+        M, C = y.shape
+        dev = y.device
+        out = torch.empty_like(y)
+        if training:
+            mean = torch.empty(C, dtype=torch.float32, device=dev)
+            invstd = torch.empty(C, dtype=torch.float32, device=dev)
+            ws = torch.empty(_lib.lib.fsg_bn_act_workspace_bytes(M, C) // 4, dtype=torch.float32, device=dev)
+        else:
+            mean, invstd, ws = rm.detach().float().contiguous(), torch.rsqrt(rv.detach().float() + eps).contiguous(), None
+        with torch.cuda.device(dev):
+            _lib.call("fsg_bn_act_fwd_f32", _p(y), _p(gamma), _p(beta), _p(rm if training else None),
+                      _p(rv if training else None), M, C, int(training), momentum, eps, slope, _p(out), _p(mean),
+                      _p(invstd), _p(ws), _stream())
+        ctx.save_for_backward(y, gamma, beta, mean, invstd)
+        ctx.meta = (M, C, bool(training), slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        y, gamma, beta, mean, invstd = ctx.saved_tensors
+        M, C, training, slope = ctx.meta
+        g = _f32c(g)
+        gy = torch.empty_like(y)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        ws = torch.empty(_lib.lib.fsg_bn_act_workspace_bytes(M, C) // 4, dtype=torch.float32, device=y.device)
+        with torch.cuda.device(y.device):
+            _lib.call("fsg_bn_act_bwd_f32", _p(g), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), M, C, int(training),
+                      slope, _p(gy), _p(dgamma), _p(dbeta), _p(ws), _stream())
+        return gy, dgamma, dbeta, None, None, None, None, None, None
+
+
+def bn_act_supported(y, bn):
+    return y.is_cuda and y.dim() == 2 and y.shape[1] % 64 == 0 and bn.affine
+
+
+def bn_act(y, bn, slope):
+    """LeakyReLU(slope)(BatchNorm1d(y)) for point-major rows y (M, C): one fused HIP stage (slope 1: BN only)."""
+    _need_gpu(y)
+    training, momentum = _bn_step(bn)
+    track = training and bn.track_running_stats
+    return _BNAct.apply(y, bn.weight, bn.bias, bn.running_mean if (track or not training) else None,
+                        bn.running_var if (track or not training) else None, training, momentum, float(bn.eps),
+                        float(slope))
+
+
 # ------------------------------------------------------------------ Chamfer (losses/chamfer_loss.py:19)
 class _ChamferNN(torch.autograd.Function):
     @staticmethod

@@ -106,7 +106,14 @@ def pointwise_block(x_pm, block):
     B*N points, BatchNorm1d sees the same B*N samples per channel as on the (B,C,N) layout."""
     conv = block.layers[0]
     y = nn.functional.linear(x_pm, conv.weight.view(conv.out_channels, conv.in_channels), conv.bias)
-    for layer in list(block.layers)[1:]:
+    return _norm_act(y, list(block.layers)[1:])
+
+
+def _norm_act(y, tail):
+    """[BatchNorm, LeakyReLU] tail of a ConvBlock on point-major rows: one fused HIP stage when the width allows."""
+    if len(tail) == 2 and isinstance(tail[1], nn.LeakyReLU) and F_hip.bn_act_supported(y, tail[0]):
+        return F_hip.bn_act(y, tail[0], tail[1].negative_slope)
+    for layer in tail:
         y = layer(y)
     return y
 
@@ -221,9 +228,7 @@ class DGCNNSeg(DGCNNBase):
         seg0 = self.segmentation[0]
         w0 = seg0.layers[0].weight.view(seg0.layers[0].out_channels, -1)
         y = nn.functional.linear(levels, w0[:, :192]).view(B, N, -1) + nn.functional.linear(g, w0[:, 192:]).unsqueeze(1)
-        y = y.view(B * N, -1)
-        for layer in list(seg0.layers)[1:]:
-            y = layer(y)
+        y = _norm_act(y.view(B * N, -1), list(seg0.layers)[1:])
         for block in list(self.segmentation)[1:]:
             y = pointwise_block(y, block)
         return y.view(B, N, self.num_classes).transpose(1, 2).contiguous()

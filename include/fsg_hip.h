@@ -127,6 +127,21 @@ int fsg_edgeconv2_bwd_f32(const float *grad_out, const float *grad_out_pm, const
                           float *grad_gamma2, float *grad_beta2, void *workspace, fsg_stream_t stream);
 
 /*
+ * Fused BatchNorm + LeakyReLU on point-major rows (M, C), C % 64 == 0: the stage behind every 1x1 conv of the
+ * point-wise head (models/dgcnn.py:282-323 ConvBlock: conv -> BatchNorm -> LeakyReLU; slope 1 = no activation,
+ * slope 0 = ReLU).  Forward: y -> out, plus mean/invstd (outputs when training, inputs otherwise) and the in-place
+ * running-statistics update; backward: grad_out, y -> grad_y, grad_gamma, grad_beta.
+ * workspace: fsg_bn_act_workspace_bytes(M, C) bytes.
+ */
+size_t fsg_bn_act_workspace_bytes(long M, int C);
+int fsg_bn_act_fwd_f32(const float *y, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                       long M, int C, int training, float momentum, float eps, float slope, float *out, float *mean,
+                       float *invstd, float *workspace, fsg_stream_t stream);
+int fsg_bn_act_bwd_f32(const float *grad_out, const float *y, const float *gamma, const float *beta, const float *mean,
+                       const float *invstd, long M, int C, int training, float slope, float *grad_y, float *grad_gamma,
+                       float *grad_beta, float *workspace, fsg_stream_t stream);
+
+/*
  * Chamfer nearest neighbour, one direction: replaces the pytorch3d.loss.chamfer_distance call of
  * losses/chamfer_loss.py:19 (and losses/mesh_loss.py:29-31, train_pc_ae.py:88).
  *   x (B,N,3), y (B,M,3) fp32 -> dist (B,N) = min_j |x_i - y_j|^2, arg (B,N) int32 (lowest j on ties)

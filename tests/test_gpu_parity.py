@@ -484,6 +484,32 @@ def test_edgeconv2_fused_vs_unfused(fsg, device, B, C, Np, k, C2, train):
             assert float((a - b).norm()) <= 5e-3 * float(b.norm()) + 1e-5, (n, float((a - b).norm()), float(b.norm()))
 
 
+@pytest.mark.parametrize("M,C,train,slope", [(1000, 64, True, 0.2), (16384, 1024, True, 0.2), (777, 256, False, 0.2),
+                                             (300, 128, True, 0.0), (129, 64, True, 1.0)])
+def test_bn_act_fused_vs_torch(fsg, device, M, C, train, slope):
+    from fissure_segmentation_amd.norm import BatchNorm1d
+    torch.manual_seed(M + C)
+    bns = [BatchNorm1d(C).to(device) for _ in range(2)]
+    w, bias = torch.rand(C, device=device) + 0.5, torch.randn(C, device=device)
+    w[::4] *= -1
+    rm, rv = torch.randn(C, device=device), torch.rand(C, device=device) + 0.5
+    for bn in bns:
+        with torch.no_grad():
+            bn.weight.copy_(w); bn.bias.copy_(bias); bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+        bn.train(train)
+    y0 = torch.randn(M, C, device=device) * 3 + 5      # mean >> spread on purpose
+    g = torch.randn(M, C, device=device)
+    res = []
+    for fused, bn in zip((True, False), bns):
+        y = y0.clone().requires_grad_(True)
+        out = fsg.functional.bn_act(y, bn, slope) if fused else torch.nn.functional.leaky_relu(bn(y), slope)
+        out.backward(g)
+        res.append((out.detach(), y.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone()))
+    for n, a, b in zip(["out", "grad_y", "grad_gamma", "grad_beta", "rm", "rv"], *res):
+        a, b = a.double(), b.double()
+        assert float((a - b).abs().max()) <= 2e-4 * (1.0 + float(b.abs().max())), (n, float((a - b).abs().max()))
+
+
 def test_reverse_graph_is_the_transpose(fsg, device):
     x = G(cloud(3, 2, 3, 500), device)
     idx = fsg.functional.knn_graph(x, 12)

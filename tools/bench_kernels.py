@@ -28,6 +28,12 @@ if "knn" in which:
         for name, rows, dbg in (("rows_mfma(v2)", False, 0), ("mfma(v1)", False, 8), ("rows(v0)", True, 0)):
             med, mn = timeit(lambda: F.knn_graph(x, k, force_rows_kernel=rows, _debug_flags=dbg))
             print(f"knn B={B} C={C} N={N} k={k} {name:14s}: median {med:8.1f} us  min {mn:8.1f} us")
+if "knn2ablate" in which:
+    for (B, C, N, k) in [(8, 3, 2048, 20), (8, 64, 2048, 20)]:
+        x = torch.from_numpy(cloud(1, B, C, N)).to(dev)
+        for name, fl in [("full", 0), ("no phase B", 256), ("no phase A", 512), ("neither", 768)]:
+            med, mn = timeit(lambda: F.knn_graph(x, k, _debug_flags=fl))
+            print(f"knn v2 C={C} {name:12s}: median {med:8.1f} us")
 if "knnablate" in which:
     for (B, C, N, k) in [(8, 3, 2048, 20), (8, 64, 2048, 20)]:
         x = torch.from_numpy(cloud(1, B, C, N)).to(dev)
