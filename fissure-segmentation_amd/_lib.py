@@ -35,6 +35,9 @@ SIGNATURES = {
     "fsg_bn_act_workspace_bytes": ([ctypes.c_long, _I], ctypes.c_size_t),
     "fsg_bn_act_fwd_f32": ([_P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P], _I),
     "fsg_bn_act_bwd_f32": ([_P, _P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _F, _P, _P, _P, _P, _P], _I),
+    "fsg_bn_act_max_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),
+    "fsg_bn_act_max_fwd_f32": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P], _I),
+    "fsg_bn_act_max_bwd_f32": ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P], _I),
     "fsg_chamfer_nn_f32": ([_P, _P, _I, _I, _I, _P, _P, _P], _I),
     "fsg_chamfer_nn_bwd_f32": ([_P, _P, _P, _P, _I, _I, _I, _P, _P, _P], _I),
     "fsg_knn_segment_f32": ([_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P], _I),

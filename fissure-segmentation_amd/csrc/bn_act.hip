@@ -130,6 +130,132 @@ __global__ __launch_bounds__(256) void bnact_bwd_apply_kernel(const float *__res
     }
 }
 
+// ---- BatchNorm + LeakyReLU + max over the points of each cloud (the global feature, models/dgcnn.py:134-137,156):
+// f(BN(.)) is monotone per channel, so only the per-cloud max (gamma >= 0) or min (gamma < 0) of the PRE-norm rows
+// is needed; the (B*N, C) activation is never written.
+__global__ __launch_bounds__(256) void bnmax_stats_kernel(const float *__restrict__ y, const float *__restrict__ gamma,
+                                                           int N, int C, int training, float *__restrict__ partials,
+                                                           float *__restrict__ sel_val, int *__restrict__ sel_arg) {
+    __shared__ float red[3][4][64];
+    __shared__ float bestv[4][64];
+    __shared__ int besta[4][64];
+    const int cg = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = cg * 64 + lane;
+    const int tiles = (N + ROWS - 1) / ROWS;
+    const int b = blockIdx.y / tiles, tile = blockIdx.y - b * tiles;
+    const int n0 = tile * ROWS, n1 = min(N, n0 + ROWS);
+    const float *yb = y + (long)b * N * C;
+    const float sgn = gamma[c] >= 0.f ? 1.f : -1.f;
+    float shift = 0.f, s1 = 0.f, s2 = 0.f, cnt = 0.f, best = -INFINITY;
+    int barg = 0;
+    if (n0 + wave < n1) shift = yb[(long)(n0 + wave) * C + c];
+#pragma unroll 4
+    for (int n = n0 + wave; n < n1; n += 4) {
+        const float v = yb[(long)n * C + c];
+        const float d = v - shift;
+        s1 += d;
+        s2 = __builtin_fmaf(d, d, s2);
+        cnt += 1.f;
+        if (sgn * v > best) { best = sgn * v; barg = n; }
+    }
+    float mean = 0.f, m2 = 0.f;
+    if (cnt > 0.f) {
+        mean = shift + s1 / cnt;
+        m2 = fmaxf(s2 - s1 * s1 / cnt, 0.f);
+    }
+    red[0][wave][lane] = cnt;
+    red[1][wave][lane] = mean;
+    red[2][wave][lane] = m2;
+    bestv[wave][lane] = best;
+    besta[wave][lane] = barg;
+    __syncthreads();
+    if (wave == 0) {
+        float n = red[0][0][lane], mu = red[1][0][lane], M2 = red[2][0][lane];
+        float bv = bestv[0][lane];
+        int ba = besta[0][lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float nb = red[0][w][lane];
+            if (nb > 0.f) {
+                const float tot = n + nb, delta = red[1][w][lane] - mu;
+                mu += delta * (nb / tot);
+                M2 += red[2][w][lane] + delta * delta * (n * nb / tot);
+                n = tot;
+            }
+            if (bestv[w][lane] > bv || (bestv[w][lane] == bv && besta[w][lane] < ba)) { bv = bestv[w][lane]; ba = besta[w][lane]; }
+        }
+        if (training) {
+            float *pr = partials + (long)blockIdx.y * 3 * C;
+            pr[c] = n;
+            pr[C + c] = mu;
+            pr[2 * C + c] = M2;
+        }
+        sel_val[(long)blockIdx.y * C + c] = bv;   // signed: sgn * y
+        sel_arg[(long)blockIdx.y * C + c] = ba;
+    }
+}
+
+__global__ __launch_bounds__(256) void bnmax_finish_kernel(const float *__restrict__ sel_val, const int *__restrict__ sel_arg,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                            const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                            int tiles, int C, float slope, float *__restrict__ out,
+                                                            float *__restrict__ ysel, int *__restrict__ arg) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float bv = -INFINITY;
+    int ba = 0;
+    for (int t = 0; t < tiles; ++t) {
+        const float v = sel_val[((long)b * tiles + t) * C + c];
+        const int a = sel_arg[((long)b * tiles + t) * C + c];
+        if (v > bv || (v == bv && a < ba)) { bv = v; ba = a; }
+    }
+    const float sgn = gamma[c] >= 0.f ? 1.f : -1.f;
+    const float yv = sgn * bv;
+    const float a1 = gamma[c] * invstd[c];
+    ysel[(long)b * C + c] = yv;
+    arg[(long)b * C + c] = ba;
+    out[(long)b * C + c] = lrelu(__builtin_fmaf(yv, a1, beta[c] - mean[c] * a1), slope);
+}
+
+// grad_out (B,C) -> dy (B,N,C) = a ( h [n = arg] - dbeta/M - yhat dgamma/M ); dbeta/dgamma are sums over the B clouds
+__global__ __launch_bounds__(256) void bnmax_bwd_kernel(const float *__restrict__ gout, const float *__restrict__ y,
+                                                         const float *__restrict__ ysel, const int *__restrict__ arg,
+                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                         const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                         int B, int N, int C, int training, float slope,
+                                                         float *__restrict__ gy, float *__restrict__ dgamma,
+                                                         float *__restrict__ dbeta) {
+    const int cg = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = cg * 64 + lane;
+    const int tiles = (N + ROWS - 1) / ROWS;
+    const int b = blockIdx.y / tiles, tile = blockIdx.y - b * tiles;
+    const float r = invstd[c], mu = mean[c], a = gamma[c] * r, bb = beta[c] - mu * a;
+    float sb = 0.f, sg = 0.f, hb = 0.f;
+    for (int q = 0; q < B; ++q) {   // B is small: every workgroup recomputes the two channel sums
+        const float ys = ysel[(long)q * C + c];
+        const float u = __builtin_fmaf(ys, a, bb);
+        const float h = gout[(long)q * C + c] * (u > 0.f ? 1.f : slope);
+        sb += h;
+        sg = __builtin_fmaf(h, (ys - mu) * r, sg);
+        if (q == b) hb = h;
+    }
+    if (blockIdx.y == 0 && wave == 0) {
+        dbeta[c] = sb;
+        dgamma[c] = sg;
+    }
+    const float invM = 1.0f / ((float)B * (float)N);
+    const float db = training ? sb * invM : 0.f, dg = training ? sg * invM * r : 0.f;
+    const int an = arg[(long)b * C + c];
+    const int n0 = tile * ROWS, n1 = min(N, n0 + ROWS);
+    const float *yb = y + (long)b * N * C;
+    float *gb = gy + (long)b * N * C;
+#pragma unroll 4
+    for (int n = n0 + wave; n < n1; n += 4) {
+        const float yv = yb[(long)n * C + c];
+        gb[(long)n * C + c] = a * ((n == an ? hb : 0.f) - db - (yv - mu) * dg);
+    }
+}
+
 }  // namespace
 
 extern "C" size_t fsg_bn_act_workspace_bytes(long M, int C) { return sizeof(float) * (size_t)fsg_cdiv(M, ROWS) * 3 * C; }
@@ -175,5 +301,48 @@ extern "C" int fsg_bn_act_bwd_f32(const float *grad_out, const float *y, const f
     hipLaunchKernelGGL(bnact_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, grad_out, y, gamma, beta, mean, invstd,
                        grad_beta, grad_gamma, total, C, training, 1.0f / (float)M, slope, grad_y);
     FSG_CHECK_LAUNCH("fsg_bn_act_bwd_f32/apply");
+    return FSG_OK;
+}
+
+extern "C" size_t fsg_bn_act_max_workspace_bytes(int B, int N, int C) {
+    const size_t rec = (size_t)B * fsg_cdiv(N, ROWS);
+    return sizeof(float) * rec * 5 * (size_t)C;  // (n, mean, M2) records + per-tile selected value and row
+}
+
+extern "C" int fsg_bn_act_max_fwd_f32(const float *y, const float *gamma, const float *beta, float *running_mean,
+                                      float *running_var, int B, int N, int C, int training, float momentum, float eps,
+                                      float slope, float *out, float *ysel, int32_t *arg, float *mean, float *invstd,
+                                      float *workspace, fsg_stream_t stream) {
+    FSG_REQUIRE(y && gamma && beta && out && ysel && arg && mean && invstd && workspace, "fsg_bn_act_max_fwd_f32: NULL pointer");
+    FSG_REQUIRE(B > 0 && N > 0 && C > 0 && C % 64 == 0, "fsg_bn_act_max_fwd_f32: bad shape B=%d N=%d C=%d", B, N, C);
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles = fsg_cdiv(N, ROWS), R = B * tiles;
+    float *partials = workspace;
+    float *sel_val = partials + (size_t)R * 3 * C;
+    int *sel_arg = (int *)(sel_val + (size_t)R * C);
+    hipLaunchKernelGGL(bnmax_stats_kernel, dim3(C / 64, R), dim3(256), 0, st, y, gamma, N, C, training, partials, sel_val,
+                       sel_arg);
+    FSG_CHECK_LAUNCH("fsg_bn_act_max_fwd_f32/stats");
+    if (training) {
+        const int rc = fsg_ec_finalize_launch(partials, R, C, eps, momentum, mean, invstd, running_mean, running_var, st);
+        if (rc != FSG_OK) return rc;
+    }
+    hipLaunchKernelGGL(bnmax_finish_kernel, dim3(fsg_cdiv(C, 256), B), dim3(256), 0, st, sel_val, sel_arg, gamma, beta, mean,
+                       invstd, tiles, C, slope, out, ysel, arg);
+    FSG_CHECK_LAUNCH("fsg_bn_act_max_fwd_f32/finish");
+    return FSG_OK;
+}
+
+extern "C" int fsg_bn_act_max_bwd_f32(const float *grad_out, const float *y, const float *ysel, const int32_t *arg,
+                                      const float *gamma, const float *beta, const float *mean, const float *invstd, int B,
+                                      int N, int C, int training, float slope, float *grad_y, float *grad_gamma,
+                                      float *grad_beta, fsg_stream_t stream) {
+    FSG_REQUIRE(grad_out && y && ysel && arg && gamma && beta && mean && invstd && grad_y && grad_gamma && grad_beta,
+                "fsg_bn_act_max_bwd_f32: NULL pointer");
+    FSG_REQUIRE(B > 0 && N > 0 && C > 0 && C % 64 == 0, "fsg_bn_act_max_bwd_f32: bad shape B=%d N=%d C=%d", B, N, C);
+    const int tiles = fsg_cdiv(N, ROWS);
+    hipLaunchKernelGGL(bnmax_bwd_kernel, dim3(C / 64, B * tiles), dim3(256), 0, (hipStream_t)stream, grad_out, y, ysel, arg,
+                       gamma, beta, mean, invstd, B, N, C, training, slope, grad_y, grad_gamma, grad_beta);
+    FSG_CHECK_LAUNCH("fsg_bn_act_max_bwd_f32");
     return FSG_OK;
 }

@@ -26,7 +26,8 @@
 
 namespace {
 
-constexpr int TP = 16;  // points per workgroup in the gather kernels (4 waves x 4 points)
+constexpr int TP = 16;  // points per tile in the gather kernels (4 waves x 4 points)
+constexpr int TPW = 4;  // tiles per workgroup of the statistics kernel (one BN partial record per workgroup)
 
 __device__ __forceinline__ float lrelu(float u, float slope) { return u > 0.f ? u : u * slope; }
 
@@ -88,9 +89,9 @@ __global__ __launch_bounds__(256) void ec1_stats_select_kernel(const float *__re
     const float sgn = gamma[c] >= 0.f ? 1.f : -1.f;
     float shift = 0.f, s1 = 0.f, s2 = 0.f, cnt = 0.f;
     bool first = true;
-    for (int t = 0; t < TP / 4; ++t) {
-        const int i = tile * TP + wave * (TP / 4) + t;
-        if (i >= N) break;
+    for (int t = 0; t < TPW * (TP / 4); ++t) {
+        const int i = (tile * TPW + t / (TP / 4)) * TP + wave * (TP / 4) + t % (TP / 4);
+        if (i >= N) continue;
         // one coalesced load brings the point's k neighbour ids into the wave; each id is then broadcast with
         // v_readlane and the P-row gathers are issued four at a time (independent loads hide the L2 latency)
         const int myj = lane < k ? idx[((long)b * N + i) * k + lane] : 0;
@@ -353,12 +354,12 @@ __global__ __launch_bounds__(256) void ec1_bwd_gather_kernel(
 }  // namespace
 
 // launch helpers shared with edgeconv2.hip
-int fsg_ec_stats1_records(int B, int N) { return B * fsg_cdiv(N, TP); }
+int fsg_ec_stats1_records(int B, int N) { return B * fsg_cdiv(N, TP * TPW); }
 
 int fsg_ec_stats1_launch(const float *pq, const int32_t *idx, const float *gamma, int B, int N, int k, int Co,
                          float *ysel, uint8_t *arg, float *ssum, float *partials, hipStream_t st) {
-    hipLaunchKernelGGL(ec1_stats_select_kernel, dim3(B, fsg_cdiv(N, TP), Co / 64), dim3(256), 0, st, pq, idx, gamma, N,
-                       k, Co, 1, ysel, arg, ssum, partials);
+    hipLaunchKernelGGL(ec1_stats_select_kernel, dim3(B, fsg_cdiv(N, TP * TPW), Co / 64), dim3(256), 0, st, pq, idx, gamma,
+                       N, k, Co, 1, ysel, arg, ssum, partials);
     FSG_CHECK_LAUNCH("edgeconv/stats");
     return FSG_OK;
 }
@@ -419,7 +420,7 @@ extern "C" int fsg_graph_reverse_csr(const int32_t *idx, int B, int N, int k, in
 }
 
 extern "C" size_t fsg_edgeconv1_workspace_bytes(int B, int N, int Co) {
-    const size_t rec = (size_t)B * (size_t)fsg_cdiv(N, TP);
+    const size_t rec = (size_t)B * (size_t)fsg_cdiv(N, TP * TPW);
     return sizeof(float) * rec * 3 * (size_t)Co;
 }
 
@@ -433,7 +434,7 @@ extern "C" int fsg_edgeconv1_fwd_f32(const float *pq, const int32_t *idx, const 
                 "fsg_edgeconv1_fwd_f32: bad shape B=%d N=%d k=%d Co=%d (Co must be a multiple of 64)", B, N, k, Co);
     FSG_REQUIRE(!training || workspace, "fsg_edgeconv1_fwd_f32: training needs the workspace");
     hipStream_t st = (hipStream_t)stream;
-    const int tiles = fsg_cdiv(N, TP);
+    const int tiles = fsg_cdiv(N, TP * TPW);
     hipLaunchKernelGGL(ec1_stats_select_kernel, dim3(B, tiles, Co / 64), dim3(256), 0, st, pq, idx, gamma, N, k, Co,
                        training, ysel, arg, ssum, workspace);
     FSG_CHECK_LAUNCH("fsg_edgeconv1_fwd_f32/stats");

@@ -55,61 +55,66 @@ def broadcast_parameters(model, src=0):
 
 
 class BucketedGradAverager:
-    """Owns flat gradient buckets (parameter .grad tensors are views into them) and averages them
-    across ranks.  `early` = predicate on parameter names selecting the bucket that is reduced as soon as
-    all of its gradients exist (overlapping the rest of backward); everything else is reduced in
-    `finish()`, which also joins the side stream.  With world_size 1 it is a no-op."""
+    """Averages gradients across ranks in (at most) two flat buckets.  `early` = predicate on parameter names
+    selecting the bucket that is reduced as soon as all of its gradients exist (on a side stream, overlapping the
+    rest of backward); everything else is reduced in `finish()`, which also joins the side stream and writes the
+    averages back into the .grad tensors (one foreach copy per bucket).  Between steps gradients are dropped
+    (`zero_grad` sets them to None), so autograd assigns instead of accumulating -- no per-parameter add/fill
+    kernels.  With world_size 1 nothing is launched at all."""
 
     def __init__(self, model, early=lambda name: False):
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        self.params = [p for _, p in named]
         groups = [[p for n, p in named if early(n)], [p for n, p in named if not early(n)]]
-        self.buckets = []
-        for params in groups:
-            if not params:
-                continue
-            flat = torch.zeros(sum(p.numel() for p in params), dtype=params[0].dtype, device=params[0].device)
-            off = 0
-            for p in params:
-                p.grad = flat[off:off + p.numel()].view_as(p)
-                off += p.numel()
-            self.buckets.append({"flat": flat, "params": params, "pending": len(params), "work": None})
+        self.buckets = [{"params": g, "pending": len(g), "flat": None, "work": None} for g in groups if g]
         self.early_bucket = self.buckets[0] if (len(self.buckets) == 2 and self.world > 1) else None
-        self.side = torch.cuda.Stream() if (self.early_bucket and self.buckets[0]["flat"].is_cuda) else None
+        on_gpu = self.params[0].is_cuda
+        self.side = torch.cuda.Stream() if (self.early_bucket is not None and on_gpu) else None
         if self.early_bucket is not None:
             for p in self.early_bucket["params"]:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
     def zero_grad(self):
+        for p in self.params:
+            p.grad = None
         for b in self.buckets:
-            b["flat"].zero_()
-            b["pending"] = len(b["params"])
-            b["work"] = None
+            b["pending"], b["flat"], b["work"] = len(b["params"]), None, None
 
-    def _launch(self, b):
-        if self.side is not None:
-            self.side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.side):
+    def _launch(self, b, side):
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b["params"]]
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                b["flat"] = torch.cat([g.reshape(-1) for g in grads])
                 b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
         else:
+            b["flat"] = torch.cat([g.reshape(-1) for g in grads])
             b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
 
     def _on_grad(self, p):
         b = self.early_bucket
         b["pending"] -= 1
         if b["pending"] == 0:
-            self._launch(b)
+            self._launch(b, self.side)
 
     def finish(self):
-        """Call after backward(): reduces what is left, waits, divides by the world size."""
+        """Call after backward(): reduces what is left, waits, writes the averaged gradients back."""
         if self.world == 1:
             return
         for b in self.buckets:
             if b["work"] is None:
-                b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
+                self._launch(b, None)
         for b in self.buckets:
             b["work"].wait()
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
         for b in self.buckets:
-            b["flat"].div_(self.world)
+            flat = b["flat"].div_(self.world)
+            outs, off = [], 0
+            for p in b["params"]:
+                if p.grad is None:
+                    p.grad = torch.empty_like(p)
+                outs.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            torch._foreach_copy_([p.grad for p in b["params"]], outs)

@@ -302,6 +302,52 @@ class _BNAct(torch.autograd.Function):
         return gy, dgamma, dbeta, None, None, None, None, None, None
 
 
+class _BNActMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, gamma, beta, rm, rv, training, momentum, eps, slope):
+        y, gamma, beta = _f32c(y), _f32c(gamma), _f32c(beta)
+        B, N, C = y.shape
+        dev = y.device
+        out = torch.empty(B, C, dtype=torch.float32, device=dev)
+        ysel = torch.empty(B, C, dtype=torch.float32, device=dev)
+        arg = torch.empty(B, C, dtype=torch.int32, device=dev)
+        if training:
+            mean = torch.empty(C, dtype=torch.float32, device=dev)
+            invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        else:
+            mean, invstd = rm.detach().float().contiguous(), torch.rsqrt(rv.detach().float() + eps).contiguous()
+        ws = torch.empty(_lib.lib.fsg_bn_act_max_workspace_bytes(B, N, C) // 4, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("fsg_bn_act_max_fwd_f32", _p(y), _p(gamma), _p(beta), _p(rm if training else None),
+                      _p(rv if training else None), B, N, C, int(training), momentum, eps, slope, _p(out), _p(ysel),
+                      _p(arg), _p(mean), _p(invstd), _p(ws), _stream())
+        ctx.save_for_backward(y, gamma, beta, mean, invstd, ysel, arg)
+        ctx.meta = (B, N, C, bool(training), slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        y, gamma, beta, mean, invstd, ysel, arg = ctx.saved_tensors
+        B, N, C, training, slope = ctx.meta
+        g = _f32c(g)
+        gy = torch.empty_like(y)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        with torch.cuda.device(y.device):
+            _lib.call("fsg_bn_act_max_bwd_f32", _p(g), _p(y), _p(ysel), _p(arg), _p(gamma), _p(beta), _p(mean), _p(invstd),
+                      B, N, C, int(training), slope, _p(gy), _p(dgamma), _p(dbeta), _stream())
+        return gy, dgamma, dbeta, None, None, None, None, None, None
+
+
+def bn_act_max(y, bn, slope):
+    """max over dim 1 of LeakyReLU(slope)(BatchNorm(y)) for y (B, N, C) -> (B, C), without the (B,N,C) activation."""
+    _need_gpu(y)
+    training, momentum = _bn_step(bn)
+    track = training and bn.track_running_stats
+    return _BNActMax.apply(y, bn.weight, bn.bias, bn.running_mean if (track or not training) else None,
+                           bn.running_var if (track or not training) else None, training, momentum, float(bn.eps),
+                           float(slope))
+
+
 def bn_act_supported(y, bn):
     return y.is_cuda and y.dim() == 2 and y.shape[1] % 64 == 0 and bn.affine
 

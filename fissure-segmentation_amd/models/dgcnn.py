@@ -222,7 +222,12 @@ class DGCNNSeg(DGCNNBase):
         x2, p2 = self.ec2(x1, self.knn_graph, x_pm=p1, both=True)
         _, p3 = self.ec3(x2, self.knn_graph, x_pm=p2, both=True)
         levels = torch.cat([p1, p2, p3], dim=2).view(B * N, 192)
-        g = pointwise_block(levels, self.global_feature[0]).view(B, N, -1).max(dim=1)[0]      # (B,1024)
+        gf = self.global_feature[0].layers                                                   # conv, BN, LeakyReLU
+        yg = nn.functional.linear(levels, gf[0].weight.view(gf[0].out_channels, -1))
+        if yg.shape[1] % 64 == 0:  # BN + LeakyReLU + max over the points in one stage, activation never written
+            g = F_hip.bn_act_max(yg.view(B, N, -1), gf[1], gf[2].negative_slope)              # (B,1024)
+        else:
+            g = _norm_act(yg, list(gf)[1:]).view(B, N, -1).max(dim=1)[0]
         # first head layer on cat([levels, g.repeat(N)]) (models/dgcnn.py:159-160 of the reference): the global part
         # is constant per cloud, so its product is computed once per cloud instead of once per point
         seg0 = self.segmentation[0]

@@ -142,6 +142,22 @@ int fsg_bn_act_bwd_f32(const float *grad_out, const float *y, const float *gamma
                        float *grad_beta, float *workspace, fsg_stream_t stream);
 
 /*
+ * BatchNorm + LeakyReLU + max over the N points of each cloud in one stage: the global feature of DGCNNSeg
+ * (models/dgcnn.py:134-137: SharedFullyConnected(192,1024) -> AdaptiveMaxPool1d(1)) without materialising the
+ * (B*N, C) activation.  y (B,N,C) pre-norm rows -> out (B,C); saved: ysel (B,C) selected pre-norm value, arg (B,C)
+ * its point index.  Backward: grad_out (B,C) -> grad_y (B,N,C) (dense: BN statistics terms), grad_gamma, grad_beta.
+ */
+size_t fsg_bn_act_max_workspace_bytes(int B, int N, int C);
+int fsg_bn_act_max_fwd_f32(const float *y, const float *gamma, const float *beta, float *running_mean,
+                           float *running_var, int B, int N, int C, int training, float momentum, float eps,
+                           float slope, float *out, float *ysel, int32_t *arg, float *mean, float *invstd,
+                           float *workspace, fsg_stream_t stream);
+int fsg_bn_act_max_bwd_f32(const float *grad_out, const float *y, const float *ysel, const int32_t *arg,
+                           const float *gamma, const float *beta, const float *mean, const float *invstd, int B, int N,
+                           int C, int training, float slope, float *grad_y, float *grad_gamma, float *grad_beta,
+                           fsg_stream_t stream);
+
+/*
  * Chamfer nearest neighbour, one direction: replaces the pytorch3d.loss.chamfer_distance call of
  * losses/chamfer_loss.py:19 (and losses/mesh_loss.py:29-31, train_pc_ae.py:88).
  *   x (B,N,3), y (B,M,3) fp32 -> dist (B,N) = min_j |x_i - y_j|^2, arg (B,N) int32 (lowest j on ties)

@@ -510,6 +510,34 @@ def test_bn_act_fused_vs_torch(fsg, device, M, C, train, slope):
         assert float((a - b).abs().max()) <= 2e-4 * (1.0 + float(b.abs().max())), (n, float((a - b).abs().max()))
 
 
+@pytest.mark.parametrize("B,Np,C,train", [(8, 2048, 1024, True), (3, 130, 64, True), (2, 257, 128, False)])
+def test_bn_act_max_fused_vs_torch(fsg, device, B, Np, C, train):
+    from fissure_segmentation_amd.norm import BatchNorm1d
+    torch.manual_seed(Np + C)
+    bns = [BatchNorm1d(C).to(device) for _ in range(2)]
+    w, bias = torch.rand(C, device=device) + 0.5, torch.randn(C, device=device)
+    w[::4] *= -1
+    rm, rv = torch.randn(C, device=device), torch.rand(C, device=device) + 0.5
+    for bn in bns:
+        with torch.no_grad():
+            bn.weight.copy_(w); bn.bias.copy_(bias); bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+        bn.train(train)
+    y0 = torch.randn(B, Np, C, device=device) * 2 + 1
+    g = torch.randn(B, C, device=device)
+    res = []
+    for fused, bn in zip((True, False), bns):
+        y = y0.clone().requires_grad_(True)
+        if fused:
+            out = fsg.functional.bn_act_max(y, bn, 0.2)
+        else:
+            out = torch.nn.functional.leaky_relu(bn(y.view(B * Np, C)), 0.2).view(B, Np, C).max(dim=1)[0]
+        out.backward(g)
+        res.append((out.detach(), y.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone()))
+    for n, a, b in zip(["out", "grad_y", "grad_gamma", "grad_beta", "rm", "rv"], *res):
+        a, b = a.double(), b.double()
+        assert float((a - b).abs().max()) <= 2e-4 * (1.0 + float(b.abs().max())), (n, float((a - b).abs().max()))
+
+
 def test_reverse_graph_is_the_transpose(fsg, device):
     x = G(cloud(3, 2, 3, 500), device)
     idx = fsg.functional.knn_graph(x, 12)
