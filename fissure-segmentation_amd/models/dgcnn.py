@@ -105,7 +105,7 @@ def pointwise_block(x_pm, block):
     """A SharedFullyConnected(dim=1) block applied to point-major rows (M, Cin): the 1x1 Conv1d is one GEMM over all
     B*N points, BatchNorm1d sees the same B*N samples per channel as on the (B,C,N) layout."""
     conv = block.layers[0]
-    y = nn.functional.linear(x_pm, conv.weight.view(conv.out_channels, conv.in_channels), conv.bias)
+    y = F_hip.linear_pm(x_pm, conv.weight.view(conv.out_channels, conv.in_channels), conv.bias)
     return _norm_act(y, list(block.layers)[1:])
 
 
@@ -223,7 +223,7 @@ class DGCNNSeg(DGCNNBase):
         _, p3 = self.ec3(x2, self.knn_graph, x_pm=p2, both=True)
         levels = torch.cat([p1, p2, p3], dim=2).view(B * N, 192)
         gf = self.global_feature[0].layers                                                   # conv, BN, LeakyReLU
-        yg = nn.functional.linear(levels, gf[0].weight.view(gf[0].out_channels, -1))
+        yg = F_hip.linear_pm(levels, gf[0].weight.view(gf[0].out_channels, -1))
         if yg.shape[1] % 64 == 0:  # BN + LeakyReLU + max over the points in one stage, activation never written
             g = F_hip.bn_act_max(yg.view(B, N, -1), gf[1], gf[2].negative_slope)              # (B,1024)
         else:
@@ -232,7 +232,7 @@ class DGCNNSeg(DGCNNBase):
         # is constant per cloud, so its product is computed once per cloud instead of once per point
         seg0 = self.segmentation[0]
         w0 = seg0.layers[0].weight.view(seg0.layers[0].out_channels, -1)
-        y = nn.functional.linear(levels, w0[:, :192]).view(B, N, -1) + nn.functional.linear(g, w0[:, 192:]).unsqueeze(1)
+        y = F_hip.linear_pm(levels, w0[:, :192]).view(B, N, -1) + nn.functional.linear(g, w0[:, 192:]).unsqueeze(1)
         y = _norm_act(y.view(B * N, -1), list(seg0.layers)[1:])
         for block in list(self.segmentation)[1:]:
             y = pointwise_block(y, block)
