@@ -27,7 +27,7 @@
 namespace {
 
 constexpr int TP = 16;  // points per tile in the gather kernels (4 waves x 4 points)
-constexpr int TPW = 4;  // tiles per workgroup of the statistics kernel (one BN partial record per workgroup)
+constexpr int TPW = 2;  // tiles per workgroup of the statistics kernel: 8 waves, one BN partial record per workgroup
 
 __device__ __forceinline__ float lrelu(float u, float slope) { return u > 0.f ? u : u * slope; }
 
@@ -42,7 +42,14 @@ __global__ __launch_bounds__(1024) void csr_build_kernel(const int32_t *__restri
     const int32_t *ib = idx + b * NK;
     for (int j = tid; j < N; j += 1024) hist[j] = 0;
     __syncthreads();
-    for (long e = tid; e < NK; e += 1024) atomicAdd(&hist[ib[e]], 1);
+    for (long e0 = tid; e0 < NK; e0 += 8 * 1024) {
+        int dst[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dst[u] = (e0 + u * 1024 < NK) ? ib[e0 + u * 1024] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (dst[u] >= 0) atomicAdd(&hist[dst[u]], 1);
+    }
     __syncthreads();
     const int per = (N + 1023) / 1024;
     const int j0 = tid * per, j1 = min(N, j0 + per);
@@ -65,23 +72,31 @@ __global__ __launch_bounds__(1024) void csr_build_kernel(const int32_t *__restri
     }
     if (tid == 0) rowptr[(long)b * (N + 1) + N] = (int)NK;
     __syncthreads();
-    for (long e = tid; e < NK; e += 1024) {
-        const int pos = atomicAdd(&hist[ib[e]], 1);
-        const int i = (int)(e / k), s = (int)(e - (long)i * k);
-        col[b * NK + pos] = (i << 6) | s;
+    for (long e0 = tid; e0 < NK; e0 += 8 * 1024) {
+        int dst[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dst[u] = (e0 + u * 1024 < NK) ? ib[e0 + u * 1024] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (dst[u] >= 0) {
+                const long e = e0 + u * 1024;
+                const int pos = atomicAdd(&hist[dst[u]], 1);
+                const int i = (int)(e / k), s = (int)(e - (long)i * k);
+                col[b * NK + pos] = (i << 6) | s;
+            }
     }
 }
 
 // ------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256) void ec1_stats_select_kernel(const float *__restrict__ pq,
+__global__ __launch_bounds__(512) void ec1_stats_select_kernel(const float *__restrict__ pq,
                                                                 const int32_t *__restrict__ idx,
                                                                 const float *__restrict__ gamma, int N, int k, int Co,
                                                                 int training, float *__restrict__ ysel,
                                                                 uint8_t *__restrict__ arg, float *__restrict__ ssum,
                                                                 float *__restrict__ partials) {
-    __shared__ float red[3][4][64];
+    __shared__ float red[3][4 * TPW][64];
     const int b = blockIdx.x, tile = blockIdx.y, cg = blockIdx.z;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // 4 * TPW waves, 4 points each
     const int c = cg * 64 + lane;
     const int ld = 2 * Co;
     const float *P = pq + (long)b * N * ld;
@@ -89,8 +104,8 @@ __global__ __launch_bounds__(256) void ec1_stats_select_kernel(const float *__re
     const float sgn = gamma[c] >= 0.f ? 1.f : -1.f;
     float shift = 0.f, s1 = 0.f, s2 = 0.f, cnt = 0.f;
     bool first = true;
-    for (int t = 0; t < TPW * (TP / 4); ++t) {
-        const int i = (tile * TPW + t / (TP / 4)) * TP + wave * (TP / 4) + t % (TP / 4);
+    for (int t = 0; t < TP / 4; ++t) {
+        const int i = tile * TP * TPW + wave * (TP / 4) + t;
         if (i >= N) continue;
         // one coalesced load brings the point's k neighbour ids into the wave; each id is then broadcast with
         // v_readlane and the P-row gathers are issued four at a time (independent loads hide the L2 latency)
@@ -141,7 +156,7 @@ __global__ __launch_bounds__(256) void ec1_stats_select_kernel(const float *__re
     if (wave == 0) {
         float n = red[0][0][lane], mu = red[1][0][lane], M2 = red[2][0][lane];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
+        for (int w = 1; w < 4 * TPW; ++w) {
             const float nb_ = red[0][w][lane];
             if (nb_ > 0.f) {
                 const float tot = n + nb_;
@@ -358,8 +373,8 @@ int fsg_ec_stats1_records(int B, int N) { return B * fsg_cdiv(N, TP * TPW); }
 
 int fsg_ec_stats1_launch(const float *pq, const int32_t *idx, const float *gamma, int B, int N, int k, int Co,
                          float *ysel, uint8_t *arg, float *ssum, float *partials, hipStream_t st) {
-    hipLaunchKernelGGL(ec1_stats_select_kernel, dim3(B, fsg_cdiv(N, TP * TPW), Co / 64), dim3(256), 0, st, pq, idx, gamma,
-                       N, k, Co, 1, ysel, arg, ssum, partials);
+    hipLaunchKernelGGL(ec1_stats_select_kernel, dim3(B, fsg_cdiv(N, TP * TPW), Co / 64), dim3(256 * TPW), 0, st, pq, idx,
+                       gamma, N, k, Co, 1, ysel, arg, ssum, partials);
     FSG_CHECK_LAUNCH("edgeconv/stats");
     return FSG_OK;
 }
@@ -435,7 +450,7 @@ extern "C" int fsg_edgeconv1_fwd_f32(const float *pq, const int32_t *idx, const 
     FSG_REQUIRE(!training || workspace, "fsg_edgeconv1_fwd_f32: training needs the workspace");
     hipStream_t st = (hipStream_t)stream;
     const int tiles = fsg_cdiv(N, TP * TPW);
-    hipLaunchKernelGGL(ec1_stats_select_kernel, dim3(B, tiles, Co / 64), dim3(256), 0, st, pq, idx, gamma, N, k, Co,
+    hipLaunchKernelGGL(ec1_stats_select_kernel, dim3(B, tiles, Co / 64), dim3(256 * TPW), 0, st, pq, idx, gamma, N, k, Co,
                        training, ysel, arg, ssum, workspace);
     FSG_CHECK_LAUNCH("fsg_edgeconv1_fwd_f32/stats");
     if (training) {

@@ -121,6 +121,21 @@ def linear_pm(x, w, b=None):
     return _LinearPM.apply(x, w, b)
 
 
+class _EdgeWeights(torch.autograd.Function):
+    """W = [W_rel | W_ctr] (Co, 2C) -> [W_rel ; W_ctr - W_rel] (2Co, C): the P/Q form of the first EdgeConv layer, with a
+    two-kernel backward instead of the slice/zero-fill/accumulate chain autograd would record."""
+
+    @staticmethod
+    def forward(ctx, W):
+        C = W.shape[1] // 2
+        return torch.cat([W[:, :C], W[:, C:] - W[:, :C]], dim=0)
+
+    @staticmethod
+    def backward(ctx, g):
+        Co = g.shape[0] // 2
+        return torch.cat([g[:Co] - g[Co:], g[Co:]], dim=1)
+
+
 # ------------------------------------------------------------------ fused EdgeConv (models/dgcnn.py:234-241)
 def reverse_graph(idx):
     """CSR-by-destination of a kNN graph, cached on the index tensor (a static graph is shared by all layers)."""
@@ -196,8 +211,7 @@ def edgeconv1(x, idx, conv_weight, bn, slope, x_pm=None, both=False):
     _need_gpu(x, idx, conv_weight)
     Co, C2 = conv_weight.shape[0], conv_weight.shape[1]
     C = C2 // 2
-    W = conv_weight.reshape(Co, C2).to(torch.float32)
-    w_cat = torch.cat([W[:, :C], W[:, C:] - W[:, :C]], dim=0)                     # (2Co, C): [W_rel ; W_ctr - W_rel]
+    w_cat = _EdgeWeights.apply(conv_weight.reshape(Co, C2).to(torch.float32))   # (2Co, C): [W_rel ; W_ctr - W_rel]
     if x_pm is None:
         x_pm = x.transpose(1, 2)
     pq = linear_pm(x_pm.to(torch.float32).contiguous(), w_cat)                   # (B,N,2Co): one plain GEMM
@@ -285,8 +299,7 @@ def edgeconv2(x, idx, conv1_weight, bn1, conv2_weight, bn2, slope, x_pm=None, bo
     _need_gpu(x, idx, conv1_weight, conv2_weight)
     C1, CC = conv1_weight.shape[0], conv1_weight.shape[1]
     C = CC // 2
-    W = conv1_weight.reshape(C1, CC).to(torch.float32)
-    w_cat = torch.cat([W[:, :C], W[:, C:] - W[:, :C]], dim=0)
+    w_cat = _EdgeWeights.apply(conv1_weight.reshape(C1, CC).to(torch.float32))
     if x_pm is None:
         x_pm = x.transpose(1, 2)
     pq = linear_pm(x_pm.to(torch.float32).contiguous(), w_cat)                   # (B,N,128)
