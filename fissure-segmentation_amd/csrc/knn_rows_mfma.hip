@@ -27,7 +27,6 @@ typedef unsigned long long u64;
 constexpr int QB = 32;            // queries per workgroup (two 16-row MFMA blocks)
 constexpr int CH = 1024;          // candidates per chunk
 constexpr int STRIDE = CH + 4;    // LDS row stride (floats): 4*STRIDE = 16 (mod 32) -> conflict-free accumulator stores
-constexpr int WAVES = 8;
 constexpr int VPL = CH / 64;      // values per lane in phase B (16)
 
 __device__ __forceinline__ unsigned f2o(float d) {
@@ -88,16 +87,18 @@ __device__ __forceinline__ void sort64(T &v, int lane) {
     }
 }
 
-template <int KS>
-__global__ __launch_bounds__(512) void knn_rows_mfma_kernel(const float *__restrict__ x, const float *__restrict__ xx,
+// WAVES waves per workgroup (16 when the register budget allows: everything here is latency-bound, so thread-level
+// parallelism is the lever), SURV = survivor slots per wave
+template <int KS, int WAVES, int SURV>
+__global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *__restrict__ x, const float *__restrict__ xx,
                                                              int N, long sb, long sc, int c_knn, int k, int flags,
                                                              int32_t *__restrict__ idx_out,
                                                              float *__restrict__ dist_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *rows = reinterpret_cast<float *>(smem);                                        // [QB][STRIDE]
     u64 *carry = reinterpret_cast<u64 *>(smem + sizeof(float) * QB * STRIDE);             // [QB][64] best list so far
-    u64 *surv = carry + QB * 64;                                                          // [WAVES][128]
-    int *ccount = reinterpret_cast<int *>(surv + WAVES * 128);                            // [QB]
+    u64 *surv = carry + QB * 64;                                                          // [WAVES][SURV]
+    int *ccount = reinterpret_cast<int *>(surv + WAVES * SURV);                           // [QB]
 
     const int b = blockIdx.y, q0 = blockIdx.x * QB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -133,23 +134,33 @@ __global__ __launch_bounds__(512) void knn_rows_mfma_kernel(const float *__restr
         const int len = min(CH, N - c0);
         const int ntile = (len + 15) >> 4;
         // ---------------------------------------------------------------- phase A: distance block into LDS
+        float bn[KS], xn = 0.f;   // operand of the NEXT tile of this wave: its loads fly while the current MFMAs run
+        auto load_tile = [&](int t) {
+            const int jc = c0 + t * 16 + l15;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int ch = 4 * s + l4;
+                bn[s] = (ch < c_knn && jc < N) ? xb[ch * sc + jc] : 0.f;
+            }
+            xn = jc < N ? xxb[jc] : 0.f;
+        };
+        constexpr bool PREFETCH = KS <= 16;  // the 128-channel instantiation has no registers to spare
+        if (PREFETCH && wave < ntile && !(flags & 512)) load_tile(wave);
         for (int t = wave; t < CH / 16; t += WAVES) {
-            const int j0 = c0 + t * 16;
-            if (t >= ntile || (flags & 512)) {  // beyond the cloud (flag 512: timing ablation of phase A): +inf so that phase B never selects it
+            if (t >= ntile || (flags & 512)) {  // beyond the cloud (flag 512: timing ablation of phase A)
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) rows[(blk * 16 + l4 * 4 + e) * STRIDE + t * 16 + l15] = INFINITY;
                 continue;
             }
-            const int jc = j0 + l15;  // candidate column of this lane
+            const int jc = c0 + t * 16 + l15;  // candidate column of this lane
+            if (!PREFETCH) load_tile(t);
             float bv[KS];
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const int ch = 4 * s + l4;
-                bv[s] = (ch < c_knn && jc < N) ? xb[ch * sc + jc] : 0.f;
-            }
-            const float xc = jc < N ? xxb[jc] : 0.f;
+            for (int s = 0; s < KS; ++s) bv[s] = bn[s];
+            const float xc = xn;
+            if (PREFETCH && t + WAVES < ntile) load_tile(t + WAVES);
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -172,63 +183,61 @@ __global__ __launch_bounds__(512) void knn_rows_mfma_kernel(const float *__restr
         for (int qi = wave; qi < QB; qi += WAVES) {
             if (q0 + qi >= N || (flags & 256)) break;  // flag 256: timing ablation of phase B
             const float *row = rows + qi * STRIDE;
-            u64 *sv = surv + wave * 128;
-            unsigned key[VPL];
+            u64 *sv = surv + wave * SURV;
+            float v[VPL];
 #pragma unroll
             for (int s = 0; s < VPL / 4; ++s) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(row + s * 256 + 4 * lane);
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(row + s * 256 + 4 * lane);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) key[4 * s + e] = f2o(v[e]);
+                for (int e = 0; e < 4; ++e) v[4 * s + e] = w[e];
             }
             const int cc = ccount[qi];
             unsigned tau;
             if (cc >= KK) {
                 tau = (unsigned)(carry[qi * 64 + KK - 1] >> 32);   // K-th best so far: tighter than any chunk estimate
             } else {
-                unsigned m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;       // two smallest keys of this lane
+                float f1 = INFINITY, f2 = INFINITY;                // two smallest values of this lane
 #pragma unroll
                 for (int e = 0; e < VPL; ++e) {
-                    const unsigned kx = key[e];
-                    const unsigned hi = kx > m1 ? kx : m1;
-                    m1 = kx < m1 ? kx : m1;
-                    m2 = hi < m2 ? hi : m2;
+                    const float hi = fmaxf(v[e], f1);
+                    f1 = fminf(v[e], f1);
+                    f2 = fminf(f2, hi);
                 }
-                // carried entries (fewer than KK) also count as candidates of the bound
-                if (lane < cc) {
-                    const unsigned kx = (unsigned)(carry[qi * 64 + lane] >> 32);
-                    const unsigned hi = kx > m1 ? kx : m1;
-                    m1 = kx < m1 ? kx : m1;
-                    m2 = hi < m2 ? hi : m2;
+                if (lane < cc) {  // carried entries (fewer than K) also count as candidates of the bound
+                    const float cv = o2f((unsigned)(carry[qi * 64 + lane] >> 32));
+                    const float hi = fmaxf(cv, f1);
+                    f1 = fminf(cv, f1);
+                    f2 = fminf(f2, hi);
                 }
-                // K-th smallest of the 128 lane minima by binary search on the key bits: 32 rounds of two wave-wide
-                // compares + population counts (no cross-lane data movement, unlike a bitonic sort)
+                const unsigned m1 = f2o(f1), m2 = f2o(f2);
+                // upper bound of the K-th smallest of the 128 lane minima: binary search on the top 20 key bits (two
+                // wave-wide compares + population counts per round), the 12 low bits are rounded up
                 unsigned prefix = 0u;
 #pragma unroll 4
-                for (int bit = 31; bit >= 0; --bit) {
+                for (int bit = 31; bit >= 12; --bit) {
                     const unsigned t = prefix | ((1u << bit) - 1u);
                     const int c = __popcll(__ballot(m1 <= t)) + __popcll(__ballot(m2 <= t));
                     if (c < KK) prefix |= 1u << bit;
                 }
-                tau = prefix;
+                tau = prefix | 0xFFFu;
             }
-            // count + compact the survivors behind the carried list
-            int mine = 0;
+            const float tau_f = tau >= 0xFF800000u ? INFINITY : o2f(tau);   // keys above +inf are NaN patterns
+            // compact the survivors behind the carried list: one ballot + mbcnt per value slot
+            if (lane < cc) sv[lane] = carry[qi * 64 + lane];
+            int total = cc;
 #pragma unroll
             for (int e = 0; e < VPL; ++e) {
                 const int j = c0 + (e >> 2) * 256 + 4 * lane + (e & 3);
-                mine += (key[e] <= tau && j < N) ? 1 : 0;
-            }
-            const int incl = wave_incl_scan(mine, lane);
-            const int total_new = __shfl(incl, 63);
-            const int total = cc + total_new;
-            if (total <= 128) {
-                if (lane < cc) sv[lane] = carry[qi * 64 + lane];
-                int pos = cc + incl - mine;
-#pragma unroll
-                for (int e = 0; e < VPL; ++e) {
-                    const int j = c0 + (e >> 2) * 256 + 4 * lane + (e & 3);
-                    if (key[e] <= tau && j < N) sv[pos++] = ((u64)key[e] << 32) | (unsigned)j;
+                const bool pass = v[e] <= tau_f && j < N;
+                const u64 mask = __ballot(pass);
+                if (mask) {
+                    const int pos = total + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                           __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    if (pass && pos < SURV) sv[pos] = ((u64)f2o(v[e]) << 32) | (unsigned)j;
+                    total += __popcll(mask);
                 }
+            }
+            if (total <= SURV) {
                 __builtin_amdgcn_wave_barrier();
                 // rank by counting: every lane holds up to two survivors and counts how many of the `total` entries are
                 // smaller (entries are distinct: the index is part of the key); rank < K goes to slot `rank`
@@ -250,7 +259,7 @@ __global__ __launch_bounds__(512) void knn_rows_mfma_kernel(const float *__restr
 #pragma unroll
                 for (int e = 0; e < VPL; ++e) {
                     const int j = c0 + (e >> 2) * 256 + 4 * lane + (e & 3);
-                    mykeys[e] = (key[e] <= tau && j < N) ? (((u64)key[e] << 32) | (unsigned)j) : ~0ull;
+                    mykeys[e] = (v[e] <= tau_f && j < N) ? (((u64)f2o(v[e]) << 32) | (unsigned)j) : ~0ull;
                 }
                 mykeys[VPL] = lane < cc ? carry[qi * 64 + lane] : ~0ull;
                 for (int r = 0; r < KK; ++r) {
@@ -291,7 +300,15 @@ __global__ __launch_bounds__(256) void knn_sqnorm2_kernel(const float *__restric
     if (j >= N) return;
     const float *xb = x + (long)b * sb;
     float a = 0.f;
-    for (int c = 0; c < c_knn; ++c) a = __builtin_fmaf(xb[c * sc + j], xb[c * sc + j], a);
+    int c = 0;
+    for (; c + 8 <= c_knn; c += 8) {  // eight loads in flight, then the channel-ordered fma chain
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = xb[(c + u) * sc + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a = __builtin_fmaf(v[u], v[u], a);
+    }
+    for (; c < c_knn; ++c) a = __builtin_fmaf(xb[c * sc + j], xb[c * sc + j], a);
     xx[(long)b * N + j] = a;
 }
 
@@ -305,26 +322,27 @@ int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int
     hipLaunchKernelGGL(knn_sqnorm2_kernel, dim3(fsg_cdiv(N, 256), B), dim3(256), 0, st, x, N, (long)stride_b,
                        (long)stride_c, c_knn, xx_scratch);
     FSG_CHECK_LAUNCH("fsg_knn_dense_f32/sqnorm");
-    const size_t lds = sizeof(float) * QB * STRIDE + sizeof(u64) * (QB * 64 + WAVES * 128) + sizeof(int) * QB;
     dim3 grid(fsg_cdiv(N, QB), B);
-#define FSG_KNN_RM(KS)                                                                                                 \
+#define FSG_KNN_RM(KS, WV, SV)                                                                                         \
     do {                                                                                                               \
+        const size_t lds = sizeof(float) * QB * STRIDE + sizeof(u64) * (QB * 64 + (WV) * (SV)) + sizeof(int) * QB;     \
         static bool granted = false;                                                                                   \
         if (!granted) {                                                                                                \
-            if (hipFuncSetAttribute((const void *)knn_rows_mfma_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)lds) != hipSuccess) {                                                         \
+            if (hipFuncSetAttribute((const void *)knn_rows_mfma_kernel<KS, WV, SV>,                                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {             \
                 fsg_set_error("fsg_knn_dense_f32: cannot raise dynamic LDS to %zu", lds);                              \
                 return FSG_ERR_HIP;                                                                                    \
             }                                                                                                          \
             granted = true;                                                                                            \
         }                                                                                                              \
-        hipLaunchKernelGGL(knn_rows_mfma_kernel<KS>, grid, dim3(512), lds, st, x, xx_scratch, N, (long)stride_b,       \
-                           (long)stride_c, c_knn, k, flags, idx_out, dist_out);                                        \
+        hipLaunchKernelGGL((knn_rows_mfma_kernel<KS, WV, SV>), grid, dim3((WV) * 64), lds, st, x, xx_scratch, N,       \
+                           (long)stride_b, (long)stride_c, c_knn, k, flags, idx_out, dist_out);                        \
     } while (0)
-    if (c_knn <= 4) FSG_KNN_RM(1);
-    else if (c_knn <= 16) FSG_KNN_RM(4);
-    else if (c_knn <= 64) FSG_KNN_RM(16);
-    else FSG_KNN_RM(32);
+    const bool wide = k + drop <= 32;  // 16 waves leave 96 survivor slots per wave: enough for K <= 32
+    if (c_knn <= 4) { if (wide) FSG_KNN_RM(1, 16, 96); else FSG_KNN_RM(1, 8, 128); }
+    else if (c_knn <= 16) FSG_KNN_RM(4, 8, 128);
+    else if (c_knn <= 64) FSG_KNN_RM(16, 8, 128);
+    else FSG_KNN_RM(32, 8, 128);
 #undef FSG_KNN_RM
     FSG_CHECK_LAUNCH("fsg_knn_dense_f32/rows_mfma");
     return FSG_OK;
