@@ -552,3 +552,61 @@ def test_reverse_graph_is_the_transpose(fsg, device):
                 assert idxc[b, i, s] == j
                 edges.add((i, s))
         assert len(edges) == 500 * 12
+
+
+def test_hipgraph_replay_matches_eager_training(fsg, device):
+    """bench.py replays the training step as a hipGraph: three replayed steps must land on the same weights and loss as
+    three eagerly launched steps from the same initial state."""
+    import copy
+    import torch.nn.functional as F
+    from fissure_segmentation_amd.models.dgcnn import DGCNNSeg
+    torch.manual_seed(0)
+    base = DGCNNSeg(k=8, in_features=3, num_classes=4).to(device).train()
+    x = G(cloud(11, 2, 3, 256), device)
+    y = torch.randint(0, 4, (2, 256), device=device)
+
+    def one_step(net, opt):
+        for p in net.parameters():
+            p.grad = None
+        loss = F.cross_entropy(net(x), y)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def reset(net, opt):   # back to `base` IN PLACE (a captured graph keeps pointing at these very tensors)
+        with torch.no_grad():
+            for (_, a), (_, b) in zip(net.state_dict().items(), base.state_dict().items()):
+                a.copy_(b)
+            for st in opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+
+    runs = []
+    for use_graph in (False, True):
+        net = copy.deepcopy(base)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            one_step(net, opt)      # creates the optimizer state, sets kernel attributes, warms the allocator
+        torch.cuda.current_stream().wait_stream(side)
+        losses = []
+        if use_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = one_step(net, opt)
+            reset(net, opt)
+            for _ in range(3):
+                graph.replay()
+                losses.append(float(static_loss))
+        else:
+            reset(net, opt)
+            for _ in range(3):
+                losses.append(float(one_step(net, opt)))
+        runs.append((losses, [p.detach().clone() for p in net.parameters()]))
+    (l0, w0), (l1, w1) = runs
+    assert l0[0] > l0[-1]                                # training moves
+    np.testing.assert_allclose(l1, l0, rtol=2e-4)
+    for a, b in zip(w0, w1):
+        torch.testing.assert_close(a, b, rtol=5e-3, atol=2e-5)
