@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     args = ap.parse_args()
 
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)  # warm-up and capture use side streams
     rank, world, device = D.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")

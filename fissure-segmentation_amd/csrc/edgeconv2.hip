@@ -16,6 +16,8 @@
 // MFMA products per tile: dz1 = dy2 W2 (-> du1 = dz1 f'(u1), written once to HBM, and the dbeta1/dgamma1 sums) and
 // dW2 += dy2^T z1 (accumulated in registers over all tiles of the workgroup).  dP/dQ then come from the
 // reverse-graph gather over du1 (no float atomics anywhere).
+#include <stdlib.h>
+
 #include "fsg_common.h"
 
 namespace {
@@ -447,12 +449,17 @@ int fsg_ec_apply_launch(const float *ysel, const float *gamma, const float *beta
 int fsg_ec_stats1_records(int B, int N);
 
 static void ec2_tiling(int k, int C2, int &TP, int &Rpad, int &G, int B, int N) {
-    const int rmax = C2 == 64 ? 192 : 96;
+    static int rmax_env = -1;
+    if (rmax_env < 0) {
+        const char *e = getenv("FSG_EC2_FWD_RMAX");
+        rmax_env = e ? atoi(e) : 0;
+    }
+    const int rmax = rmax_env > 0 ? rmax_env : 64;   // measured: 64..128 rows/tile 160 us, 192 rows 191 us (C2 = 64)
     TP = rmax / k;
     if (TP < 1) TP = 1;
     Rpad = (TP * k + 31) & ~31;
     const int ntiles = (N + TP - 1) / TP;
-    G = 768 / (B > 0 ? B : 1);  // about three workgroups per CU in flight
+    G = 1024 / (B > 0 ? B : 1);  // about four workgroups per CU in flight
     if (G < 1) G = 1;
     if (G > ntiles) G = ntiles;
 }
@@ -534,12 +541,19 @@ int fsg_ec_bwd_point_launch(const float *gout, const float *gout_pm, const float
 int fsg_ec_sum_launch(const float *partials, int R, int L, int nvec, float *out0, float *out1, hipStream_t st);
 
 static void ec2_bwd_tiling(int k, int C2, int &TP, int &Rpad, int &G, int B, int N) {
-    const int rmax = C2 == 64 ? 96 : 64;
+    // 64 edge rows per tile: two row tiles x two column tiles = one MFMA pair per wave in every phase (balanced), and
+    // ~52 KB of LDS, i.e. three workgroups per CU (FSG_EC2_BWD_RMAX overrides for experiments)
+    static int rmax_env = -1;
+    if (rmax_env < 0) {
+        const char *e = getenv("FSG_EC2_BWD_RMAX");
+        rmax_env = e ? atoi(e) : 0;
+    }
+    const int rmax = rmax_env > 0 ? rmax_env : 64;
     TP = rmax / k;
     if (TP < 1) TP = 1;
     Rpad = (TP * k + 31) & ~31;
     const int ntiles = (N + TP - 1) / TP;
-    G = 512 / (B > 0 ? B : 1);
+    G = 768 / (B > 0 ? B : 1);
     if (G < 1) G = 1;
     if (G > ntiles) G = ntiles;
 }

@@ -21,6 +21,9 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("FSG_SHARE_GPU0"):  # rehearsal on a one-GPU box: every rank on device 0 (use with gloo)
+        local = 0
+    backend = backend or os.environ.get("FSG_DIST_BACKEND")
     use_gpu = torch.cuda.is_available()
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
     if use_gpu:

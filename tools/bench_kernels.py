@@ -54,6 +54,21 @@ if "edgeconv" in which:
             y = ec(x, idx); y.backward(g)
         med, mn = timeit(fb)
         print(f"edgeconv fwd+bwd                          : median {med:8.1f} us min {mn:8.1f}")
+if "ec2" in which:
+    from fissure_segmentation_amd.models.dgcnn import EdgeConv
+    B, C, N, k = 8, 3, 2048, 20
+    ec = EdgeConv(C, [64, 64], k, first_layer=True).to(dev).train()
+    x = torch.from_numpy(cloud(1, B, C, N)).to(dev).requires_grad_(True)
+    idx = F.knn_graph(x, k, c_knn=3)
+    g = torch.randn(B, 64, N, device=dev)
+    def fb():
+        y = ec(x, idx); y.backward(g)
+    fsg._lib.start_timing()
+    for _ in range(20): fb()
+    ms = fsg._lib.stop_timing()
+    for n, v in ms.items():
+        v = sorted(v)[len(v)//2]
+        print(f"  {n}: median {1e3*v:.1f} us")
 if "chamfer" in which:
     for (B, N) in [(8, 2048), (8, 4096)]:
         a = torch.rand(B, N, 3, device=dev); b = torch.rand(B, N, 3, device=dev)
