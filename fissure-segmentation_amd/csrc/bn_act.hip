@@ -8,6 +8,7 @@
 
 int fsg_ec_finalize_launch(const float *partials, int R, int Co, float eps, float momentum, float *mean, float *invstd,
                            float *running_mean, float *running_var, hipStream_t st);                 // edgeconv.hip
+size_t fsg_ec_finalize_stage_floats(int Co);
 int fsg_ec_sum_launch(const float *partials, int R, int L, int nvec, float *out0, float *out1, hipStream_t st);
 
 namespace {
@@ -258,7 +259,9 @@ __global__ __launch_bounds__(256) void bnmax_bwd_kernel(const float *__restrict_
 
 }  // namespace
 
-extern "C" size_t fsg_bn_act_workspace_bytes(long M, int C) { return sizeof(float) * (size_t)fsg_cdiv(M, ROWS) * 3 * C; }
+extern "C" size_t fsg_bn_act_workspace_bytes(long M, int C) {
+    return sizeof(float) * ((size_t)fsg_cdiv(M, ROWS) * 3 * C + fsg_ec_finalize_stage_floats(C));
+}
 
 extern "C" int fsg_bn_act_fwd_f32(const float *y, const float *gamma, const float *beta, float *running_mean,
                                   float *running_var, long M, int C, int training, float momentum, float eps,
@@ -306,7 +309,7 @@ extern "C" int fsg_bn_act_bwd_f32(const float *grad_out, const float *y, const f
 
 extern "C" size_t fsg_bn_act_max_workspace_bytes(int B, int N, int C) {
     const size_t rec = (size_t)B * fsg_cdiv(N, ROWS);
-    return sizeof(float) * rec * 5 * (size_t)C;  // (n, mean, M2) records + per-tile selected value and row
+    return sizeof(float) * (rec * 5 * (size_t)C + fsg_ec_finalize_stage_floats(C));  // records + stage + per-tile selection
 }
 
 extern "C" int fsg_bn_act_max_fwd_f32(const float *y, const float *gamma, const float *beta, float *running_mean,
@@ -318,7 +321,7 @@ extern "C" int fsg_bn_act_max_fwd_f32(const float *y, const float *gamma, const 
     hipStream_t st = (hipStream_t)stream;
     const int tiles = fsg_cdiv(N, ROWS), R = B * tiles;
     float *partials = workspace;
-    float *sel_val = partials + (size_t)R * 3 * C;
+    float *sel_val = partials + (size_t)R * 3 * C + fsg_ec_finalize_stage_floats(C);
     int *sel_arg = (int *)(sel_val + (size_t)R * C);
     hipLaunchKernelGGL(bnmax_stats_kernel, dim3(C / 64, R), dim3(256), 0, st, y, gamma, N, C, training, partials, sel_val,
                        sel_arg);

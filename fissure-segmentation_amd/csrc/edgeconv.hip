@@ -24,6 +24,10 @@
 // cloud's P rows.
 #include "fsg_common.h"
 
+size_t fsg_ec_finalize_stage_floats(int Co);
+int fsg_ec_finalize_launch(const float *partials, int R, int Co, float eps, float momentum, float *mean, float *invstd,
+                           float *running_mean, float *running_var, hipStream_t st);
+
 namespace {
 
 constexpr int TP = 16;  // points per tile in the gather kernels (4 waves x 4 points)
@@ -174,57 +178,64 @@ __global__ __launch_bounds__(512) void ec1_stats_select_kernel(const float *__re
     }
 }
 
-// merges R records (n, mean, M2) per channel in fp64 -> mean, invstd (+ running statistics update).
-// Two passes of plain sums (grand mean first, then M2 = sum M2_r + n_r (mean_r - mean)^2): no division per record.
-__global__ __launch_bounds__(1024) void bn_merge_finalize_kernel(const float *__restrict__ partials, int R, int Co,
-                                                                  float eps, float momentum, float *__restrict__ mean_out,
-                                                                  float *__restrict__ invstd_out,
-                                                                  float *__restrict__ running_mean,
-                                                                  float *__restrict__ running_var) {
-    __shared__ double red[2][16][64];
-    __shared__ double gmean[64];
-    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+// BatchNorm statistics from R per-workgroup records (n, mean, M2) per channel, in fp64, in two small launches:
+//   stage 1 (S workgroups per channel group): A = sum n, Bm = sum n*mean, Cm = sum (M2 + n*mean^2) over a slice of the
+//            records (one workgroup reading all records was bandwidth-bound on a single CU: 22 us for 1024 records);
+//   stage 2: mean = Bm/A, M2 = Cm - Bm^2/A (fp64: the subtraction is benign), invstd, running-statistics update.
+constexpr int FIN_S = 16;
+
+__global__ __launch_bounds__(256) void bn_partial_sums_kernel(const float *__restrict__ partials, int R, int Co,
+                                                               double *__restrict__ stage) {
+    __shared__ double red[3][4][64];
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    double sn = 0.0, sm = 0.0;
-#pragma unroll 8
-    for (int r = slice; r < R; r += 16) {
+    const int per = (R + FIN_S - 1) / FIN_S;
+    const int r0 = blockIdx.y * per, r1 = min(R, r0 + per);
+    double a = 0.0, bm = 0.0, cm = 0.0;
+#pragma unroll 4
+    for (int r = r0 + sub; r < r1; r += 4) {
         const float *pr = partials + (long)r * 3 * Co;
-        const double nb = pr[c];
-        sn += nb;
-        sm += nb * (double)pr[Co + c];
+        const double n = pr[c], mu = pr[Co + c];
+        a += n;
+        bm += n * mu;
+        cm += (double)pr[2 * Co + c] + n * mu * mu;
     }
-    red[0][slice][lane] = sn;
-    red[1][slice][lane] = sm;
+    red[0][sub][lane] = a;
+    red[1][sub][lane] = bm;
+    red[2][sub][lane] = cm;
     __syncthreads();
-    if (slice == 0) {
-        double n = 0.0, m = 0.0;
-        for (int w = 0; w < 16; ++w) { n += red[0][w][lane]; m += red[1][w][lane]; }
-        gmean[lane] = n > 0.0 ? m / n : 0.0;
-        red[0][0][lane] = n;
+    if (sub == 0) {
+        double *st = stage + ((long)blockIdx.y * 3) * Co;
+        st[c] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+        st[Co + c] = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+        st[2 * Co + c] = red[2][0][lane] + red[2][1][lane] + red[2][2][lane] + red[2][3][lane];
     }
-    __syncthreads();
-    const double mu = gmean[lane], n = red[0][0][lane];
-    __syncthreads();
-    double M2 = 0.0;
-#pragma unroll 8
-    for (int r = slice; r < R; r += 16) {
-        const float *pr = partials + (long)r * 3 * Co;
-        const double d = (double)pr[Co + c] - mu;
-        M2 += (double)pr[2 * Co + c] + (double)pr[c] * d * d;
+}
+
+__global__ __launch_bounds__(64) void bn_merge_finalize_kernel(const double *__restrict__ stage, int Co, float eps,
+                                                                float momentum, float *__restrict__ mean_out,
+                                                                float *__restrict__ invstd_out,
+                                                                float *__restrict__ running_mean,
+                                                                float *__restrict__ running_var) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    double n = 0.0, bm = 0.0, cm = 0.0;
+#pragma unroll
+    for (int s = 0; s < FIN_S; ++s) {
+        const double *st = stage + ((long)s * 3) * Co;
+        n += st[c];
+        bm += st[Co + c];
+        cm += st[2 * Co + c];
     }
-    red[1][slice][lane] = M2;
-    __syncthreads();
-    if (slice == 0) {
-        M2 = 0.0;
-        for (int w = 0; w < 16; ++w) M2 += red[1][w][lane];
-        const double var = n > 0.0 ? M2 / n : 0.0;
-        mean_out[c] = (float)mu;
-        invstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
-        if (running_mean) {
-            const double unbiased = n > 1.0 ? M2 / (n - 1.0) : var;
-            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
-            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
-        }
+    const double mu = n > 0.0 ? bm / n : 0.0;
+    double M2 = n > 0.0 ? cm - bm * mu : 0.0;
+    M2 = M2 > 0.0 ? M2 : 0.0;
+    const double var = n > 0.0 ? M2 / n : 0.0;
+    mean_out[c] = (float)mu;
+    invstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = n > 1.0 ? M2 / (n - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
     }
 }
 
@@ -379,10 +390,17 @@ int fsg_ec_stats1_launch(const float *pq, const int32_t *idx, const float *gamma
     return FSG_OK;
 }
 
+// `partials` holds R records of 3*Co floats FOLLOWED by the fp64 stage area (fsg_ec_finalize_stage_floats(Co) floats)
+size_t fsg_ec_finalize_stage_floats(int Co) { return (size_t)FIN_S * 3 * Co * 2 + 2; }
+
 int fsg_ec_finalize_launch(const float *partials, int R, int Co, float eps, float momentum, float *mean, float *invstd,
                            float *running_mean, float *running_var, hipStream_t st) {
-    hipLaunchKernelGGL(bn_merge_finalize_kernel, dim3(Co / 64), dim3(1024), 0, st, partials, R, Co, eps, momentum, mean,
-                       invstd, running_mean, running_var);
+    uintptr_t addr = (uintptr_t)(partials + (size_t)R * 3 * Co);
+    double *stage = (double *)((addr + 7) & ~(uintptr_t)7);
+    hipLaunchKernelGGL(bn_partial_sums_kernel, dim3(Co / 64, FIN_S), dim3(256), 0, st, partials, R, Co, stage);
+    FSG_CHECK_LAUNCH("edgeconv/partial_sums");
+    hipLaunchKernelGGL(bn_merge_finalize_kernel, dim3(Co / 64), dim3(64), 0, st, stage, Co, eps, momentum, mean, invstd,
+                       running_mean, running_var);
     FSG_CHECK_LAUNCH("edgeconv/finalize");
     return FSG_OK;
 }
@@ -436,7 +454,7 @@ extern "C" int fsg_graph_reverse_csr(const int32_t *idx, int B, int N, int k, in
 
 extern "C" size_t fsg_edgeconv1_workspace_bytes(int B, int N, int Co) {
     const size_t rec = (size_t)B * (size_t)fsg_cdiv(N, TP * TPW);
-    return sizeof(float) * rec * 3 * (size_t)Co;
+    return sizeof(float) * (rec * 3 * (size_t)Co + fsg_ec_finalize_stage_floats(Co));
 }
 
 extern "C" int fsg_edgeconv1_fwd_f32(const float *pq, const int32_t *idx, const float *gamma, const float *beta,
@@ -454,9 +472,9 @@ extern "C" int fsg_edgeconv1_fwd_f32(const float *pq, const int32_t *idx, const 
                        training, ysel, arg, ssum, workspace);
     FSG_CHECK_LAUNCH("fsg_edgeconv1_fwd_f32/stats");
     if (training) {
-        hipLaunchKernelGGL(bn_merge_finalize_kernel, dim3(Co / 64), dim3(1024), 0, st, workspace, B * tiles, Co, eps,
-                           momentum, mean, invstd, running_mean, running_var);
-        FSG_CHECK_LAUNCH("fsg_edgeconv1_fwd_f32/finalize");
+        const int rc = fsg_ec_finalize_launch(workspace, B * tiles, Co, eps, momentum, mean, invstd, running_mean,
+                                              running_var, st);
+        if (rc != FSG_OK) return rc;
     }
     hipLaunchKernelGGL(ec1_apply_kernel, dim3(B, fsg_cdiv(N, 64), Co / 64), dim3(256), 0, st, ysel, gamma, beta, mean,
                        invstd, N, Co, slope, out, out_pm);

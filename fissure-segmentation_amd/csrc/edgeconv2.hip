@@ -447,6 +447,7 @@ int fsg_ec_finalize_launch(const float *partials, int R, int Co, float eps, floa
 int fsg_ec_apply_launch(const float *ysel, const float *gamma, const float *beta, const float *mean, const float *invstd,
                         int B, int N, int Co, float slope, float *out, float *out_pm, hipStream_t st);
 int fsg_ec_stats1_records(int B, int N);
+size_t fsg_ec_finalize_stage_floats(int Co);
 
 static void ec2_tiling(int k, int C2, int &TP, int &Rpad, int &G, int B, int N) {
     static int rmax_env = -1;
@@ -467,8 +468,8 @@ static void ec2_tiling(int k, int C2, int &TP, int &Rpad, int &G, int B, int N) 
 extern "C" size_t fsg_edgeconv2_workspace_bytes(int B, int N, int k, int C2) {
     int TP, Rpad, G;
     ec2_tiling(k, C2, TP, Rpad, G, B, N);
-    const size_t rec1 = (size_t)fsg_ec_stats1_records(B, N) * 3 * C1;
-    const size_t rec2 = (size_t)B * G * 3 * C2;
+    const size_t rec1 = (size_t)fsg_ec_stats1_records(B, N) * 3 * C1 + fsg_ec_finalize_stage_floats(C1);
+    const size_t rec2 = (size_t)B * G * 3 * C2 + fsg_ec_finalize_stage_floats(C2);
     // layer-1 scratch: ysel1 (unused output of the shared stats kernel), arg1
     const size_t scratch1 = (size_t)B * N * C1 * sizeof(float) + (size_t)B * N * C1;
     return sizeof(float) * (rec1 + rec2) + scratch1 + 256;
@@ -492,8 +493,8 @@ extern "C" int fsg_edgeconv2_fwd_f32(const float *pq, const int32_t *idx, const 
     ec2_tiling(k, C2, TP, Rpad, G, B, N);
     const int rec1 = fsg_ec_stats1_records(B, N);
     float *part1 = (float *)workspace;
-    float *part2 = part1 + (size_t)rec1 * 3 * C1;
-    float *ysel1 = part2 + (size_t)B * G * 3 * C2;
+    float *part2 = part1 + (size_t)rec1 * 3 * C1 + fsg_ec_finalize_stage_floats(C1);
+    float *ysel1 = part2 + (size_t)B * G * 3 * C2 + fsg_ec_finalize_stage_floats(C2);
     uint8_t *arg1 = (uint8_t *)(ysel1 + (size_t)B * N * C1);
     int rc;
     if (training) {  // BN1 statistics over all edges of y1 = P_j + Q_i (shared kernel; its selection output is unused)
