@@ -137,16 +137,61 @@ class _EdgeWeights(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------ fused EdgeConv (models/dgcnn.py:234-241)
+import os as _os
+
+# Building the reverse graphs on a side stream during the forward was MEASURED SLOWER inside the replayed hipGraph
+# (2.06 vs 1.83 ms/step on MI355X: the fork/join edges cost more than the ~30 us builder hides), so it is opt-in.
+_ASYNC_CSR = _os.environ.get("FSG_ASYNC_CSR", "0") == "1"
+_side_streams = {}
+
+
+def _side_stream(device):
+    st = _side_streams.get(device)
+    if st is None:
+        st = _side_streams[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _build_csr(idx):
+    B, N, k = idx.shape
+    rowptr = torch.empty(B, N + 1, dtype=torch.int32, device=idx.device)
+    col = torch.empty(B, N * k, dtype=torch.int32, device=idx.device)
+    with torch.cuda.device(idx.device):
+        _lib.call("fsg_graph_reverse_csr", _p(idx), B, N, k, _p(rowptr), _p(col), _stream())
+    return rowptr, col
+
+
+def prefetch_reverse_graph(idx):
+    """Start building the reverse graph of `idx` on a side stream (the builder runs 8 workgroups: ~30 us of an otherwise
+    idle GPU if it sat on the main stream).  The backward joins the side stream before its first use; inside a hipGraph
+    capture this becomes a parallel branch.  Only called when a backward pass will follow."""
+    if getattr(idx, "_fsg_csr", None) is not None or getattr(idx, "_fsg_csr_pending", None) is not None:
+        return
+    main = torch.cuda.current_stream(idx.device)
+    side = _side_stream(idx.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        rowptr, col = _build_csr(idx)
+        done = torch.cuda.Event()
+        done.record(side)
+    for t in (rowptr, col):
+        t.record_stream(main)
+    idx.record_stream(side)
+    idx._fsg_csr_pending = (rowptr, col, done)
+
+
 def reverse_graph(idx):
     """CSR-by-destination of a kNN graph, cached on the index tensor (a static graph is shared by all layers)."""
     cached = getattr(idx, "_fsg_csr", None)
     if cached is None:
-        B, N, k = idx.shape
-        rowptr = torch.empty(B, N + 1, dtype=torch.int32, device=idx.device)
-        col = torch.empty(B, N * k, dtype=torch.int32, device=idx.device)
-        with torch.cuda.device(idx.device):
-            _lib.call("fsg_graph_reverse_csr", _p(idx), B, N, k, _p(rowptr), _p(col), _stream())
-        cached = (rowptr, col)
+        pending = getattr(idx, "_fsg_csr_pending", None)
+        if pending is not None:
+            rowptr, col, done = pending
+            torch.cuda.current_stream(idx.device).wait_event(done)
+            idx._fsg_csr_pending = None
+            cached = (rowptr, col)
+        else:
+            cached = _build_csr(idx)
         idx._fsg_csr = cached
     return cached
 
@@ -223,7 +268,10 @@ def edgeconv1(x, idx, conv_weight, bn, slope, x_pm=None, both=False):
     track = training and bn.track_running_stats
     if idx.dtype != torch.int32:
         idx = idx.to(torch.int32)
-    out, out_pm = _EdgeConv1.apply(pq, idx.contiguous(), bn.weight, bn.bias,
+    idx = idx.contiguous()
+    if torch.is_grad_enabled() and pq.requires_grad and _ASYNC_CSR:
+        prefetch_reverse_graph(idx)
+    out, out_pm = _EdgeConv1.apply(pq, idx, bn.weight, bn.bias,
                                    bn.running_mean if (track or not training) else None,
                                    bn.running_var if (track or not training) else None, training, float(momentum),
                                    float(bn.eps), float(slope))
@@ -310,7 +358,10 @@ def edgeconv2(x, idx, conv1_weight, bn1, conv2_weight, bn2, slope, x_pm=None, bo
         raise RuntimeError("edgeconv2: both BatchNorm layers must be in the same mode")
     if idx.dtype != torch.int32:
         idx = idx.to(torch.int32)
-    out, out_pm = _EdgeConv2.apply(pq, idx.contiguous(), w2, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
+    idx = idx.contiguous()
+    if torch.is_grad_enabled() and pq.requires_grad and _ASYNC_CSR:
+        prefetch_reverse_graph(idx)
+    out, out_pm = _EdgeConv2.apply(pq, idx, w2, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
                                    bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, t1, m1, m2, float(bn1.eps),
                                    float(bn2.eps), float(slope))
     return (out, out_pm) if both else out
