@@ -36,16 +36,39 @@ class DGCNN_Cls_Encoder(LoadableModel):
         if not x.is_cuda:
             raise RuntimeError("PC-AE encoder (HIP path) needs its input on the GPU")
         graph = F_hip.knn_graph(x, self.k, c_knn=3, fix_diag=False) if self.static else None
-        feats = []
+        B, _, N = x.shape
+        feats, x_pm = [], None
         for block in (self.conv1, self.conv2, self.conv3, self.conv4):
             conv, bn, act = block
             if F_hip.edgeconv1_supported(conv.out_channels, self.k):  # fused gather+conv+BN+LeakyReLU+max
                 idx = graph if graph is not None else F_hip.knn_graph(x, self.k, fix_diag=False)
-                x = F_hip.edgeconv1(x, idx, conv.weight, bn, act.negative_slope)
+                x, x_pm = F_hip.edgeconv1(x, idx, conv.weight, bn, act.negative_slope, x_pm=x_pm, both=True)
             else:
                 x = block(get_graph_feature(x, k=self.k, idx=graph)).max(dim=-1)[0]
-            feats.append(x)
-        return self.conv5(torch.cat(feats, dim=1)).max(dim=-1)[0].unsqueeze(1)  # (B, 1, n_embedding)
+                x_pm = x.transpose(1, 2).contiguous()
+            feats.append(x_pm)
+        conv5, bn5, act5 = self.conv5
+        y = F_hip.linear_pm(torch.cat(feats, dim=2).view(B * N, -1), conv5.weight.view(conv5.out_channels, -1))
+        if conv5.out_channels % 64 == 0:   # BN + LeakyReLU + max over the points, activation never materialised
+            code = F_hip.bn_act_max(y.view(B, N, -1), bn5, act5.negative_slope)
+        else:
+            code = act5(bn5(y)).view(B, N, -1).max(dim=1)[0]
+        return code.unsqueeze(1)  # (B, 1, n_embedding)
+
+
+def _first_layer_split(conv, code, pts_pm):
+    """1x1 conv on cat([code repeated over the m points, per-point input]) without building that tensor: the code part is
+    one small GEMM per cloud, the per-point part (2 or 3 channels) one thin GEMM -- (B,E), (B,m,c) -> (B*m, Cout)."""
+    E = code.shape[1]
+    w = conv.weight.view(conv.out_channels, -1)
+    per_cloud = nn.functional.linear(code, w[:, :E], conv.bias)                         # (B, Cout)
+    per_point = F_hip.linear_pm(pts_pm.reshape(-1, pts_pm.shape[-1]), w[:, E:].contiguous())   # (B*m, Cout)
+    B, m = pts_pm.shape[0], pts_pm.shape[1]
+    return (per_point.view(B, m, -1) + per_cloud.unsqueeze(1)).view(B * m, -1)
+
+
+def _lin(conv, x_pm):
+    return F_hip.linear_pm(x_pm, conv.weight.view(conv.out_channels, -1), conv.bias)
 
 
 class Decoder(LoadableModel):
@@ -96,10 +119,14 @@ class FoldingDecoder(Decoder):
         self.folding2 = _fold_mlp(n_embedding + 3, n_embedding)
 
     def forward(self, x):
-        z = x.transpose(1, 2).expand(-1, -1, self.m)
-        grid = self.get_folding_points(x.shape[0]).transpose(1, 2).to(x.device)
-        first = self.folding1(torch.cat((z, grid), dim=1))
-        return self.folding2(torch.cat((z, first), dim=1))
+        B = x.shape[0]
+        code = x.reshape(B, -1)                                                  # (B, E)
+        pts = self.get_folding_points(B).to(x.device)                            # (B, m, 2|3) point-major
+        for fold in (self.folding1, self.folding2):                              # Conv1d-ReLU-Conv1d-ReLU-Conv1d as GEMMs
+            y = torch.relu(_first_layer_split(fold[0], code, pts))
+            y = torch.relu(_lin(fold[2], y))
+            pts = _lin(fold[4], y).view(B, self.m, 3)
+        return pts.transpose(1, 2).contiguous()                                  # (B, 3, m)
 
 
 def _deform_mlp(width):
@@ -126,11 +153,16 @@ class DeformingDecoder(Decoder):
         return pts
 
     def forward(self, x):
-        z = x.transpose(1, 2).expand(-1, -1, self.m)
-        pts = self.get_folding_points(x.shape[0]).transpose(1, 2).to(x.device)
-        for layer in self.deforming_layers:
-            pts = pts + layer(torch.cat((z, pts), dim=1))
-        return pts
+        from .dgcnn import _norm_act, pointwise_block
+        B = x.shape[0]
+        code = x.reshape(B, -1)
+        pts = self.get_folding_points(B).to(x.device)                            # (B, m, 3) point-major
+        for mlp in self.deforming_layers:
+            y = _first_layer_split(mlp[0].layers[0], code, pts)
+            y = _norm_act(y, list(mlp[0].layers)[1:])
+            y = pointwise_block(y, mlp[1])
+            pts = pts + pointwise_block(y, mlp[2]).view(B, self.m, 3)
+        return pts.transpose(1, 2).contiguous()
 
 
 class DGCNNFoldingNet(LoadableModel):

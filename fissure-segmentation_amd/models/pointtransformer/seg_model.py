@@ -7,7 +7,15 @@ import torch.nn as nn
 
 from ...norm import BatchNorm1d
 from ..point_seg_net import PointSegmentationModelBase
+from ... import functional as F_hip
 from . import pointops
+
+
+def _lin(layer, x):
+    """nn.Linear applied as a point-major GEMM with the split-K weight gradient (functional.linear_pm)."""
+    shape = x.shape
+    y = F_hip.linear_pm(x.reshape(-1, shape[-1]), layer.weight, layer.bias)
+    return y.view(*shape[:-1], -1)
 
 
 class PointTransformerLayer(nn.Module):
@@ -36,16 +44,16 @@ class PointTransformerLayer(nn.Module):
 
     def forward(self, pxo):
         p, x, o = pxo
-        q, k, v = self.linear_q(x), self.linear_k(x), self.linear_v(x)
+        q, k, v = _lin(self.linear_q, x), _lin(self.linear_k, x), _lin(self.linear_v, x)
         idx, _ = pointops.knnquery(self.nsample, p, p, o, o)  # one graph for keys and values
         rel = pointops.grouping(p, idx) - p.unsqueeze(1)       # (n, ns, 3)
         gk = pointops.grouping(k, idx)                         # (n, ns, c)
         lin1, bn, act, lin2 = self.linear_p
-        pr = lin2(act(self._bn_over_neighbours(bn, lin1(rel))))
+        pr = _lin(lin2, act(self._bn_over_neighbours(bn, _lin(lin1, rel))))
         w = gk - q.unsqueeze(1) + pr
         bn1, act1, lw1, bn2, act2, lw2 = self.linear_w
-        w = lw1(act1(self._bn_over_neighbours(bn1, w)))
-        w = lw2(act2(self._bn_over_neighbours(bn2, w)))
+        w = _lin(lw1, act1(self._bn_over_neighbours(bn1, w)))
+        w = _lin(lw2, act2(self._bn_over_neighbours(bn2, w)))
         w = self.softmax(w)                                    # over the neighbours
         return pointops.aggregation(v, pr, w, idx)             # (n, c)
 
@@ -67,7 +75,7 @@ class TransitionDown(nn.Module):
     def forward(self, pxo):
         p, x, o = pxo
         if self.stride == 1:
-            return [p, self.relu(self.bn(self.linear(x))), o]
+            return [p, self.relu(self.bn(_lin(self.linear, x))), o]
         ends = pointops.host_offsets(o)
         new_ends, prev, total = [], 0, 0
         for e in ends:
@@ -79,7 +87,7 @@ class TransitionDown(nn.Module):
         n_p = p[idx.long(), :].contiguous()
         g = pointops.queryandgroup(self.nsample, p, n_p, x, None, o, n_o, use_xyz=True)  # (m, ns, 3+c)
         m, ns, c = g.shape
-        y = self.relu(self.bn(self.linear(g).reshape(m * ns, -1))).view(m, ns, -1)
+        y = self.relu(self.bn(_lin(self.linear, g).reshape(m * ns, -1))).view(m, ns, -1)
         return [n_p, y.max(dim=1)[0], n_o]
 
 
@@ -128,9 +136,9 @@ class PointTransformerBlock(nn.Module):
 
     def forward(self, pxo):
         p, x, o = pxo
-        y = self.relu(self.bn1(self.linear1(x)))
+        y = self.relu(self.bn1(_lin(self.linear1, x)))
         y = self.relu(self.bn2(self.transformer2([p, y, o])))
-        return [p, self.relu(self.bn3(self.linear3(y)) + x), o]
+        return [p, self.relu(self.bn3(_lin(self.linear3, y)) + x), o]
 
 
 class PointTransformerSeg(nn.Module):
