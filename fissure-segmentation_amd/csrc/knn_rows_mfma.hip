@@ -25,9 +25,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
 
 constexpr int QB = 32;            // queries per workgroup (two 16-row MFMA blocks)
-constexpr int CH = 1024;          // candidates per chunk
-constexpr int STRIDE = CH + 4;    // LDS row stride (floats): 4*STRIDE = 16 (mod 32) -> conflict-free accumulator stores
-constexpr int VPL = CH / 64;      // values per lane in phase B (16)
+// CH = candidates per chunk (template): 1024 -> 131 KB of distance rows, one workgroup per CU; 512 -> 66 KB, TWO workgroups
+// per CU, so one workgroup's selection phase overlaps the other's MFMA phase.  LDS row stride CH + 4 floats:
+// 4*STRIDE = 16 (mod 32) -> conflict-free accumulator stores.  CK = capacity of the carried best list (>= k + drop).
 
 __device__ __forceinline__ unsigned f2o(float d) {
     const unsigned u = __float_as_uint(d);
@@ -89,15 +89,17 @@ __device__ __forceinline__ void sort64(T &v, int lane) {
 
 // WAVES waves per workgroup (16 when the register budget allows: everything here is latency-bound, so thread-level
 // parallelism is the lever), SURV = survivor slots per wave
-template <int KS, int WAVES, int SURV>
+template <int KS, int WAVES, int SURV, int CH, int CK>
 __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *__restrict__ x, const float *__restrict__ xx,
                                                              int N, long sb, long sc, int c_knn, int k, int flags,
                                                              int32_t *__restrict__ idx_out,
                                                              float *__restrict__ dist_out) {
+    constexpr int STRIDE = CH + 4;
+    constexpr int VPL = CH / 64;      // values per lane in the selection phase
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *rows = reinterpret_cast<float *>(smem);                                        // [QB][STRIDE]
-    u64 *carry = reinterpret_cast<u64 *>(smem + sizeof(float) * QB * STRIDE);             // [QB][64] best list so far
-    u64 *surv = carry + QB * 64;                                                          // [WAVES][SURV]
+    u64 *carry = reinterpret_cast<u64 *>(smem + sizeof(float) * QB * STRIDE);             // [QB][CK] best list so far
+    u64 *surv = carry + QB * CK;                                                          // [WAVES][SURV]
     int *ccount = reinterpret_cast<int *>(surv + WAVES * SURV);                           // [QB]
 
     const int b = blockIdx.y, q0 = blockIdx.x * QB;
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
             const int cc = ccount[qi];
             unsigned tau;
             if (cc >= KK) {
-                tau = (unsigned)(carry[qi * 64 + KK - 1] >> 32);   // K-th best so far: tighter than any chunk estimate
+                tau = (unsigned)(carry[qi * CK + KK - 1] >> 32);   // K-th best so far: tighter than any chunk estimate
             } else {
                 float f1 = INFINITY, f2 = INFINITY;                // two smallest values of this lane
 #pragma unroll
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
                     f2 = fminf(f2, hi);
                 }
                 if (lane < cc) {  // carried entries (fewer than K) also count as candidates of the bound
-                    const float cv = o2f((unsigned)(carry[qi * 64 + lane] >> 32));
+                    const float cv = o2f((unsigned)(carry[qi * CK + lane] >> 32));
                     const float hi = fmaxf(cv, f1);
                     f1 = fminf(cv, f1);
                     f2 = fminf(f2, hi);
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
             }
             const float tau_f = tau >= 0xFF800000u ? INFINITY : o2f(tau);   // keys above +inf are NaN patterns
             // compact the survivors behind the carried list: one ballot + mbcnt per value slot
-            if (lane < cc) sv[lane] = carry[qi * 64 + lane];
+            if (lane < cc) sv[lane] = carry[qi * CK + lane];
             int total = cc;
 #pragma unroll
             for (int e = 0; e < VPL; ++e) {
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
                 // rank by counting: every lane holds up to two survivors and counts how many of the `total` entries are
                 // smaller (entries are distinct: the index is part of the key); rank < K goes to slot `rank`
                 const u64 e0 = lane < total ? sv[lane] : ~0ull;
-                const u64 e1 = (64 + lane) < total ? sv[64 + lane] : ~0ull;
+                const u64 e1 = (SURV > 64 && (64 + lane) < total) ? sv[(64 + lane) % SURV] : ~0ull;
                 int r0 = 0, r1 = 0;
 #pragma unroll 8
                 for (int t = 0; t < total; ++t) {
@@ -250,8 +252,8 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
                     r0 += xk < e0 ? 1 : 0;
                     r1 += xk < e1 ? 1 : 0;
                 }
-                if (lane < total && r0 < KK) carry[qi * 64 + r0] = e0;
-                if ((64 + lane) < total && r1 < KK) carry[qi * 64 + r1] = e1;
+                if (lane < total && r0 < KK) carry[qi * CK + r0] = e0;
+                if (SURV > 64 && (64 + lane) < total && r1 < KK) carry[qi * CK + r1] = e1;
                 __builtin_amdgcn_wave_barrier();
             } else {
                 // slow exact path (massive ties): KK rounds of wave arg-min over the 16 row values + carried entry
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
                     const int j = c0 + (e >> 2) * 256 + 4 * lane + (e & 3);
                     mykeys[e] = (v[e] <= tau_f && j < N) ? (((u64)f2o(v[e]) << 32) | (unsigned)j) : ~0ull;
                 }
-                mykeys[VPL] = lane < cc ? carry[qi * 64 + lane] : ~0ull;
+                mykeys[VPL] = lane < cc ? carry[qi * CK + lane] : ~0ull;
                 for (int r = 0; r < KK; ++r) {
                     u64 best = mykeys[0];
 #pragma unroll
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
                     }
 #pragma unroll
                     for (int e = 0; e <= VPL; ++e) mykeys[e] = mykeys[e] == best ? ~0ull : mykeys[e];
-                    if (lane == 0) carry[qi * 64 + r] = best;
+                    if (lane == 0) carry[qi * CK + r] = best;
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
         const int q = q0 + qi;
         if (q >= N) break;
         if (lane >= drop && lane < KK) {
-            const u64 v = carry[qi * 64 + lane];
+            const u64 v = carry[qi * CK + lane];
             const long o = ((long)b * N + q) * k + (lane - drop);
             idx_out[o] = (int)(unsigned)(v & 0xFFFFFFFFull);
             if (dist_out) dist_out[o] = o2f((unsigned)(v >> 32));
@@ -323,26 +325,29 @@ int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int
                        (long)stride_c, c_knn, xx_scratch);
     FSG_CHECK_LAUNCH("fsg_knn_dense_f32/sqnorm");
     dim3 grid(fsg_cdiv(N, QB), B);
-#define FSG_KNN_RM(KS, WV, SV)                                                                                         \
+#define FSG_KNN_RM(KS, WV, SV, CHK, CKK)                                                                               \
     do {                                                                                                               \
-        const size_t lds = sizeof(float) * QB * STRIDE + sizeof(u64) * (QB * 64 + (WV) * (SV)) + sizeof(int) * QB;     \
+        const size_t lds = sizeof(float) * QB * ((CHK) + 4) + sizeof(u64) * (QB * (CKK) + (WV) * (SV)) + sizeof(int) * QB; \
         static bool granted = false;                                                                                   \
         if (!granted) {                                                                                                \
-            if (hipFuncSetAttribute((const void *)knn_rows_mfma_kernel<KS, WV, SV>,                                    \
+            if (hipFuncSetAttribute((const void *)knn_rows_mfma_kernel<KS, WV, SV, CHK, CKK>,                          \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {             \
                 fsg_set_error("fsg_knn_dense_f32: cannot raise dynamic LDS to %zu", lds);                              \
                 return FSG_ERR_HIP;                                                                                    \
             }                                                                                                          \
             granted = true;                                                                                            \
         }                                                                                                              \
-        hipLaunchKernelGGL((knn_rows_mfma_kernel<KS, WV, SV>), grid, dim3((WV) * 64), lds, st, x, xx_scratch, N,       \
+        hipLaunchKernelGGL((knn_rows_mfma_kernel<KS, WV, SV, CHK, CKK>), grid, dim3((WV) * 64), lds, st, x, xx_scratch, N, \
                            (long)stride_b, (long)stride_c, c_knn, k, flags, idx_out, dist_out);                        \
     } while (0)
-    const bool wide = k + drop <= 32;  // 16 waves leave 96 survivor slots per wave: enough for K <= 32
-    if (c_knn <= 4) { if (wide) FSG_KNN_RM(1, 16, 96); else FSG_KNN_RM(1, 8, 128); }
-    else if (c_knn <= 16) FSG_KNN_RM(4, 8, 128);
-    else if (c_knn <= 64) FSG_KNN_RM(16, 8, 128);
-    else FSG_KNN_RM(32, 8, 128);
+    const bool small_k = k + drop <= 32;                      // carried list fits 32 slots
+    // 512-candidate chunks fit two workgroups per CU in LDS but not in registers (241 VGPRs -> 2 waves/SIMD): measured
+    // 148 us against 136 us for the 1024-candidate chunks at C=64, so they are opt-in (flag 2048, tests)
+    const bool half = small_k && (flags & 2048);
+    if (c_knn <= 4) { if (small_k) FSG_KNN_RM(1, 16, 96, 1024, 64); else FSG_KNN_RM(1, 8, 128, 1024, 64); }
+    else if (c_knn <= 16) FSG_KNN_RM(4, 8, 128, 1024, 64);
+    else if (c_knn <= 64) { if (half) FSG_KNN_RM(16, 8, 64, 512, 32); else FSG_KNN_RM(16, 8, 128, 1024, 64); }
+    else { if (half) FSG_KNN_RM(32, 8, 64, 512, 32); else FSG_KNN_RM(32, 8, 128, 1024, 64); }
 #undef FSG_KNN_RM
     FSG_CHECK_LAUNCH("fsg_knn_dense_f32/rows_mfma");
     return FSG_OK;
