@@ -113,6 +113,8 @@ __global__ __launch_bounds__(BLOCK) void knn_dense_rows_kernel(
 
 int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k,
                              int flags, int32_t *idx_out, float *dist_out, float *xx_scratch, hipStream_t st);
+int fsg_knn_pipe_launch(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k, int flags,
+                        int32_t *idx_out, float *dist_out, float *xx_scratch, hipStream_t st);
 int fsg_knn_mfma_launch(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k, int flags,
                         int32_t *idx_out, float *dist_out, float *xx_scratch, hipStream_t st);  // knn_mfma.hip
 
@@ -130,7 +132,15 @@ extern "C" int fsg_knn_dense_f32(const float *x, int B, int N, int64_t stride_b,
     if (flags & FSG_KNN_FORCE_MFMA) {  // the first matrix-core design (per-lane filter + sorting network), kept for tests
         const int rc = fsg_knn_mfma_launch(x, B, N, stride_b, stride_c, c_knn, k, flags, idx_out, dist_out, xx_scratch, st);
         if (rc != FSG_ERR_UNSUPPORTED) return rc;
-    } else if (!(flags & FSG_KNN_FORCE_ROWS)) {  // production path
+    } else if (!(flags & FSG_KNN_FORCE_ROWS)) {  // production paths
+        // The wave-specialised pipeline (knn_pipe.hip: MFMA producer waves + selection consumer waves over a double-buffered
+        // LDS block) was MEASURED SLOWER than the two-phase kernel (C=3: 85 vs 65 us, C=64: 147 vs 136 us): the selection is
+        // VALU-throughput-bound (~1000 vector ops per query and chunk), so overlapping it with the MFMA phase buys nothing
+        // while 512-candidate chunks double the number of selection passes.  Opt-in (flag 4096) for tests/experiments.
+        if (flags & 4096) {
+            const int rc = fsg_knn_pipe_launch(x, B, N, stride_b, stride_c, c_knn, k, flags, idx_out, dist_out, xx_scratch, st);
+            if (rc != FSG_ERR_UNSUPPORTED) return rc;
+        }
         const int rc = fsg_knn_rows_mfma_launch(x, B, N, stride_b, stride_c, c_knn, k, flags, idx_out, dist_out, xx_scratch, st);
         if (rc != FSG_ERR_UNSUPPORTED) return rc;
     }

@@ -54,7 +54,8 @@ def test_knn_mfma_kernel_equals_rows_kernel_at_full_size(fsg, device, B, C, Np, 
     x = G(cloud(5000 + Np + C, B, C, Np), device)
     r = fsg.functional.knn_graph(x, k, c_knn=c_knn, fix_diag=fix, drop_first=drop, return_dist=True,
                                  force_rows_kernel=True)
-    for dbg in (0, 2048, 8):  # production kernel, its 1024-candidate-chunk variant, first matrix-core design (knn_mfma.hip)
+    # two-phase kernel (production), its 512-candidate-chunk variant, wave-specialised pipeline (4096), first MFMA design (8)
+    for dbg in (0, 2048, 4096, 8):
         a = fsg.functional.knn_graph(x, k, c_knn=c_knn, fix_diag=fix, drop_first=drop, return_dist=True, _debug_flags=dbg)
         assert torch.equal(a[0], r[0]), dbg
         assert torch.equal(a[1].view(torch.int32), r[1].view(torch.int32)), dbg
