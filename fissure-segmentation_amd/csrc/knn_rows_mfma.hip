@@ -163,11 +163,17 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
             for (int s = 0; s < KS; ++s) bv[s] = bn[s];
             const float xc = xn;
             if (PREFETCH && t + WAVES < ntile) load_tile(t + WAVES);
+            // two independent accumulator chains (the two 16-query blocks) interleaved: a dependent 16x16x4 MFMA issues
+            // every 40 cycles, two alternating chains keep the pipe at its 32-cycle rate
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[0][s], bv[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[1][s], bv[s], acc1, 0, 0, 0);
+            }
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[blk][s], bv[s], acc, 0, 0, 0);
+                const f32x4 acc = blk ? acc1 : acc0;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int qr = blk * 16 + l4 * 4 + e;
@@ -212,31 +218,34 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
                     f2 = fminf(f2, hi);
                 }
                 const unsigned m1 = f2o(f1), m2 = f2o(f2);
-                // upper bound of the K-th smallest of the 128 lane minima: binary search on the top 20 key bits (two
-                // wave-wide compares + population counts per round), the 12 low bits are rounded up
+                // upper bound of the K-th smallest of the 128 lane minima: binary search on the top 16 key bits (two
+                // wave-wide compares + population counts per round), the 16 low bits are rounded up
                 unsigned prefix = 0u;
 #pragma unroll 4
-                for (int bit = 31; bit >= 12; --bit) {
+                for (int bit = 31; bit >= 16; --bit) {   // sign, exponent and 7 mantissa bits: the bound is within 0.8 %
                     const unsigned t = prefix | ((1u << bit) - 1u);
                     const int c = __popcll(__ballot(m1 <= t)) + __popcll(__ballot(m2 <= t));
                     if (c < KK) prefix |= 1u << bit;
                 }
-                tau = prefix | 0xFFFu;
+                tau = prefix | 0xFFFFu;
             }
             const float tau_f = tau >= 0xFF800000u ? INFINITY : o2f(tau);   // keys above +inf are NaN patterns
-            // compact the survivors behind the carried list: one ballot + mbcnt per value slot
+            // compact the survivors behind the carried list: per-lane count, wave prefix sum, per-lane stores
             if (lane < cc) sv[lane] = carry[qi * CK + lane];
-            int total = cc;
+            int mine = 0;
 #pragma unroll
             for (int e = 0; e < VPL; ++e) {
                 const int j = c0 + (e >> 2) * 256 + 4 * lane + (e & 3);
-                const bool pass = v[e] <= tau_f && j < N;
-                const u64 mask = __ballot(pass);
-                if (mask) {
-                    const int pos = total + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                           __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                    if (pass && pos < SURV) sv[pos] = ((u64)f2o(v[e]) << 32) | (unsigned)j;
-                    total += __popcll(mask);
+                mine += (v[e] <= tau_f && j < N) ? 1 : 0;
+            }
+            const int incl = wave_incl_scan(mine, lane);
+            const int total = cc + __shfl(incl, 63);
+            if (total <= SURV) {
+                int pos = cc + incl - mine;
+#pragma unroll
+                for (int e = 0; e < VPL; ++e) {
+                    const int j = c0 + (e >> 2) * 256 + 4 * lane + (e & 3);
+                    if (v[e] <= tau_f && j < N) sv[pos++] = ((u64)f2o(v[e]) << 32) | (unsigned)j;
                 }
             }
             if (total <= SURV) {
@@ -244,16 +253,23 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
                 // rank by counting: every lane holds up to two survivors and counts how many of the `total` entries are
                 // smaller (entries are distinct: the index is part of the key); rank < K goes to slot `rank`
                 const u64 e0 = lane < total ? sv[lane] : ~0ull;
-                const u64 e1 = (SURV > 64 && (64 + lane) < total) ? sv[(64 + lane) % SURV] : ~0ull;
-                int r0 = 0, r1 = 0;
+                int r0 = 0;
+                if (SURV <= 64 || total <= 64) {   // the usual case: one survivor per lane
 #pragma unroll 8
-                for (int t = 0; t < total; ++t) {
-                    const u64 xk = sv[t];  // same address in every lane: LDS broadcast
-                    r0 += xk < e0 ? 1 : 0;
-                    r1 += xk < e1 ? 1 : 0;
+                    for (int t = 0; t < total; ++t) r0 += sv[t] < e0 ? 1 : 0;   // same address in every lane: LDS broadcast
+                    if (lane < total && r0 < KK) carry[qi * CK + r0] = e0;
+                } else {
+                    const u64 e1 = (64 + lane) < total ? sv[(64 + lane) % SURV] : ~0ull;
+                    int r1 = 0;
+#pragma unroll 8
+                    for (int t = 0; t < total; ++t) {
+                        const u64 xk = sv[t];
+                        r0 += xk < e0 ? 1 : 0;
+                        r1 += xk < e1 ? 1 : 0;
+                    }
+                    if (lane < total && r0 < KK) carry[qi * CK + r0] = e0;
+                    if ((64 + lane) < total && r1 < KK) carry[qi * CK + r1] = e1;
                 }
-                if (lane < total && r0 < KK) carry[qi * CK + r0] = e0;
-                if (SURV > 64 && (64 + lane) < total && r1 < KK) carry[qi * CK + r1] = e1;
                 __builtin_amdgcn_wave_barrier();
             } else {
                 // slow exact path (massive ties): KK rounds of wave arg-min over the 16 row values + carried entry
