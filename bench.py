@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 
 import fissure_segmentation_amd as fsg  # noqa: E402
 from fissure_segmentation_amd import _lib, distributed as D  # noqa: E402
+from fissure_segmentation_amd.losses.nnu_loss import NNULoss  # noqa: E402
 from fissure_segmentation_amd.models.dgcnn import DGCNNSeg  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
@@ -68,10 +69,11 @@ def cpu_baseline(B, N, k, classes, steps=2):
     net = ref_cpu.DGCNNSeg(k=k, in_features=3, num_classes=classes).train()
     opt = torch.optim.Adam(net.parameters(), lr=1e-3)
     x, y = synthetic_batch(B, N, classes, 1234, "cpu")
+    crit = ref_cpu.NNULoss(torch.tensor([0.4, 1.2, 1.2, 1.2][:classes]))
 
     def step():
         opt.zero_grad()
-        F.cross_entropy(net(x), y).backward()
+        crit(net(x), y)[0].backward()
         opt.step()
     step()
     t0 = time.perf_counter()
@@ -80,7 +82,7 @@ def cpu_baseline(B, N, k, classes, steps=2):
     dt = (time.perf_counter() - t0) / steps
     return {"value": B * N / dt, "unit": "points/s", "cores": cores, "kind": "port",
             "sample": f"{steps} steps of the same workload (B={B}, N={N}, k={k}) after 1 warm-up, "
-                      f"oracle/ref_cpu.DGCNNSeg fwd+CE+bwd+Adam, {dt:.2f} s/step"}
+                      f"oracle/ref_cpu.DGCNNSeg fwd+CE+GDL+bwd+Adam, {dt:.2f} s/step"}
 
 
 def main():
@@ -114,10 +116,13 @@ def main():
     # fused=True: one multi-tensor kernel for the whole model (the foreach/capturable path issues ~65 tiny kernels)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=use_graph, fused=True)
     x, y = synthetic_batch(B, N, classes, 1234 + rank, device)
+    # the criterion train.py:38 builds by default (--loss nnunet, cli_args.py:16-17): class-weighted cross-entropy +
+    # generalised Dice, here on the fused HIP loss kernel; weights as ds.get_class_weights() would hand over (train.py:34)
+    criterion = NNULoss(torch.tensor([0.4, 1.2, 1.2, 1.2][:classes])).to(device)
 
     def fwd_bwd():
         averager.zero_grad()
-        loss = F.cross_entropy(net(x), y)
+        loss, _parts = criterion(net(x), y)
         loss.backward()
         return loss
 

@@ -24,7 +24,7 @@ def install_reference_aliases():
         "models.access_models": ".models.access_models",
         "models.pointtransformer.pointops": ".models.pointtransformer.pointops",
         "models.pointtransformer.seg_model": ".models.pointtransformer.seg_model",
-        "losses.chamfer_loss": ".losses.chamfer_loss",
+        "losses.chamfer_loss": ".losses.chamfer_loss", "losses.nnu_loss": ".losses.nnu_loss",
     }
     for ref_name, ours in pairs.items():
         sys.modules[ref_name] = importlib.import_module(ours, __name__)

@@ -498,6 +498,55 @@ def chamfer_nn(x, y):
     return _ChamferNN.apply(x, y)
 
 
+# ------------------------------------------------------------------ segmentation loss (losses/nnu_loss.py:6-19)
+class _NNULoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, class_weights, w_ce, w_dice, smooth):
+        B, C, N = logits.shape
+        dev = logits.device
+        vals = torch.empty(4, dtype=torch.float32, device=dev)
+        need_grad = ctx.needs_input_grad[0]
+        grad = torch.empty_like(logits) if need_grad else None      # keeps the (possibly point-major) strides
+        if grad is not None and grad.stride() != logits.stride():
+            grad = torch.empty_strided(logits.shape, logits.stride(), dtype=torch.float32, device=dev)
+        ws = torch.empty(_lib.lib.fsg_nnu_loss_workspace_bytes(C) // 8, dtype=torch.float64, device=dev)
+        gs = grad.stride() if grad is not None else (0, 0, 0)
+        with torch.cuda.device(dev):
+            _lib.call("fsg_nnu_loss_f32", _p(logits), logits.stride(0), logits.stride(1), logits.stride(2), _p(target),
+                      _p(class_weights) if class_weights is not None else None, B, C, N, float(w_ce), float(w_dice),
+                      float(smooth), _p(vals), _p(grad) if grad is not None else None, gs[0], gs[1], gs[2], _p(ws),
+                      _stream())
+        ctx.grad = grad
+        total, ce, gdl = vals[0], vals[1], vals[2]
+        ctx.mark_non_differentiable(ce, gdl)
+        return total, ce, gdl
+
+    @staticmethod
+    def backward(ctx, g, _gce, _ggdl):
+        grad, ctx.grad = ctx.grad, None
+        return grad * g, None, None, None, None, None
+
+
+def nnu_loss(logits, target, class_weights=None, w_ce=1.0, w_dice=1.0, smooth=1.0):
+    """CrossEntropyLoss(class_weights) + generalised Dice (softmax, batch_dice) of logits (B,C,N) against labels (B,N).
+
+    Returns 0-d tensors (w_ce*ce + w_dice*gdl, ce, gdl); the first is differentiable in `logits` (any strides), the
+    other two are for logging.  The gradient is produced by the same two launches that evaluate the loss."""
+    _need_gpu(logits, target)
+    if logits.dim() != 3 or target.shape != (logits.shape[0], logits.shape[2]):
+        raise ValueError(f"expected logits (B,C,N) and labels (B,N), got {tuple(logits.shape)} and {tuple(target.shape)}")
+    if not 2 <= logits.shape[1] <= 32:
+        raise ValueError(f"number of classes must be in [2, 32], got {logits.shape[1]}")
+    if logits.dtype != torch.float32:
+        logits = logits.float()
+    target = target.to(torch.int64).contiguous()
+    if class_weights is not None:
+        if class_weights.numel() != logits.shape[1]:
+            raise ValueError("class_weights must have one entry per class")
+        class_weights = _f32c(class_weights.to(logits.device))
+    return _NNULoss.apply(logits, target, class_weights, w_ce, w_dice, smooth)
+
+
 # ------------------------------------------------------------------ packed clouds (pointops.py)
 def knn_segment(nsample, xyz, new_xyz, offset, new_offset):
     """-> idx (m,nsample) int32, dist2 (m,nsample) squared distances."""

@@ -170,6 +170,22 @@ int fsg_chamfer_nn_bwd_f32(const float *x, const float *y, const int32_t *arg, c
                            int B, int N, int M, float *grad_x, float *grad_y, fsg_stream_t stream);
 
 /*
+ * Segmentation loss, value and gradient: replaces losses/nnu_loss.py:6-19, i.e.
+ * nn.CrossEntropyLoss(class_weights) + GDL(softmax over dim 1, batch_dice=True, do_bg=True, smooth=1, weights 1/volume)
+ * of losses/dice_loss.py:24-96 (the criterion train.py:38 builds for the default --loss nnunet).
+ *   logits (B,C,N) fp32 with element strides (stride_b, stride_c, stride_n) -- class-major or point-major alike;
+ *   labels (B,N) int64 contiguous, values in [0,C); class_weights (C) fp32 or NULL (= all ones); 2 <= C <= 32
+ *   loss_out[4] = { w_ce*ce + w_dice*gdl, ce, gdl, number of labels outside [0,C) (those points are skipped) }
+ *   grad (nullable) = d loss_out[0] / d logits, written with its own element strides
+ *   workspace: fsg_nnu_loss_workspace_bytes(C) bytes, 8-byte aligned.  Reproducible: no atomics, fixed reduction order.
+ */
+size_t fsg_nnu_loss_workspace_bytes(int C);
+int fsg_nnu_loss_f32(const float *logits, int64_t stride_b, int64_t stride_c, int64_t stride_n,
+                     const int64_t *labels, const float *class_weights, int B, int C, int N, float w_ce,
+                     float w_dice, float smooth, float *loss_out, float *grad, int64_t gstride_b,
+                     int64_t gstride_c, int64_t gstride_n, void *workspace, fsg_stream_t stream);
+
+/*
  * Packed-segment kNN query: replaces pointops_cuda.knnquery_cuda behind
  * models/pointtransformer/pointops.py:42-62.
  *   xyz (n,3), new_xyz (m,3) fp32; offset / new_offset (b) int32 cumulative segment ends

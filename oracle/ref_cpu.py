@@ -537,3 +537,44 @@ class PointTransformerCompatibility(nn.Module):
         off = (torch.arange(B, dtype=torch.int32) + 1) * N
         out = self.point_transformer([flat[:, :3].contiguous(), flat[:, 3:].contiguous(), off])
         return out.reshape(B, N, -1).transpose(1, 2)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# segmentation loss (losses/nnu_loss.py:6-19; losses/dice_loss.py:24-96, 99-152)
+
+def nnu_loss(logits, labels, class_weights=None, smooth=1.0):
+    """CE(class_weights) + generalised Dice on softmax probabilities with batch_dice=True, do_bg=True, weights 1/volume.
+
+    logits (B,C,N) float, labels (B,N) int64.  Returns (total, ce, gdl) as 0-d tensors, differentiable in `logits`.
+    Restated from the closed form: per class c over all B*N points, tp_c = sum p_c [y=c], fp_c = sum p_c - tp_c,
+    fn_c = count_c - tp_c, vol_c = count_c + 1e-6; tp, fp, fn = sum_c (.)/vol_c; dice = (2tp+s)/(2tp+fp+fn+s)."""
+    B, C, N = logits.shape
+    logp = torch.log_softmax(logits, dim=1)
+    w = torch.ones(C, dtype=logits.dtype) if class_weights is None else class_weights.to(logits.dtype)
+    picked = logp.gather(1, labels[:, None, :])[:, 0]                       # (B,N)
+    wy = w[labels]
+    ce = -(wy * picked).sum() / wy.sum()                                    # weighted mean of nn.CrossEntropyLoss
+    p = logp.exp()
+    onehot = torch.zeros_like(p).scatter_(1, labels[:, None, :], 1.0)
+    tp_c = (p * onehot).sum((0, 2))
+    sp_c = p.sum((0, 2))
+    cnt_c = onehot.sum((0, 2))
+    vol = cnt_c + 1e-6
+    tp = (tp_c / vol).sum()
+    fp = ((sp_c - tp_c) / vol).sum()
+    fn = ((cnt_c - tp_c) / vol).sum()
+    gdl = -(2 * tp + smooth) / (2 * tp + fp + fn + smooth)
+    return ce + gdl, ce, gdl
+
+
+class NNULoss(nn.Module):
+    """losses/nnu_loss.py:6-19.  `w_dice` / `w_ce` are stored and, as in the reference, not applied."""
+
+    def __init__(self, class_weights, w_dice=1, w_ce=1):
+        super().__init__()
+        self.w_dice, self.w_ce = w_dice, w_ce
+        self.class_weights = class_weights
+
+    def forward(self, prediction, target):
+        total, ce, gdl = nnu_loss(prediction, target, self.class_weights)
+        return total, {"CE": ce, "GDL": gdl}

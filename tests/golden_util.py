@@ -48,5 +48,15 @@ def cloud(seed, B, C, N):
     return x
 
 
+def seg_loss_case(seed, B, C, N, weighted, drop_class=False):
+    """logits (B,C,N) ~ 2*N(0,1), labels (B,N) int64, class weights (C,) or None; `drop_class` leaves the last class
+    without any point (its volume term is then 1/1e-6, losses/dice_loss.py:71)."""
+    rng = np.random.default_rng(seed)
+    logits = (2.0 * rng.standard_normal((B, C, N))).astype(np.float32)
+    labels = rng.integers(0, C - 1 if drop_class else C, (B, N)).astype(np.int64)
+    w = (0.5 + rng.random(C)).astype(np.float32) if weighted else None
+    return logits, labels, w
+
+
 def load(name):
     return np.load(os.path.join(GOLDEN_DIR, name + ".npz"))

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import GOLDEN_DIR, cloud, fill_state_dict, load
+from golden_util import GOLDEN_DIR, cloud, fill_state_dict, load, seg_loss_case
 from knn_check import assert_knn_equal
 from oracle import c_api, ref_cpu
 
@@ -198,6 +198,60 @@ def test_chamfer_loss_vs_golden(fsg, device):
     assert abs(l2.item() - float(g["loss"])) <= 1e-5 * float(g["loss"])
     with pytest.raises(AssertionError):
         ChamferLoss()(G(a, device), G(b[:1], device))
+
+
+# --------------------------------------------------------------------------- segmentation loss
+def _nnu_case(g, row):
+    seed, B, C, Np, wt = (int(v) for v in row)
+    lg, lb, w = seg_loss_case(seed, B, C, Np, bool(wt), drop_class=(seed == 305))
+    return seed, lg, lb, w
+
+
+@pytest.mark.parametrize("layout", ["class_major", "point_major"])
+def test_nnu_loss_vs_golden(fsg, device, layout):
+    """fused CE + generalised Dice (value and gradient) against the reference's own outputs (tests/golden/nnu_loss.npz,
+    made by oracle/make_golden_losses.py from losses/nnu_loss.py) -- fp32, tolerance 1e-4 relative (north star)."""
+    from fissure_segmentation_amd.losses.nnu_loss import NNULoss
+    g = load("nnu_loss")
+    for row in g["cases"]:
+        seed, lg, lb, w = _nnu_case(g, row)
+        x = G(lg, device)
+        if layout == "point_major":
+            x = x.transpose(1, 2).contiguous().transpose(1, 2)      # (B,C,N) view of (B,N,C) memory
+        x.requires_grad_(True)
+        crit = NNULoss(None if w is None else torch.from_numpy(w)).to(device)
+        total, parts = crit(x, G(lb, device))
+        total.backward()
+        for got, key in [(total, "total"), (parts["CE"], "ce"), (parts["GDL"], "gdl")]:
+            ref = float(g[f"s{seed}_{key}"])
+            assert abs(got.item() - ref) <= 1e-4 * max(abs(ref), 1e-3), (seed, key, got.item(), ref)
+        gr = g[f"s{seed}_grad"]
+        assert x.grad.stride() == x.stride()
+        assert np.abs(N(x.grad) - gr).max() <= 1e-4 * np.abs(gr).max(), seed
+
+
+def test_nnu_loss_vs_oracle_full_size(fsg, device):
+    """BASELINE config 2 shape (8 x 4 x 2048) and a 6-class, ragged one against the CPU restatement in fp64; the result
+    must be reproducible bit for bit (no atomics) and scale with the incoming gradient."""
+    from oracle import ref_cpu
+    for seed, B, C, Np in [(311, 8, 4, 2048), (312, 3, 6, 1000), (313, 2, 17, 130), (314, 1, 32, 70)]:
+        lg, lb, w = seg_loss_case(seed, B, C, Np, True)
+        xr = torch.from_numpy(lg).double().requires_grad_(True)
+        tr, cr, gr = ref_cpu.nnu_loss(xr, torch.from_numpy(lb), torch.from_numpy(w).double())
+        (3.0 * tr).backward()
+        x = G(lg, device).requires_grad_(True)
+        t, c, gd = fsg.functional.nnu_loss(x, G(lb, device), G(w, device))
+        (3.0 * t).backward()
+        for got, ref in [(t, tr), (c, cr), (gd, gr)]:
+            assert abs(got.item() - ref.item()) <= 1e-5 * max(abs(ref.item()), 1e-3)
+        ref_g = xr.grad.numpy()
+        assert np.abs(N(x.grad) - ref_g).max() <= 1e-4 * np.abs(ref_g).max()
+        x2 = G(lg, device).requires_grad_(True)
+        t2, _, _ = fsg.functional.nnu_loss(x2, G(lb, device), G(w, device))
+        (3.0 * t2).backward()
+        assert torch.equal(t, t2) and torch.equal(x.grad, x2.grad)
+    with pytest.raises(ValueError):
+        fsg.functional.nnu_loss(G(lg, device), G(lb[:, :5], device))
 
 
 # --------------------------------------------------------------------------- packed-cloud primitives

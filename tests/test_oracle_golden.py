@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import GOLDEN_DIR, cloud, fill_state_dict, load
+from golden_util import GOLDEN_DIR, cloud, fill_state_dict, load, seg_loss_case
 from knn_check import assert_knn_equal
 from oracle import c_api, ref_cpu
 
@@ -139,3 +139,20 @@ def test_chamfer_restatement():
     d2, _ = c_api.chamfer_nn(b, a)
     assert abs(d1.mean(1).mean() + d2.mean(1).mean() - float(g["loss"])) <= 1e-5 * float(g["loss"])
     assert abs(ref_cpu.chamfer(T(a).transpose(1, 2), T(b).transpose(1, 2)).item() - float(g["loss"])) < 1e-5
+
+
+def test_nnu_loss_restatement():
+    """oracle/ref_cpu.nnu_loss against the reference's NNULoss outputs (losses/nnu_loss.py, losses/dice_loss.py)."""
+    g = load("nnu_loss")
+    for seed, B, C, N, wt in g["cases"]:
+        seed = int(seed)
+        lg, lb, w = seg_loss_case(seed, int(B), int(C), int(N), bool(wt), drop_class=(seed == 305))
+        x = T(lg).requires_grad_(True)
+        crit = ref_cpu.NNULoss(None if w is None else T(w))
+        total, parts = crit(x, T(lb))
+        total.backward()
+        assert abs(total.item() - float(g[f"s{seed}_total"])) < 2e-6
+        assert abs(parts["CE"].item() - float(g[f"s{seed}_ce"])) < 2e-6
+        assert abs(parts["GDL"].item() - float(g[f"s{seed}_gdl"])) < 2e-6
+        gr = g[f"s{seed}_grad"]
+        assert np.abs(x.grad.numpy() - gr).max() <= 1e-5 * np.abs(gr).max()
