@@ -136,6 +136,52 @@ class _EdgeWeights(torch.autograd.Function):
         return torch.cat([g[:Co] - g[Co:], g[Co:]], dim=1)
 
 
+# ------------------------------------------------------------------ BatchNorm call counters
+import contextlib as _contextlib
+
+_deferred_counters = None
+
+
+def bump_bn_counter(bn):
+    """`num_batches_tracked += 1` as torch's BatchNorm does on every training call; returns the momentum of this call.
+    Inside `deferred_bn_counters()` the increments of a whole forward are issued as ONE multi-tensor add instead of one
+    tiny kernel per BatchNorm (8 per DGCNN-seg step)."""
+    if bn.momentum is None:                       # cumulative average: the value is needed now
+        bn.num_batches_tracked.add_(1)
+        return 1.0 / float(bn.num_batches_tracked)
+    if _deferred_counters is not None:
+        _deferred_counters.append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked.add_(1)
+    return bn.momentum
+
+
+@_contextlib.contextmanager
+def deferred_bn_counters():
+    global _deferred_counters
+    if _deferred_counters is not None:            # nested: the outermost context flushes
+        yield
+        return
+    _deferred_counters = []
+    try:
+        yield
+    finally:
+        pending, _deferred_counters = _deferred_counters, None
+        if pending:
+            torch._foreach_add_(pending, 1)
+
+
+def with_deferred_bn_counters(forward):
+    """decorator for a top-level model forward"""
+    import functools
+
+    @functools.wraps(forward)
+    def wrapped(*args, **kwargs):
+        with deferred_bn_counters():
+            return forward(*args, **kwargs)
+    return wrapped
+
+
 # ------------------------------------------------------------------ fused EdgeConv (models/dgcnn.py:234-241)
 import os as _os
 
@@ -263,8 +309,7 @@ def edgeconv1(x, idx, conv_weight, bn, slope, x_pm=None, both=False):
     training = bn.training or bn.running_mean is None
     momentum = 0.0
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-        momentum = (1.0 / float(bn.num_batches_tracked)) if bn.momentum is None else bn.momentum
+        momentum = bump_bn_counter(bn)
     track = training and bn.track_running_stats
     if idx.dtype != torch.int32:
         idx = idx.to(torch.int32)
@@ -337,8 +382,7 @@ def _bn_step(bn):
     training = bn.training or bn.running_mean is None
     momentum = 0.0
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-        momentum = (1.0 / float(bn.num_batches_tracked)) if bn.momentum is None else bn.momentum
+        momentum = bump_bn_counter(bn)
     return training, float(momentum)
 
 

@@ -213,6 +213,7 @@ class DGCNNSeg(DGCNNBase):
                                           SharedFullyConnected(128, self.num_classes, dim=1, last_layer=True))
         self.init_weights()
 
+    @F_hip.with_deferred_bn_counters
     def forward(self, x):
         x = super().forward(x)
         B, _, N = x.shape
@@ -255,6 +256,7 @@ class DGCNNReg(DGCNNBase):
                                         SharedFullyConnected(256, self.num_classes, dim=1, last_layer=True))
         self.init_weights()
 
+    @F_hip.with_deferred_bn_counters
     def forward(self, x):
         x = super().forward(x)
         feats = []

@@ -180,6 +180,7 @@ class DGCNNFoldingNet(LoadableModel):
         else:
             self.decoder = FoldingDecoder(n_embedding, shape_type, m, decode_mesh)
 
+    @F_hip.with_deferred_bn_counters
     def forward(self, x, return_hidden=False):
         h = self.encoder(x)
         out = self.decoder(h)

@@ -4,6 +4,7 @@ no HIP kernel on this model; it runs wherever its tensors live."""
 import torch
 from torch import nn
 
+from .. import functional as F_hip
 from ..norm import BatchNorm1d
 from ..utils.model_utils import init_weights
 from .point_seg_net import PointSegmentationModelBase
@@ -44,6 +45,7 @@ class PointNetSeg(PointSegmentationModelBase):
                                         nn.Conv1d(64, num_classes, 1, bias=True))
         self.init_weights()
 
+    @F_hip.with_deferred_bn_counters
     def forward(self, x):
         local = self.local_features(x)
         glob = self.global_features(local)

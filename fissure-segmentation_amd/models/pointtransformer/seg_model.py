@@ -199,6 +199,7 @@ class PointTransformerCompatibility(PointSegmentationModelBase):
         super().__init__(in_features, num_classes)
         self.point_transformer = pointtransformer_seg_repro(c=in_features, k=num_classes)
 
+    @F_hip.with_deferred_bn_counters
     def forward(self, x):
         bs, n_feat, npts = x.shape
         flat = x.transpose(1, 2).reshape(-1, n_feat)

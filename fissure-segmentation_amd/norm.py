@@ -10,9 +10,8 @@ def _forward(self, x):
     self._check_input_dim(x)
     momentum = 0.0 if self.momentum is None else self.momentum
     if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-        self.num_batches_tracked.add_(1)
-        if self.momentum is None:  # cumulative moving average
-            momentum = 1.0 / float(self.num_batches_tracked)
+        from .functional import bump_bn_counter       # one multi-tensor add per forward inside deferred_bn_counters()
+        momentum = bump_bn_counter(self)
     use_batch_stats = self.training or (self.running_mean is None and self.running_var is None)
     keep = not self.training or self.track_running_stats
     return torch.native_batch_norm(x, self.weight, self.bias, self.running_mean if keep else None,
