@@ -42,6 +42,9 @@ SIGNATURES = {
     "fsg_chamfer_nn_bwd_f32": ([_P, _P, _P, _P, _I, _I, _I, _P, _P, _P], _I),
     "fsg_nnu_loss_workspace_bytes": ([_I], ctypes.c_size_t),
     "fsg_nnu_loss_f32": ([_P, _L, _L, _L, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _L, _L, _L, _P, _P], _I),
+    "fsg_pt_attn_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),
+    "fsg_pt_attn_fwd_f32": ([_P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P], _I),
+    "fsg_pt_attn_bwd_f32": ([_P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P], _I),
     "fsg_knn_segment_f32": ([_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P], _I),
     "fsg_fps_f32": ([_P, _P, _P, _I, _I, _P, _P, _P], _I),
     "fsg_group_gather_fwd_f32": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
@@ -71,6 +74,19 @@ def stop_timing():
     rec, _timing = _timing, None
     torch.cuda.synchronize()
     return {name: [s.elapsed_time(e) for s, e in evs] for name, evs in (rec or {}).items()}
+
+
+class PTLayerParams(ctypes.Structure):
+    """include/fsg_hip.h: fsg_pt_layer_params"""
+    _fields_ = [(n, _P) for n in ("lp1_w", "lp1_b", "bnp_g", "bnp_b", "bnp_rm", "bnp_rv", "lp2_w", "lp2_b", "bn1_g", "bn1_b",
+                                  "bn1_rm", "bn1_rv", "lw1_w", "lw1_b", "bn2_g", "bn2_b", "bn2_rm", "bn2_rv", "lw2_w",
+                                  "lw2_b")] + [(n, _F) for n in ("eps_p", "eps_1", "eps_2", "mom_p", "mom_1", "mom_2")]
+
+
+class PTLayerGrads(ctypes.Structure):
+    """include/fsg_hip.h: fsg_pt_layer_grads"""
+    _fields_ = [(n, _P) for n in ("lp1_w", "lp1_b", "bnp_g", "bnp_b", "lp2_w", "lp2_b", "bn1_g", "bn1_b", "lw1_w", "lw1_b",
+                                  "bn2_g", "bn2_b", "lw2_w", "lw2_b")]
 
 
 def call(name, *args):

@@ -683,3 +683,99 @@ def vec_attn(v, pos, w, idx):
     if pos.shape != (v.shape[0], idx.shape[1], v.shape[1]) or w.shape[:2] != pos.shape[:2] or v.shape[1] % w.shape[2]:
         raise ValueError(f"vec_attn: inconsistent shapes v{tuple(v.shape)} pos{tuple(pos.shape)} w{tuple(w.shape)}")
     return _VecAttn.apply(v, pos, w, idx.to(torch.int32).contiguous())
+
+
+# ------------------------------------------------------------------ fused PointTransformerLayer body (seg_model.py:38-53)
+_PT_PARAM_NAMES = ("lp1_w", "lp1_b", "bnp_g", "bnp_b", "lp2_w", "lp2_b", "bn1_g", "bn1_b", "lw1_w", "lw1_b", "bn2_g", "bn2_b",
+                   "lw2_w", "lw2_b")
+
+
+class _PTAttn(torch.autograd.Function):
+    """out = fused(grouping, linear_p, linear_w, softmax, aggregate)(p, idx, qkv; 14 parameters).  Only the (n,ns,c/8)
+    tensors u1 and softmax weights are kept for the backward; gradients: qkv and the 14 parameters."""
+
+    @staticmethod
+    def forward(ctx, p, idx, qkv, bns, *params):
+        n, c3 = qkv.shape
+        c, ns = c3 // 3, idx.shape[1]
+        cs = c // 8
+        dev = qkv.device
+        bnp, bn1, bn2 = bns
+        training = bnp.training or bnp.running_mean is None
+        moms = [0.0, 0.0, 0.0]
+        if training:
+            for i, bn in enumerate(bns):
+                if bn.track_running_stats and bn.num_batches_tracked is not None:
+                    moms[i] = float(bump_bn_counter(bn))
+        prm = _lib.PTLayerParams()
+        for name, t in zip(_PT_PARAM_NAMES, params):
+            setattr(prm, name, t.data_ptr())
+        for tag, bn in (("bnp", bnp), ("bn1", bn1), ("bn2", bn2)):
+            track = training and bn.track_running_stats and bn.running_mean is not None
+            setattr(prm, tag + "_rm", bn.running_mean.data_ptr() if track else None)
+            setattr(prm, tag + "_rv", bn.running_var.data_ptr() if track else None)
+        prm.eps_p, prm.eps_1, prm.eps_2 = bnp.eps, bn1.eps, bn2.eps
+        prm.mom_p, prm.mom_1, prm.mom_2 = moms
+        if training:
+            stats = torch.empty(2 * (3 + c + cs), dtype=torch.float32, device=dev)
+        else:
+            stats = torch.cat([t for bn in bns for t in (bn.running_mean.float(), torch.rsqrt(bn.running_var.float() + bn.eps))])
+        out = torch.empty(n, c, dtype=torch.float32, device=dev)
+        u1 = torch.empty(n, ns, cs, dtype=torch.float32, device=dev)
+        sm = torch.empty(n, ns, cs, dtype=torch.float32, device=dev)
+        ws = torch.empty(_lib.lib.fsg_pt_attn_workspace_bytes(n, ns, c) // 8 + 1, dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("fsg_pt_attn_fwd_f32", _p(p), _p(idx), _p(qkv), ctypes.c_void_p(qkv.data_ptr() + 4 * c),
+                      ctypes.c_void_p(qkv.data_ptr() + 8 * c), c3, ctypes.byref(prm), n, ns, c, int(training), _p(out),
+                      _p(stats), _p(u1), _p(sm), _p(ws), _stream())
+        ctx.save_for_backward(p, idx, qkv, stats, u1, sm, *params)
+        ctx.meta = (n, ns, c, training, (bnp.eps, bn1.eps, bn2.eps))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        p, idx, qkv, stats, u1, sm, *params = ctx.saved_tensors
+        n, ns, c, training, eps = ctx.meta
+        dev = qkv.device
+        prm = _lib.PTLayerParams()
+        for name, t in zip(_PT_PARAM_NAMES, params):
+            setattr(prm, name, t.data_ptr())
+        prm.eps_p, prm.eps_1, prm.eps_2 = eps
+        sizes = [t.numel() for t in params]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        grads, gstruct, off = [], _lib.PTLayerGrads(), 0
+        for name, t, sz in zip(_PT_PARAM_NAMES, params, sizes):
+            gt = flat[off:off + sz].view(t.shape)
+            setattr(gstruct, name, gt.data_ptr())
+            grads.append(gt)
+            off += sz
+        dqkv = torch.zeros(n, 3 * c, dtype=torch.float32, device=dev)
+        dp = torch.zeros_like(p) if ctx.needs_input_grad[0] else None
+        ws = torch.empty(_lib.lib.fsg_pt_attn_workspace_bytes(n, ns, c) // 8 + 1, dtype=torch.float64, device=dev)
+        g = _f32c(g)
+        with torch.cuda.device(dev):
+            _lib.call("fsg_pt_attn_bwd_f32", _p(p), _p(idx), _p(qkv), ctypes.c_void_p(qkv.data_ptr() + 4 * c),
+                      ctypes.c_void_p(qkv.data_ptr() + 8 * c), 3 * c, ctypes.byref(prm), n, ns, c, int(training), _p(g),
+                      _p(stats), _p(u1), _p(sm), _p(dqkv), ctypes.c_void_p(dqkv.data_ptr() + 4 * c),
+                      ctypes.c_void_p(dqkv.data_ptr() + 8 * c), 3 * c, _p(dp), ctypes.byref(gstruct), _p(ws), _stream())
+        return (dp, None, dqkv, None, *grads)
+
+
+PT_ATTN_PLANES = (32, 64, 128, 256, 512)
+
+
+def pt_attn(p, idx, qkv, linear_p, linear_w):
+    """Fused body of PointTransformerLayer.  p (n,3), idx (n,ns) int32, qkv (n,3c) = [q | k | v] rows;
+    linear_p = Sequential(Linear(3,3), BatchNorm1d(3), ReLU, Linear(3,c)), linear_w = Sequential(BatchNorm1d(c), ReLU,
+    Linear(c,c/8), BatchNorm1d(c/8), ReLU, Linear(c/8,c/8)) -- the reference's module layout (seg_model.py:27-33)."""
+    _need_gpu(p, idx, qkv)
+    c = qkv.shape[1] // 3
+    if c not in PT_ATTN_PLANES or not 1 <= idx.shape[1] <= 16:
+        raise ValueError(f"fused PointTransformer layer supports planes {PT_ATTN_PLANES} and nsample <= 16, got {c}, {idx.shape[1]}")
+    lp1, bnp, _, lp2 = linear_p
+    bn1, _, lw1, bn2, _, lw2 = linear_w
+    params = (lp1.weight, lp1.bias, bnp.weight, bnp.bias, lp2.weight, lp2.bias, bn1.weight, bn1.bias, lw1.weight, lw1.bias,
+              bn2.weight, bn2.bias, lw2.weight, lw2.bias)
+    params = tuple(t if t.is_contiguous() else t.contiguous() for t in params)
+    p = p if p.dtype == torch.float32 and p.is_contiguous() else p.float().contiguous()
+    return _PTAttn.apply(p, idx.to(torch.int32).contiguous(), qkv.contiguous(), (bnp, bn1, bn2), *params)

@@ -42,10 +42,17 @@ class PointTransformerLayer(nn.Module):
         n, ns, c = t.shape
         return bn(t.reshape(n * ns, c)).view(n, ns, c)
 
+    fused = True  # class-wide switch: False composes the layer from the separate grouping / vec_attn ops (tests)
+
     def forward(self, pxo):
         p, x, o = pxo
-        q, k, v = _lin(self.linear_q, x), _lin(self.linear_k, x), _lin(self.linear_v, x)
         idx, _ = pointops.knnquery(self.nsample, p, p, o, o)  # one graph for keys and values
+        if self.fused and self.out_planes in F_hip.PT_ATTN_PLANES and self.nsample <= 16 and self.share_planes == 8:
+            # q, k, v as ONE GEMM, then everything up to the aggregate in the fused HIP layer (no (n,ns,c) tensor in HBM)
+            w_qkv = torch.cat([self.linear_q.weight, self.linear_k.weight, self.linear_v.weight], 0)
+            b_qkv = torch.cat([self.linear_q.bias, self.linear_k.bias, self.linear_v.bias], 0)
+            return F_hip.pt_attn(p, idx, F_hip.linear_pm(x, w_qkv, b_qkv), self.linear_p, self.linear_w)
+        q, k, v = _lin(self.linear_q, x), _lin(self.linear_k, x), _lin(self.linear_v, x)
         rel = pointops.grouping(p, idx) - p.unsqueeze(1)       # (n, ns, 3)
         gk = pointops.grouping(k, idx)                         # (n, ns, c)
         lin1, bn, act, lin2 = self.linear_p

@@ -229,6 +229,54 @@ int fsg_vec_attn_bwd_f32(const float *v, const float *pos, const float *w, const
                          const float *grad_out, float *grad_v, float *grad_pos, float *grad_w, int n,
                          int ns, int c, int cw, fsg_stream_t stream);
 
+/*
+ * Fused PointTransformerLayer body: replaces models/pointtransformer/seg_model.py:38-53 after the three
+ * q/k/v Linears (:37), i.e. neighbour grouping of keys, values and coordinates, linear_p (Linear(3,3) -> BatchNorm1d(3)
+ * -> ReLU -> Linear(3,c)), w = k_j - q_i + p_r, linear_w (BatchNorm1d(c) -> ReLU -> Linear(c,c/8) -> BatchNorm1d(c/8) ->
+ * ReLU -> Linear(c/8,c/8)), softmax over the nsample neighbours and the shared-plane aggregate
+ *     out[i,ch] = sum_s (v[idx[i,s],ch] + p_r[i,s,ch]) * softmax_s(w)[i,s,ch mod c/8]
+ * without any (n,nsample,c) tensor in HBM.  Train-mode BatchNorm statistics run over all n*nsample edges (one pass per
+ * BatchNorm, fp64 sums, fixed order) and update the running buffers with torch's rule (unbiased variance).
+ *   p (n,3) fp32; idx (n,ns) int32 rows of p/q/k/v (every entry valid -- fsg_knn_segment_f32 pads short segments);
+ *   q, k, v (n,c) fp32 with a common row stride ld (in elements: 3c when they are slices of one (n,3c) GEMM output);
+ *   c in {32,64,128,256,512}, 1 <= ns <= 16, share_planes = 8.
+ *   stats [2*(3+c+c/8)] = mean|rstd of the three BatchNorms (written in training, read in eval: the caller fills them
+ *   from the running buffers); u1 (n,ns,c/8) pre-BatchNorm output of the first linear_w Linear and sm (n,ns,c/8) the
+ *   softmax weights are kept for the backward; workspace: fsg_pt_attn_workspace_bytes(n, ns, c), 8-byte aligned.
+ * _bwd: grad_out (n,c) -> grad_q (n,c, row stride ldg) overwritten; grad_k, grad_v ACCUMULATED (caller zero-fills);
+ *   every pointer of `grads` overwritten (same shapes as the parameters); grad_p (n,3) nullable, ACCUMULATED (the
+ *   coordinates are network inputs, seg_model.py:202-231: pass NULL unless the input itself needs a gradient).
+ */
+typedef struct fsg_pt_layer_params {
+    const float *lp1_w, *lp1_b;               /* linear_p.0: (3,3), (3) */
+    const float *bnp_g, *bnp_b;               /* linear_p.1: (3) */
+    float *bnp_rm, *bnp_rv;                   /*   running mean / var, nullable */
+    const float *lp2_w, *lp2_b;               /* linear_p.3: (c,3), (c) */
+    const float *bn1_g, *bn1_b;               /* linear_w.0: (c) */
+    float *bn1_rm, *bn1_rv;
+    const float *lw1_w, *lw1_b;               /* linear_w.2: (c/8,c), (c/8) */
+    const float *bn2_g, *bn2_b;               /* linear_w.3: (c/8) */
+    float *bn2_rm, *bn2_rv;
+    const float *lw2_w, *lw2_b;               /* linear_w.5: (c/8,c/8), (c/8) */
+    float eps_p, eps_1, eps_2;
+    float mom_p, mom_1, mom_2;                /* momentum of this call for the running buffers */
+} fsg_pt_layer_params;
+
+typedef struct fsg_pt_layer_grads {
+    float *lp1_w, *lp1_b, *bnp_g, *bnp_b, *lp2_w, *lp2_b, *bn1_g, *bn1_b, *lw1_w, *lw1_b, *bn2_g, *bn2_b, *lw2_w,
+        *lw2_b;
+} fsg_pt_layer_grads;
+
+size_t fsg_pt_attn_workspace_bytes(int n, int ns, int c);
+int fsg_pt_attn_fwd_f32(const float *p, const int32_t *idx, const float *q, const float *k, const float *v,
+                        int64_t ld, const fsg_pt_layer_params *params, int n, int ns, int c, int training,
+                        float *out, float *stats, float *u1, float *sm, void *workspace, fsg_stream_t stream);
+int fsg_pt_attn_bwd_f32(const float *p, const int32_t *idx, const float *q, const float *k, const float *v,
+                        int64_t ld, const fsg_pt_layer_params *params, int n, int ns, int c, int training,
+                        const float *grad_out, const float *stats, const float *u1, const float *sm,
+                        float *grad_q, float *grad_k, float *grad_v, int64_t ldg, float *grad_p,
+                        const fsg_pt_layer_grads *grads, void *workspace, fsg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -421,6 +421,66 @@ def test_pointtransformer_vs_cpu_restatement(fsg, device):
         assert float((a - b).norm()) <= 3e-2 * float(b.norm()) + 1e-3 * scale, n
 
 
+@pytest.mark.parametrize("c,ns,sizes,train", [(32, 8, (100, 37), True), (64, 16, (61, 40), True), (128, 16, (50, 9), True),
+                                              (256, 16, (33, 17), True), (512, 16, (8, 20), True), (256, 8, (5, 30), True),
+                                              (32, 16, (300, 211), True), (64, 16, (64, 23), False), (512, 8, (12, 9), False)])
+def test_pt_layer_fused_vs_cpu_restatement(fsg, device, c, ns, sizes, train):
+    """Fused PointTransformerLayer (fsg_pt_attn_*: one pass per BatchNorm, MFMA channel contraction, atomics for dk/dv)
+    against the CPU restatement of seg_model.py:17-53 in fp64: output, gradient of the input features and of every
+    parameter, running statistics.  A segment shorter than nsample exercises the padding rule of the packed kNN."""
+    from fissure_segmentation_amd.models.pointtransformer.seg_model import PointTransformerLayer
+    xyz, feat, off = packed(900 + c + ns, sizes, c)
+    ref = fill_state_dict(ref_cpu.PTLayer(c, c, 8, ns), 811 + c).double()
+    lay = PointTransformerLayer(c, c, 8, ns)
+    lay.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    lay = lay.to(device)
+    ref.train(train), lay.train(train)
+    xr = torch.from_numpy(feat).double().requires_grad_(True)
+    pr = torch.from_numpy(xyz).double().requires_grad_(True)
+    yr = ref([pr, xr, torch.from_numpy(off)])
+    gr = np.random.default_rng(5).standard_normal(tuple(yr.shape)).astype(np.float32)
+    yr.backward(torch.from_numpy(gr).double())
+    x = G(feat, device).requires_grad_(True)
+    pg = G(xyz, device).requires_grad_(True)
+    y = lay([pg, x, G(off, device)])
+    y.backward(G(gr, device))
+    assert np.linalg.norm(N(pg.grad) - pr.grad.numpy()) <= 1e-3 * np.linalg.norm(pr.grad.numpy())
+    yr_np = yr.detach().numpy()
+    assert np.abs(N(y) - yr_np).max() <= 1e-4 * max(1.0, np.abs(yr_np).max())
+    rgx = xr.grad.numpy()
+    assert np.linalg.norm(N(x.grad) - rgx) <= 1e-3 * np.linalg.norm(rgx)
+    refp = dict(ref.named_parameters())
+    scale = max(float(q.grad.norm()) for q in refp.values())
+    for name, prm in lay.named_parameters():   # biases in front of a train-mode BatchNorm / the softmax have zero gradient
+        a, b = prm.grad.double().cpu().reshape(-1), refp[name].grad.reshape(-1)
+        assert float((a - b).norm()) <= 1e-3 * float(b.norm()) + 1e-5 * scale, name
+    if train:
+        for name, buf in lay.named_buffers():
+            np.testing.assert_allclose(N(buf.double()), dict(ref.named_buffers())[name].numpy(), rtol=1e-4, atol=1e-6, err_msg=name)
+
+
+def test_pt_layer_fused_vs_unfused_composition(fsg, device):
+    """same layer through the separate grouping / linear / BatchNorm / vec_attn ops (the first HIP path) and fused"""
+    from fissure_segmentation_amd.models.pointtransformer.seg_model import PointTransformerLayer
+    c, ns = 64, 16
+    xyz, feat, off = packed(77, (500, 300, 7), c)
+    a = fill_state_dict(PointTransformerLayer(c, c, 8, ns), 5).to(device).train()
+    b = fill_state_dict(PointTransformerLayer(c, c, 8, ns), 5).to(device).train()
+    b.fused = False
+    outs = []
+    for lay in (a, b):
+        x = G(feat, device).requires_grad_(True)
+        y = lay([G(xyz, device), x, G(off, device)])
+        y.square().sum().backward()
+        outs.append((y, x.grad, lay))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-4, atol=1e-4)
+    assert float((outs[0][1] - outs[1][1]).norm()) <= 1e-3 * float(outs[1][1].norm())
+    pb = dict(b.named_parameters())
+    scale = max(float(q.grad.norm()) for q in pb.values())
+    for name, prm in a.named_parameters():
+        assert float((prm.grad - pb[name].grad).norm()) <= 2e-3 * float(pb[name].grad.norm()) + 1e-4 * scale, name
+
+
 def test_save_load_roundtrip_and_reinstantiate(fsg, device, tmp_path):
     from fissure_segmentation_amd.models.access_models import get_point_seg_model_class
     cls = get_point_seg_model_class("DGCNN")
