@@ -120,18 +120,22 @@ __global__ __launch_bounds__(256) void pt_stats_p_kernel(const float *__restrict
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-// records [R][2][L] (sum | sum of squares) -> mean, rstd (+ running buffers, torch's rule)
-__global__ __launch_bounds__(64) void pt_bn_finalize_kernel(const double *__restrict__ rec, int R, int L, double M,
-                                                            float eps, float mom, float *__restrict__ mean,
-                                                            float *__restrict__ rstd, float *__restrict__ rm,
-                                                            float *__restrict__ rv) {
-    const int l = blockIdx.x * 64 + threadIdx.x;
+// records [R][2][L] (sum | sum of squares) -> mean, rstd (+ running buffers, torch's rule).  One wave per channel:
+// the lanes stride over the records (fixed assignment, fixed shuffle tree -> reproducible).
+__global__ __launch_bounds__(256) void pt_bn_finalize_kernel(const double *__restrict__ rec, int R, int L, double M,
+                                                             float eps, float mom, float *__restrict__ mean,
+                                                             float *__restrict__ rstd, float *__restrict__ rm,
+                                                             float *__restrict__ rv) {
+    const int l = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (l >= L) return;
     double S = 0, SS = 0;
-    for (int r = 0; r < R; ++r) {
+    for (int r = lane; r < R; r += 64) {
         S += rec[(long)r * 2 * L + l];
         SS += rec[(long)r * 2 * L + L + l];
     }
+    S = wave_sum_d(S);
+    SS = wave_sum_d(SS);
+    if (lane != 0) return;
     const double m = S / M;
     double var = SS / M - m * m;
     if (var < 0) var = 0;
@@ -508,7 +512,7 @@ __device__ __forceinline__ void stage_du1(const Prm &P, const Stats &S, const fl
     }
 }
 
-// B2: du1 -> dh1 -> dz1 sums, dWa, dba.  records per (block, point slot): [dWa (cs,c) | dg1 | db1 | dba]
+// B2: du1 -> dh1 -> dz1 sums, dWa, dba.  records per workgroup: [dWa (cs,c) | dg1 | db1 | dba]
 template <int C>
 __global__ __launch_bounds__(Geo<C>::NT) void pt_b2_kernel(const float *__restrict__ p, const int32_t *__restrict__ idx,
                                                            const float *__restrict__ q, const float *__restrict__ k, long ld,
@@ -521,6 +525,7 @@ __global__ __launch_bounds__(Geo<C>::NT) void pt_b2_kernel(const float *__restri
     __shared__ int IDX[G::EMAX];
     __shared__ float T[G::EMAX * 4];
     __shared__ float DU1[G::EMAX * RS];
+    __shared__ float COMB[G::PT > 1 ? (CS + 2) * G::NT : 1];
     const Stats S = split_stats(stats, C);
     const int tid = threadIdx.x, ps = tid / C, ch = tid % C;
     const float w20 = P.lp2_w[3 * ch], w21 = P.lp2_w[3 * ch + 1], w22 = P.lp2_w[3 * ch + 2], b2 = P.lp2_b[ch];
@@ -560,16 +565,32 @@ __global__ __launch_bounds__(Geo<C>::NT) void pt_b2_kernel(const float *__restri
             for (int e = 0; e < E; ++e) dba += DU1[e * RS + tid];
     }
     const int L = CS * C + 2 * C + CS;
-    float *my = rec + ((long)blockIdx.x * G::PT + ps) * L;
+    float *my = rec + (long)blockIdx.x * L;
+    if (G::PT == 1) {
 #pragma unroll
-    for (int o = 0; o < CS; ++o) my[o * C + ch] = dwa[o];
-    my[CS * C + ch] = dg1;
-    my[CS * C + C + ch] = db1;
-    if (ch < CS) my[CS * C + 2 * C + ch] = ps == 0 ? dba : 0.f;   // tid < CS <=> ps == 0 && ch < CS
+        for (int o = 0; o < CS; ++o) my[o * C + ch] = dwa[o];
+        my[CS * C + ch] = dg1;
+        my[CS * C + C + ch] = db1;
+    } else {  // fold the point slots of the workgroup: one record per workgroup
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < CS; ++o) COMB[o * G::NT + tid] = dwa[o];
+        COMB[CS * G::NT + tid] = dg1;
+        COMB[(CS + 1) * G::NT + tid] = db1;
+        __syncthreads();
+        for (int i = tid; i < (CS + 2) * C; i += G::NT) {
+            const int vv = i / C, c2 = i % C;
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < G::PT; ++r) a += COMB[vv * G::NT + r * C + c2];
+            my[i] = a;
+        }
+    }
+    if (tid < CS) my[CS * C + 2 * C + tid] = dba;
 }
 
 // B3: dw0 -> dk (atomics), dq, dW2, db2, dt -> dzp (kept), (dgp, dbp).
-// records per (block, point slot): [dW2 (c,3) | db2 (c) | dgp (3) | dbp (3)]
+// records per workgroup: [dW2 (c,3) | db2 (c) | dgp (3) | dbp (3)]
 template <int C>
 __global__ __launch_bounds__(Geo<C>::NT) void pt_b3_kernel(const float *__restrict__ p, const int32_t *__restrict__ idx,
                                                            const float *__restrict__ q, const float *__restrict__ k, long ld,
@@ -587,6 +608,7 @@ __global__ __launch_bounds__(Geo<C>::NT) void pt_b3_kernel(const float *__restri
     __shared__ float DU1[G::EMAX * RS], SM[G::EMAX * RS];
     __shared__ float REDH[HALVES * 4];
     __shared__ float REDP[G::NT / 64][8];
+    __shared__ float COMB[4 * G::NT];
     const Stats S = split_stats(stats, C);
     const int tid = threadIdx.x, ps = tid / C, ch = tid % C;
     const float w20 = P.lp2_w[3 * ch], w21 = P.lp2_w[3 * ch + 1], w22 = P.lp2_w[3 * ch + 2], b2 = P.lp2_b[ch];
@@ -665,9 +687,17 @@ __global__ __launch_bounds__(Geo<C>::NT) void pt_b3_kernel(const float *__restri
         }
     }
     const int L = 4 * C + 6;
-    float *my = rec + ((long)blockIdx.x * G::PT + ps) * L;
-    my[3 * ch] = dw2[0]; my[3 * ch + 1] = dw2[1]; my[3 * ch + 2] = dw2[2];
-    my[3 * C + ch] = db2a;
+    float *my = rec + (long)blockIdx.x * L;
+    __syncthreads();
+    COMB[tid] = dw2[0]; COMB[G::NT + tid] = dw2[1]; COMB[2 * G::NT + tid] = dw2[2]; COMB[3 * G::NT + tid] = db2a;
+    __syncthreads();
+    for (int i = tid; i < 4 * C; i += G::NT) {
+        const int vv = i / C, c2 = i % C;
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < G::PT; ++r) a += COMB[vv * G::NT + r * C + c2];
+        my[vv < 3 ? 3 * c2 + vv : 3 * C + c2] = a;
+    }
     // (dgp, dbp): block sum of the first EMAX threads' accumulators
     const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
@@ -679,8 +709,7 @@ __global__ __launch_bounds__(Geo<C>::NT) void pt_b3_kernel(const float *__restri
     if (tid < 6) {
         float a = 0.f;
         for (int w = 0; w < G::NT / 64; ++w) a += REDP[w][tid];
-        rec[((long)blockIdx.x * G::PT) * L + 4 * C + tid] = a;                          // slot 0 carries the block's sums
-        for (int r = 1; r < G::PT; ++r) rec[((long)blockIdx.x * G::PT + r) * L + 4 * C + tid] = 0.f;
+        my[4 * C + tid] = a;
     }
 }
 
@@ -739,15 +768,17 @@ struct Segs {
     int count;
 };
 __global__ __launch_bounds__(256) void pt_reduce_kernel(const float *__restrict__ rec, int R, int L, Segs sg) {
-    __shared__ double red[4][64];
-    const int l = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    __shared__ double red[8][32];
+    const int ll = threadIdx.x & 31, sl = threadIdx.x >> 5, l = blockIdx.x * 32 + ll;
     double a = 0;
     if (l < L)
-        for (int r = sl; r < R; r += 4) a += rec[(long)r * L + l];
-    red[sl][threadIdx.x & 63] = a;
+        for (int r = sl; r < R; r += 8) a += rec[(long)r * L + l];
+    red[sl][ll] = a;
     __syncthreads();
     if (sl == 0 && l < L) {
-        const double t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        double t = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[i][ll];
         for (int i = 0; i < sg.count; ++i)
             if (l >= sg.off[i] && l < sg.off[i + 1]) sg.dst[i][l - sg.off[i]] = (float)t;
     }
@@ -771,7 +802,7 @@ struct Work {
 template <int C>
 size_t rec_bytes(int n) {
     typedef Geo<C> G;
-    const size_t g = (size_t)grid_for<C>(n), gp = g * G::PT;
+    const size_t g = (size_t)grid_for<C>(n), gp = g;
     size_t fwd = sizeof(double) * 2 * C * g;
     const size_t p0 = sizeof(double) * 6 * 256;
     if (p0 > fwd) fwd = p0;
@@ -807,16 +838,16 @@ int forward(const float *p, const int32_t *idx, const float *q, const float *k, 
     if (training) {
         const int ge = edge_grid((long)n * ns);
         hipLaunchKernelGGL(pt_stats_p_kernel, dim3(ge), dim3(256), 0, st, p, idx, P, n, ns, w.rec_d);
-        hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3(1), dim3(64), 0, st, w.rec_d, ge, 3, M, P.eps_p, P.mom_p,
+        hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3(1), dim3(256), 0, st, w.rec_d, ge, 3, M, P.eps_p, P.mom_p,
                            (float *)S.mp, (float *)S.rp, P.bnp_rm, P.bnp_rv);
         hipLaunchKernelGGL(pt_stats_w_kernel<C>, dim3(g), dim3(G::NT), 0, st, p, idx, q, k, ld, P, stats, n, ns, w.rec_d);
-        hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3(fsg_cdiv(C, 64)), dim3(64), 0, st, w.rec_d, g, C, M, P.eps_1, P.mom_1,
+        hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3(C / 4), dim3(256), 0, st, w.rec_d, g, C, M, P.eps_1, P.mom_1,
                            (float *)S.m1, (float *)S.r1, P.bn1_rm, P.bn1_rv);
     }
     hipLaunchKernelGGL(pt_u1_kernel<C>, dim3(g), dim3(G::NT), u1_lds_bytes<C>(), st, p, idx, q, k, ld, P, stats, n, ns, u1,
                        training ? w.rec_d : (double *)nullptr);
     if (training)
-        hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3(1), dim3(64), 0, st, w.rec_d, g, G::CS, M, P.eps_2, P.mom_2,
+        hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3(fsg_cdiv(G::CS, 4)), dim3(256), 0, st, w.rec_d, g, G::CS, M, P.eps_2, P.mom_2,
                            (float *)S.m2, (float *)S.r2, P.bn2_rm, P.bn2_rv);
     hipLaunchKernelGGL(pt_out_kernel<C>, dim3(g), dim3(G::NT), 0, st, p, idx, v, ld, P, stats, n, ns, u1, sm, out);
     return 0;
@@ -838,7 +869,7 @@ int backward(const float *p, const int32_t *idx, const float *q, const float *k,
     {
         const int L = CS * CS + 3 * CS;
         Segs sg = {{0, CS * CS, CS * CS + CS, CS * CS + 2 * CS, L}, {G_.lw2_w, G_.lw2_b, G_.bn2_g, G_.bn2_b}, 4};
-        hipLaunchKernelGGL(pt_reduce_kernel, dim3(fsg_cdiv(L, 64)), dim3(256), 0, st, rec, gr, L, sg);
+        hipLaunchKernelGGL(pt_reduce_kernel, dim3(fsg_cdiv(L, 32)), dim3(256), 0, st, rec, gr, L, sg);
     }
     // B2
     hipLaunchKernelGGL(pt_b2_kernel<C>, dim3(gr), dim3(G::NT), 0, st, p, idx, q, k, ld, P, stats, n, ns, u1, w.dz2, G_.bn2_g,
@@ -846,7 +877,7 @@ int backward(const float *p, const int32_t *idx, const float *q, const float *k,
     {
         const int L = CS * C + 2 * C + CS;
         Segs sg = {{0, CS * C, CS * C + C, CS * C + 2 * C, L}, {G_.lw1_w, G_.bn1_g, G_.bn1_b, G_.lw1_b}, 4};
-        hipLaunchKernelGGL(pt_reduce_kernel, dim3(fsg_cdiv(L, 64)), dim3(256), 0, st, rec, gr * G::PT, L, sg);
+        hipLaunchKernelGGL(pt_reduce_kernel, dim3(fsg_cdiv(L, 32)), dim3(256), 0, st, rec, gr, L, sg);
     }
     // B3
     hipLaunchKernelGGL(pt_b3_kernel<C>, dim3(gr), dim3(G::NT), 0, st, p, idx, q, k, ld, P, stats, n, ns, g, u1, sm, w.dz2,
@@ -854,7 +885,7 @@ int backward(const float *p, const int32_t *idx, const float *q, const float *k,
     {
         const int L = 4 * C + 6;
         Segs sg = {{0, 3 * C, 4 * C, 4 * C + 3, L}, {G_.lp2_w, G_.lp2_b, G_.bnp_g, G_.bnp_b}, 4};
-        hipLaunchKernelGGL(pt_reduce_kernel, dim3(fsg_cdiv(L, 64)), dim3(256), 0, st, rec, gr * G::PT, L, sg);
+        hipLaunchKernelGGL(pt_reduce_kernel, dim3(fsg_cdiv(L, 32)), dim3(256), 0, st, rec, gr, L, sg);
     }
     // B4
     const int ge = edge_grid((long)n * ns);

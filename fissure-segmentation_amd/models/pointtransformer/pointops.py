@@ -23,6 +23,33 @@ class knn_cache:
         _knn_memo = self._outer
 
 
+_const_memo = {}
+
+
+def device_ints(values, device, dtype=torch.int32):
+    """Small constant integer tensor (segment ends, counts) on the device.  Memoised by value: the host-to-device copy
+    happens once, so a training step with static shapes issues no copy at all and can be captured into a hipGraph."""
+    key = (tuple(int(v) for v in values), str(device), dtype)
+    t = _const_memo.get(key)
+    if t is None:
+        if len(_const_memo) > 4096:
+            _const_memo.clear()
+        t = torch.tensor(key[0], device=device, dtype=dtype)
+        _const_memo[key] = t
+    return t
+
+
+def segment_ids(ends, device):
+    """(n) int64: segment number of every packed row (memoised like device_ints)."""
+    key = ("seg", tuple(int(v) for v in ends), str(device))
+    t = _const_memo.get(key)
+    if t is None:
+        counts = device_ints([e - s for s, e in zip([0] + list(ends[:-1]), ends)], device, torch.int64)
+        t = torch.repeat_interleave(torch.arange(len(ends), device=device), counts, output_size=int(ends[-1]))
+        _const_memo[key] = t
+    return t
+
+
 def host_offsets(o):
     """Segment ends as a Python list without a device sync when the producer attached them."""
     cached = getattr(o, "_fsg_host", None)

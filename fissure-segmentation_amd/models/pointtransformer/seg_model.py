@@ -89,7 +89,7 @@ class TransitionDown(nn.Module):
             total += (e - prev) // self.stride
             new_ends.append(total)
             prev = e
-        n_o = pointops.with_host_offsets(torch.tensor(new_ends, device=p.device, dtype=o.dtype), new_ends)
+        n_o = pointops.with_host_offsets(pointops.device_ints(new_ends, p.device, o.dtype), new_ends)
         idx = pointops.furthestsampling(p, o, n_o)
         n_p = p[idx.long(), :].contiguous()
         g = pointops.queryandgroup(self.nsample, p, n_p, x, None, o, n_o, use_xyz=True)  # (m, ns, 3+c)
@@ -117,8 +117,8 @@ class TransitionUp(nn.Module):
         if pxo2 is None:  # head: concat every point with its cloud's mean feature (:101-113)
             _, x, o = pxo1
             ends = pointops.host_offsets(o)
-            counts = torch.tensor([e - s for s, e in zip([0] + ends[:-1], ends)], device=x.device)
-            seg = torch.repeat_interleave(torch.arange(len(ends), device=x.device), counts, output_size=ends[-1])
+            counts = pointops.device_ints([e - s for s, e in zip([0] + ends[:-1], ends)], x.device, torch.int64)
+            seg = pointops.segment_ids(ends, x.device)
             mean = torch.zeros(len(ends), x.shape[1], device=x.device, dtype=x.dtype).index_add_(0, seg, x)
             mean = mean / counts.unsqueeze(1).to(x.dtype)
             return self.linear1(torch.cat((x, self.linear2(mean)[seg]), dim=1))
@@ -213,6 +213,6 @@ class PointTransformerCompatibility(PointSegmentationModelBase):
         coords = flat[:, :3].contiguous()
         feat = flat[:, 3:].contiguous()
         ends = [(i + 1) * npts for i in range(bs)]
-        offsets = pointops.with_host_offsets(torch.tensor(ends, dtype=torch.int32, device=x.device), ends)
+        offsets = pointops.with_host_offsets(pointops.device_ints(ends, x.device, torch.int32), ends)
         out = self.point_transformer([coords, feat, offsets])
         return out.reshape(bs, npts, -1).transpose(1, 2)

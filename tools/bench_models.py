@@ -10,10 +10,28 @@ from fissure_segmentation_amd.models.dgcnn import DGCNNSeg
 from fissure_segmentation_amd.losses.chamfer_loss import ChamferLoss
 dev = torch.device("cuda:0")
 
+GRAPH = "--graph" in sys.argv
+if GRAPH: sys.argv.remove("--graph")
+
 def run(name, net, x, lossfn, steps=10, warm=3):
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=GRAPH, fused=True)
     def step():
         opt.zero_grad(set_to_none=True); l = lossfn(net(x)); l.backward(); opt.step(); return l
+    if GRAPH:   # static shapes: capture fwd + loss + bwd + Adam once, replay
+        name = name.replace("eager", "hipGraph replay")
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warm): step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        opt.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            static_l = step()
+        def step():
+            g.replay(); return static_l
     for _ in range(warm): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps): l = step()
