@@ -89,11 +89,20 @@ __device__ __forceinline__ void sort64(T &v, int lane) {
 
 // WAVES waves per workgroup (16 when the register budget allows: everything here is latency-bound, so thread-level
 // parallelism is the lever), SURV = survivor slots per wave
-template <int KS, int WAVES, int SURV, int CH, int CK>
+// SEG = true: the packed-segment query of the PointTransformer path (fsg_knn_segment_f32): x = candidate coordinates
+// (n,3), xq = query coordinates (m,3), cumulative segment ends in seg_c / seg_q; phase A evaluates the direct form
+// fma(dz,dz, fma(dy,dy, dx*dx)) on the VALU (bit-identical to the oracle's orc_knn_segment_f32), phase B is shared.
+struct SegArgs {
+    const float *xq;
+    const int32_t *seg_c, *seg_q;
+    int nseg;
+};
+
+template <int KS, int WAVES, int SURV, int CH, int CK, bool SEG = false>
 __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *__restrict__ x, const float *__restrict__ xx,
                                                              int N, long sb, long sc, int c_knn, int k, int flags,
                                                              int32_t *__restrict__ idx_out,
-                                                             float *__restrict__ dist_out) {
+                                                             float *__restrict__ dist_out, SegArgs sa) {
     constexpr int STRIDE = CH + 4;
     constexpr int VPL = CH / 64;      // values per lane in the selection phase
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -102,12 +111,31 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
     u64 *surv = carry + QB * CK;                                                          // [WAVES][SURV]
     int *ccount = reinterpret_cast<int *>(surv + WAVES * SURV);                           // [QB]
 
-    const int b = blockIdx.y, q0 = blockIdx.x * QB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const float *xb = x + (long)b * sb;
-    const float *xxb = xx + (long)b * N;
-    const int drop = (flags & FSG_KNN_DROP_FIRST) ? 1 : 0;
+    int b = blockIdx.y, q0 = blockIdx.x * QB;
+    int NQ = N;             // queries of this cloud / segment
+    long cbase = 0, qbase = 0;  // first candidate / query row of the segment (SEG)
+    if (SEG) {
+        // workgroup -> (segment, query tile): tiles are numbered segment by segment
+        int t = blockIdx.x, sgm = 0, found = 0;
+        for (; sgm < sa.nseg; ++sgm) {
+            const int qs = sgm ? sa.seg_q[sgm - 1] : 0, qe = sa.seg_q[sgm];
+            const int nt = (qe - qs + QB - 1) / QB;
+            if (t < nt) { found = 1; break; }
+            t -= nt;
+        }
+        if (!found) return;  // grid is an upper bound (m/QB + nseg tiles); uniform per workgroup, before any barrier
+        b = sgm;
+        q0 = t * QB;
+        qbase = sgm ? sa.seg_q[sgm - 1] : 0;
+        NQ = sa.seg_q[sgm] - (int)qbase;
+        cbase = sgm ? sa.seg_c[sgm - 1] : 0;
+        N = sa.seg_c[sgm] - (int)cbase;
+    }
+    const float *xb = SEG ? x + 3 * cbase : x + (long)b * sb;
+    const float *xxb = SEG ? nullptr : xx + (long)b * N;
+    const int drop = (!SEG && (flags & FSG_KNN_DROP_FIRST)) ? 1 : 0;
     const int KK = k + drop;
 
     if (tid < QB) ccount[tid] = 0;
@@ -119,8 +147,15 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int ch = 4 * s + l4, q = q0 + blk * 16 + l15;
-            qa[blk][s] = (ch < c_knn && q < N) ? xb[ch * sc + q] : 0.f;
+            qa[blk][s] = (!SEG && ch < c_knn && q < N) ? xb[ch * sc + q] : 0.f;
         }
+    __shared__ float qsh[SEG ? QB * 3 : 1];   // SEG: coordinates of the 32 queries
+    if (SEG) {
+        if (tid < QB * 3) {
+            const int q = q0 + tid / 3;
+            qsh[tid] = q < NQ ? sa.xq[3 * (qbase + q) + tid % 3] : 0.f;
+        }
+    }
     // squared norms of the 4 accumulator rows of this lane: row = l4*4 + e
     float xxq[2][4];
 #pragma unroll
@@ -128,7 +163,7 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int q = q0 + blk * 16 + l4 * 4 + e;
-            xxq[blk][e] = q < N ? xxb[q] : 0.f;
+            xxq[blk][e] = (!SEG && q < N) ? xxb[q] : 0.f;
         }
     const bool fix_diag = (flags & FSG_KNN_FIX_DIAG) != 0;
 
@@ -136,6 +171,20 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
         const int len = min(CH, N - c0);
         const int ntile = (len + 15) >> 4;
         // ---------------------------------------------------------------- phase A: distance block into LDS
+        if (SEG) {
+            __syncthreads();  // qsh written (first chunk) / previous chunk's rows consumed
+            for (int cidx = tid; cidx < CH; cidx += WAVES * 64) {
+                const int jc = c0 + cidx;
+                float cx = 0.f, cy = 0.f, cz = 0.f;
+                if (jc < N) { cx = xb[3L * jc]; cy = xb[3L * jc + 1]; cz = xb[3L * jc + 2]; }
+#pragma unroll 8
+                for (int qr = 0; qr < QB; ++qr) {
+                    const float dx = qsh[3 * qr] - cx, dy = qsh[3 * qr + 1] - cy, dz = qsh[3 * qr + 2] - cz;
+                    const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                    rows[qr * STRIDE + cidx] = jc < N ? d : INFINITY;
+                }
+            }
+        }
         float bn[KS], xn = 0.f;   // operand of the NEXT tile of this wave: its loads fly while the current MFMAs run
         auto load_tile = [&](int t) {
             const int jc = c0 + t * 16 + l15;
@@ -147,8 +196,8 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
             xn = jc < N ? xxb[jc] : 0.f;
         };
         constexpr bool PREFETCH = KS <= 16;  // the 128-channel instantiation has no registers to spare
-        if (PREFETCH && wave < ntile && !(flags & 512)) load_tile(wave);
-        for (int t = wave; t < CH / 16; t += WAVES) {
+        if (!SEG && PREFETCH && wave < ntile && !(flags & 512)) load_tile(wave);
+        for (int t = wave; t < (SEG ? 0 : CH / 16); t += WAVES) {
             if (t >= ntile || (flags & 512)) {  // beyond the cloud (flag 512: timing ablation of phase A)
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk)
@@ -189,7 +238,7 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
 
         // ---------------------------------------------------------------- phase B: exact selection, one wave per row
         for (int qi = wave; qi < QB; qi += WAVES) {
-            if (q0 + qi >= N || (flags & 256)) break;  // flag 256: timing ablation of phase B
+            if (q0 + qi >= NQ || (flags & 256)) break;  // flag 256: timing ablation of phase B
             const float *row = rows + qi * STRIDE;
             u64 *sv = surv + wave * SURV;
             float v[VPL];
@@ -302,8 +351,17 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
     // ---------------------------------------------------------------- output: rank r of row qi -> lane r
     for (int qi = wave; qi < QB; qi += WAVES) {
         const int q = q0 + qi;
-        if (q >= N) break;
-        if (lane >= drop && lane < KK) {
+        if (q >= NQ) break;
+        if (SEG) {
+            // global row numbers; segments shorter than nsample are padded with (first row of the segment, 1e10)
+            if (lane < KK) {
+                const bool have = lane < ccount[qi];
+                const u64 v = carry[qi * CK + lane];
+                const long o = (qbase + q) * k + lane;
+                idx_out[o] = have ? (int)(cbase + (long)(unsigned)(v & 0xFFFFFFFFull)) : (int)cbase;
+                if (dist_out) dist_out[o] = have ? o2f((unsigned)(v >> 32)) : 1e10f;
+            }
+        } else if (lane >= drop && lane < KK) {
             const u64 v = carry[qi * CK + lane];
             const long o = ((long)b * N + q) * k + (lane - drop);
             idx_out[o] = (int)(unsigned)(v & 0xFFFFFFFFull);
@@ -354,7 +412,7 @@ int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int
             granted = true;                                                                                            \
         }                                                                                                              \
         hipLaunchKernelGGL((knn_rows_mfma_kernel<KS, WV, SV, CHK, CKK>), grid, dim3((WV) * 64), lds, st, x, xx_scratch, N, \
-                           (long)stride_b, (long)stride_c, c_knn, k, flags, idx_out, dist_out);                        \
+                           (long)stride_b, (long)stride_c, c_knn, k, flags, idx_out, dist_out, SegArgs{});             \
     } while (0)
     const bool small_k = k + drop <= 32;                      // carried list fits 32 slots
     // 512-candidate chunks fit two workgroups per CU in LDS but not in registers (241 VGPRs -> 2 waves/SIMD): measured
@@ -366,5 +424,27 @@ int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int
     else { if (half) FSG_KNN_RM(32, 8, 64, 512, 32); else FSG_KNN_RM(32, 8, 128, 1024, 64); }
 #undef FSG_KNN_RM
     FSG_CHECK_LAUNCH("fsg_knn_dense_f32/rows_mfma");
+    return FSG_OK;
+}
+
+// packed-segment query on the same selection machinery; FSG_ERR_UNSUPPORTED -> caller keeps its scalar kernel
+int fsg_knn_segment_rows_launch(const float *xyz, const float *new_xyz, const int32_t *offset, const int32_t *new_offset,
+                                int b, int n, int m, int nsample, int32_t *idx, float *dist2, hipStream_t st) {
+    if (nsample > 32 || b > 4096) return FSG_ERR_UNSUPPORTED;
+    constexpr int WV = 16, SV = 96, CHK = 1024, CKK = 64;
+    const size_t lds = sizeof(float) * QB * (CHK + 4) + sizeof(u64) * (QB * CKK + WV * SV) + sizeof(int) * QB;
+    static bool granted = false;
+    if (!granted) {
+        if (hipFuncSetAttribute((const void *)knn_rows_mfma_kernel<1, WV, SV, CHK, CKK, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            fsg_set_error("fsg_knn_segment_f32: cannot raise dynamic LDS to %zu", lds);
+            return FSG_ERR_HIP;
+        }
+        granted = true;
+    }
+    const SegArgs sa{new_xyz, offset, new_offset, b};
+    hipLaunchKernelGGL((knn_rows_mfma_kernel<1, WV, SV, CHK, CKK, true>), dim3(fsg_cdiv(m, QB) + b), dim3(WV * 64), lds, st,
+                       xyz, (const float *)nullptr, n, 0L, 0L, 3, nsample, 0, idx, dist2, sa);
+    FSG_CHECK_LAUNCH("fsg_knn_segment_f32/rows");
     return FSG_OK;
 }

@@ -6,6 +6,10 @@
 // v0: one lane per query (kNN), one workgroup per cloud (FPS), lanes along channels (gather /
 // aggregate).  Distances use the direct form d = fma(dz,dz, fma(dy,dy, dx*dx)) like oracle/fsg_oracle.c.
 #include "fsg_common.h"
+#include <stdlib.h>
+
+int fsg_knn_segment_rows_launch(const float *xyz, const float *new_xyz, const int32_t *offset, const int32_t *new_offset,
+                                int b, int n, int m, int nsample, int32_t *idx, float *dist2, hipStream_t st);
 
 namespace {
 
@@ -169,6 +173,14 @@ extern "C" int fsg_knn_segment_f32(const float *xyz, const float *new_xyz, const
                 "fsg_knn_segment_f32: bad shape b=%d n=%d m=%d nsample=%d", b, n, m, nsample);
     if (m == 0) return FSG_OK;
     hipStream_t st = (hipStream_t)stream;
+    // production path: 32 queries per workgroup on the dense kNN's wave-cooperative selection (knn_rows_mfma.hip);
+    // the one-thread-per-query kernel below stays as the fallback (nsample > 32) and as a cross-check
+    // (FSG_KNN_SEGMENT_SCALAR=1)
+    static const bool scalar_only = getenv("FSG_KNN_SEGMENT_SCALAR") != nullptr;
+    if (!scalar_only) {
+        const int rc = fsg_knn_segment_rows_launch(xyz, new_xyz, offset, new_offset, b, n, m, nsample, idx, dist2, st);
+        if (rc != FSG_ERR_UNSUPPORTED) return rc;
+    }
     dim3 grid(fsg_cdiv(m, BLOCK)), block(BLOCK);
 #define FSG_KNNSEG(NS) \
     hipLaunchKernelGGL(knn_segment_kernel<NS>, grid, block, 0, st, xyz, new_xyz, offset, new_offset, b, m, nsample, idx, dist2)

@@ -263,9 +263,13 @@ def packed(seed, sizes, c=0):
     return xyz, feat, np.cumsum(sizes).astype(np.int32)
 
 
-@pytest.mark.parametrize("sizes,ns", [([300, 200, 257], 16), ([8, 8], 16), ([2048], 8), ([5, 1, 64], 3), ([100], 33)])
+@pytest.mark.parametrize("sizes,ns", [([300, 200, 257], 16), ([8, 8], 16), ([2048], 8), ([5, 1, 64], 3), ([100], 33),
+                                      ([3000, 100, 1025], 16), ([1, 2, 3, 40], 32), ([2048] * 8, 8), ([512] * 8, 16)])
 def test_knn_segment_exact(fsg, device, sizes, ns):
     xyz, _, off = packed(11, sizes)
+    xyz[7 % len(xyz)] = xyz[0]                      # duplicate points: ties go to the lower index
+    if len(xyz) > 1500:
+        xyz[1100:1400] = np.round(xyz[1100:1400] * 4) / 4   # a lattice: many exactly equal distances
     idx, d2 = fsg.functional.knn_segment(ns, G(xyz, device), G(xyz, device), G(off, device), G(off, device))
     ridx, rd2 = c_api.knn_segment(xyz, xyz, off, off, ns)
     assert np.array_equal(N(idx), ridx) and np.array_equal(N(d2).view(np.uint32), rd2.view(np.uint32))
@@ -282,6 +286,23 @@ def test_knn_segment_cross_sets_and_fps(fsg, device):
     idx, d2 = fsg.functional.knn_segment(16, G(xyz, device), G(q, device), G(off, device), G(new_off, device))
     ridx, rd2 = c_api.knn_segment(xyz, q, off, new_off, 16)
     assert np.array_equal(N(idx), ridx) and np.array_equal(N(d2).view(np.uint32), rd2.view(np.uint32))
+    # the interpolation query (pointops.py:198-215): fine points ask for their 3 nearest coarse points
+    idx, d2 = fsg.functional.knn_segment(3, G(q, device), G(xyz, device), G(new_off, device), G(off, device))
+    ridx, rd2 = c_api.knn_segment(q, xyz, new_off, off, 3)
+    assert np.array_equal(N(idx), ridx) and np.array_equal(N(d2).view(np.uint32), rd2.view(np.uint32))
+
+
+def test_knn_segment_config3_sizes(fsg, device):
+    """BASELINE config 3 shapes: 8 clouds x 2048 points; level-1 graph (nsample 8), the TransitionDown query of 512
+    sampled points per cloud (nsample 16) and the level-2 graph -- bit-exact against the C oracle."""
+    xyz, _, off = packed(13, [2048] * 8)
+    new_off = np.cumsum([512] * 8).astype(np.int32)
+    sel = np.concatenate([np.arange(512) * 4 + 2048 * b for b in range(8)])
+    q = np.ascontiguousarray(xyz[sel])
+    for ns, a, b_, oa, ob in [(8, xyz, xyz, off, off), (16, xyz, q, off, new_off), (16, q, q, new_off, new_off)]:
+        idx, d2 = fsg.functional.knn_segment(ns, G(a, device), G(b_, device), G(oa, device), G(ob, device))
+        ridx, rd2 = c_api.knn_segment(a, b_, oa, ob, ns)
+        assert np.array_equal(N(idx), ridx) and np.array_equal(N(d2).view(np.uint32), rd2.view(np.uint32))
 
 
 def test_group_gather_and_vec_attn(fsg, device):
