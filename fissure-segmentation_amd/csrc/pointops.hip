@@ -60,15 +60,67 @@ __global__ __launch_bounds__(BLOCK) void knn_segment_kernel(const float *__restr
         }
 }
 
+// Farthest point sampling of one segment by ONE wave: the segment's points and running minimum distances live in
+// registers (PPL per lane, point j = start + lane + 64 r), the coordinates also in LDS so that the next pivot is a
+// broadcast LDS read instead of a dependent global load; an iteration is PPL distance updates + a 6-step shuffle
+// arg-max, no barrier.  Same arithmetic and tie rule (largest distance, lowest index) as the scalar reference.
+template <int PPL>
+__device__ __forceinline__ void fps_one_wave(const float *__restrict__ xyz, int st, int len, int qs, int qe,
+                                             int32_t *__restrict__ idx, float *lds) {
+    const int lane = threadIdx.x & 63;
+    float px[PPL], py[PPL], pz[PPL], md[PPL];
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+        const int j = lane + 64 * r;
+        const bool ok = j < len;
+        px[r] = ok ? xyz[3L * (st + j)] : 0.f;
+        py[r] = ok ? xyz[3L * (st + j) + 1] : 0.f;
+        pz[r] = ok ? xyz[3L * (st + j) + 2] : 0.f;
+        md[r] = 1e10f;
+        if (ok) { lds[3 * j] = px[r]; lds[3 * j + 1] = py[r]; lds[3 * j + 2] = pz[r]; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    int cur = 0;  // local index of the pivot
+    if (lane == 0) idx[qs] = st;
+    for (int t = qs + 1; t < qe; ++t) {
+        const float cx = lds[3 * cur], cy = lds[3 * cur + 1], cz = lds[3 * cur + 2];
+        float bv = -1.f;
+        int bj = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < PPL; ++r) {
+            const int j = lane + 64 * r;
+            const float d = sqdist3(px[r], py[r], pz[r], cx, cy, cz);
+            const float v = fminf(d, md[r]);
+            md[r] = v;
+            if (j < len && v > bv) { bv = v; bj = j; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(bv, off);
+            const int oj = __shfl_xor(bj, off);
+            if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+        }
+        cur = bj;
+        if (lane == 0) idx[t] = st + cur;
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ offset,
                                                      const int32_t *__restrict__ new_offset, float *__restrict__ md,
                                                      int32_t *__restrict__ idx) {
     __shared__ float wv[BLOCK / 64];
     __shared__ int wj[BLOCK / 64];
+    __shared__ float pts[2048 * 3];
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int st = s ? offset[s - 1] : 0, en = offset[s];
     const int qs = s ? new_offset[s - 1] : 0, qe = new_offset[s];
     if (qe <= qs || en <= st) return;
+    if (en - st <= 2048) {  // register-resident single-wave path (uniform per workgroup: the other waves just leave)
+        if (wave != 0) return;
+        if (en - st <= 512) fps_one_wave<8>(xyz, st, en - st, qs, qe, idx, pts);
+        else fps_one_wave<32>(xyz, st, en - st, qs, qe, idx, pts);
+        return;
+    }
     for (int j = st + tid; j < en; j += BLOCK) md[j] = 1e10f;
     int cur = st;
     if (tid == 0) idx[qs] = cur;

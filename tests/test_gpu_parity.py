@@ -292,6 +292,18 @@ def test_knn_segment_cross_sets_and_fps(fsg, device):
     assert np.array_equal(N(idx), ridx) and np.array_equal(N(d2).view(np.uint32), rd2.view(np.uint32))
 
 
+@pytest.mark.parametrize("sizes", [[2048] * 8, [512, 100, 7, 513], [3000, 64, 2049], [1, 2, 65]])
+def test_fps_exact(fsg, device, sizes):
+    """farthest point sampling (pointops.py:16-39), a quarter of every segment: single-wave register path (<= 512 and
+    <= 2048 points) and the workgroup path, bit-exact incl. ties (duplicated points -> lowest index)."""
+    xyz, _, off = packed(21, sizes)
+    xyz[len(xyz) // 2] = xyz[0]
+    xyz[-1] = xyz[len(xyz) // 3]
+    new_off = np.cumsum([max(1, s // 4) for s in sizes]).astype(np.int32)
+    fi = fsg.functional.fps(G(xyz, device), G(off, device), G(new_off, device), int(new_off[-1]))
+    assert np.array_equal(N(fi), c_api.fps(xyz, off, new_off))
+
+
 def test_knn_segment_config3_sizes(fsg, device):
     """BASELINE config 3 shapes: 8 clouds x 2048 points; level-1 graph (nsample 8), the TransitionDown query of 512
     sampled points per cloud (nsample 16) and the level-2 graph -- bit-exact against the C oracle."""
