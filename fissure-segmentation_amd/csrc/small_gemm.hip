@@ -1,0 +1,132 @@
+// Small / skinny fp32 GEMM on the matrix cores -- include/fsg_hip.h: fsg_gemm_small_f32.
+//
+// The point-wise Linears of the PointTransformer path (models/pointtransformer/seg_model.py: linear_q/k/v, linear1/3,
+// TransitionDown/Up) are tiny: at the coarse levels the whole product is one 256 x 256 x 256 block, and its weight
+// gradient dW = dY^T X has a few thousand outputs behind a reduction over all points.  The vendor library answers these
+// shapes with ONE 256x256 macro-tile = one workgroup = one of 256 CUs (measured 64-175 us per call on MI355X, 3.6 ms of
+// a 15 ms step).  This kernel tiles the output 64 x 64 per workgroup (four waves, one 32 x 32 v_mfma_f32_32x32x2_f32
+// accumulator each), stages both operands through LDS with whatever orientation is contiguous in memory (generic
+// element strides: X W^T, dY W and dY^T X are the same kernel), and splits the reduction dimension over blockIdx.z
+// when the output alone cannot fill the chip; the partial products are then summed in split order by a second
+// kernel (no atomics: reproducible).  MFMA fp32 is an exact fp32 fma chain, so results match a plain fp32 GEMM up to
+// summation order.
+#include "fsg_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TI = 64, TJ = 64, TK = 16, LDT = 65;  // k-major LDS tiles [TK][64 + 1]
+
+__global__ __launch_bounds__(256) void gemm_small_kernel(const float *__restrict__ A, long sai, long sak,
+                                                         const float *__restrict__ B, long sbk, long sbj,
+                                                         const float *__restrict__ bias, float *__restrict__ C, long ldc,
+                                                         int I, int J, int K, int kchunk, float *__restrict__ part) {
+    __shared__ float As[TK * LDT], Bs[TK * LDT];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, ql = lane & 31, half = lane >> 5;
+    const int i0 = blockIdx.x * TI, j0 = blockIdx.y * TJ;
+    const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;  // this wave's 32 x 32 quadrant
+    // loader mapping: consecutive threads along whichever tile dimension is contiguous in memory
+    const bool a_kfast = sak == 1, b_kfast = sbk == 1;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int k0 = kbeg; k0 < kend; k0 += TK) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = r * 256 + tid;
+            const int ai = a_kfast ? t / TK : t % TI, ak = a_kfast ? t % TK : t / TI;
+            const int bj = b_kfast ? t / TK : t % TJ, bk = b_kfast ? t % TK : t / TJ;
+            av[r] = (i0 + ai < I && k0 + ak < kend) ? A[(long)(i0 + ai) * sai + (long)(k0 + ak) * sak] : 0.f;
+            bv[r] = (j0 + bj < J && k0 + bk < kend) ? B[(long)(k0 + bk) * sbk + (long)(j0 + bj) * sbj] : 0.f;
+        }
+        __syncthreads();  // previous tile consumed
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = r * 256 + tid;
+            const int ai = a_kfast ? t / TK : t % TI, ak = a_kfast ? t % TK : t / TI;
+            const int bj = b_kfast ? t / TK : t % TJ, bk = b_kfast ? t % TK : t / TJ;
+            As[ak * LDT + ai] = av[r];
+            Bs[bk * LDT + bj] = bv[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < TK / 2; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(2 * s + half) * LDT + wi + ql], Bs[(2 * s + half) * LDT + wj + ql],
+                                                       acc, 0, 0, 0);
+    }
+    const int col = j0 + wj + ql;
+    if (col >= J) return;
+    if (part) {
+        float *dst = part + (long)blockIdx.z * I * J;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = i0 + wi + (e & 3) + 8 * (e >> 2) + 4 * half;
+            if (row < I) dst[(long)row * J + col] = acc[e];
+        }
+    } else {
+        const float bb = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = i0 + wi + (e & 3) + 8 * (e >> 2) + 4 * half;
+            if (row < I) C[(long)row * ldc + col] = acc[e] + bb;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_small_reduce_kernel(const float *__restrict__ part, int S, long IJ, int J,
+                                                                const float *__restrict__ bias, float *__restrict__ C,
+                                                                long ldc) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= IJ) return;
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += part[(long)s * IJ + t];
+    const long row = t / J;
+    const int col = (int)(t - row * J);
+    C[row * ldc + col] = a + (bias ? bias[col] : 0.f);
+}
+
+// number of reduction splits: enough workgroups to occupy the chip, at least 64 reduction steps each
+inline int splits_for(int I, int J, int K) {
+    const long tiles = (long)fsg_cdiv(I, TI) * fsg_cdiv(J, TJ);
+    if (tiles >= 192 || K < 128) return 1;
+    long s = (256 + tiles - 1) / tiles;
+    const long smax = K / 64;
+    if (s > smax) s = smax;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : (int)s;
+}
+
+}  // namespace
+
+extern "C" size_t fsg_gemm_small_workspace_bytes(int I, int J, int K) {
+    if (I <= 0 || J <= 0 || K <= 0) return 0;
+    const int s = splits_for(I, J, K);
+    return s > 1 ? sizeof(float) * (size_t)s * (size_t)I * (size_t)J : 0;
+}
+
+extern "C" int fsg_gemm_small_f32(const float *A, int64_t sa_i, int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_j,
+                                  const float *bias, float *C, int64_t ldc, int I, int J, int K, void *workspace,
+                                  fsg_stream_t stream) {
+    FSG_REQUIRE(A && B && C, "fsg_gemm_small_f32: NULL pointer");
+    FSG_REQUIRE(I > 0 && J > 0 && K > 0 && ldc >= J, "fsg_gemm_small_f32: bad shape I=%d J=%d K=%d ldc=%ld", I, J, K, (long)ldc);
+    FSG_REQUIRE(fsg_cdiv(J, TJ) <= 65535, "fsg_gemm_small_f32: J too large");
+    const int S = splits_for(I, J, K);
+    FSG_REQUIRE(S == 1 || workspace, "fsg_gemm_small_f32: this shape needs the workspace");
+    hipStream_t st = (hipStream_t)stream;
+    int kchunk = fsg_cdiv(fsg_cdiv(K, S), TK) * TK;
+    const int S_eff = fsg_cdiv(K, kchunk);  // every split non-empty
+    float *part = S_eff > 1 ? (float *)workspace : nullptr;
+    hipLaunchKernelGGL(gemm_small_kernel, dim3(fsg_cdiv(I, TI), fsg_cdiv(J, TJ), S_eff), dim3(256), 0, st, A, (long)sa_i,
+                       (long)sa_k, B, (long)sb_k, (long)sb_j, bias, C, (long)ldc, I, J, K, kchunk, part);
+    FSG_CHECK_LAUNCH("fsg_gemm_small_f32");
+    if (part) {
+        const long IJ = (long)I * J;
+        hipLaunchKernelGGL(gemm_small_reduce_kernel, dim3(fsg_cdiv(IJ, 256)), dim3(256), 0, st, part, S_eff, IJ, J, bias, C,
+                           (long)ldc);
+        FSG_CHECK_LAUNCH("fsg_gemm_small_f32/reduce");
+    }
+    return FSG_OK;
+}

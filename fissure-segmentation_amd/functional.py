@@ -85,16 +85,39 @@ def edge_features(x, idx):
 
 
 # ------------------------------------------------------------------ point-major linear layer (1x1 conv as one GEMM)
+SMALL_GEMM_FLOPS = 6e8   # below this the vendor GEMM tends to pick one huge macro-tile (one workgroup): use fsg_gemm_small_f32
+
+
+def gemm_small(a, sa_i, sa_k, b, sb_k, sb_j, bias, I, J, K):
+    """C (I,J) = A(i,k) B(k,j) (+ bias[j]) with explicit element strides -- include/fsg_hip.h: fsg_gemm_small_f32."""
+    out = torch.empty(I, J, dtype=torch.float32, device=a.device)
+    nbytes = _lib.lib.fsg_gemm_small_workspace_bytes(I, J, K)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=a.device) if nbytes else None
+    with torch.cuda.device(a.device):
+        _lib.call("fsg_gemm_small_f32", _p(a), sa_i, sa_k, _p(b), sb_k, sb_j, _p(bias), _p(out), J, I, J, K, _p(ws), _stream())
+    return out
+
+
+def _small(x2, n_out):
+    return (x2.is_cuda and x2.dtype == torch.float32 and x2.is_contiguous()
+            and 2.0 * x2.shape[0] * x2.shape[1] * n_out < SMALL_GEMM_FLOPS and x2.shape[0] > 0)
+
+
 class _LinearPM(torch.autograd.Function):
-    """y = x W^T (+ b) over point-major rows.  Forward and dX are plain library GEMMs; the weight gradient
-    dW = dY^T X has a tiny output and a 16k-long reduction, for which the library picks a single-wave-per-tile kernel
-    (measured 106-132 us on MI355X whatever the width): it is issued as a 16-way split-K batched GEMM + a sum
-    (36-78 us)."""
+    """y = x W^T (+ b) over point-major rows.  Large products go to the vendor GEMM (the weight gradient dW = dY^T X, a
+    tiny output behind a 16k-long reduction, as a 16-way split-K batched GEMM + a sum: 36-78 us instead of 106-132 us);
+    small ones -- everything in the PointTransformer path -- to fsg_gemm_small_f32, because the vendor library runs
+    them as a single workgroup."""
 
     @staticmethod
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        x2 = x.reshape(-1, x.shape[-1])
+        N, K = w.shape
+        if _small(x2, N) and w.is_contiguous() and w.dtype == torch.float32:
+            y = gemm_small(x2, K, 1, w, 1, K, b.contiguous() if b is not None else None, x2.shape[0], N, K)
+            return y.view(*x.shape[:-1], N)
         return torch.nn.functional.linear(x, w, b)
 
     @staticmethod
@@ -103,12 +126,18 @@ class _LinearPM(torch.autograd.Function):
         g2 = g.reshape(-1, g.shape[-1])
         x2 = x.reshape(-1, x.shape[-1])
         gx = gw = gb = None
+        N, K = w.shape
+        M = g2.shape[0]
+        small = _small(x2, N) and w.is_contiguous() and g2.dtype == torch.float32
+        if small and not g2.is_contiguous():
+            g2 = g2.contiguous()
         if ctx.needs_input_grad[0]:
-            gx = (g2 @ w).view_as(x)
+            gx = (gemm_small(g2, N, 1, w, K, 1, None, M, K, N) if small else g2 @ w).view_as(x)
         if ctx.needs_input_grad[1]:
-            M = g2.shape[0]
             S = 16 if (M % 16 == 0 and M >= 4096) else 1
-            if S > 1 and g2.is_contiguous() and x2.is_contiguous():
+            if small:
+                gw = gemm_small(g2, 1, N, x2, K, 1, None, N, K, M)
+            elif S > 1 and g2.is_contiguous() and x2.is_contiguous():
                 gw = torch.bmm(g2.view(S, M // S, -1).transpose(1, 2), x2.view(S, M // S, -1)).sum(0)
             else:
                 gw = g2.t() @ x2

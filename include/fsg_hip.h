@@ -230,6 +230,19 @@ int fsg_vec_attn_bwd_f32(const float *v, const float *pos, const float *w, const
                          int ns, int c, int cw, fsg_stream_t stream);
 
 /*
+ * Small / skinny fp32 GEMM:  C[i,j] = sum_k A(i,k) * B(k,j) (+ bias[j]),  A(i,k) = A[i*sa_i + k*sa_k],
+ * B(k,j) = B[k*sb_k + j*sb_j] (element strides: any transposition), C row-major with row stride ldc.
+ * Carries the point-wise Linears of models/pointtransformer/seg_model.py (:25-33, :64-69, :92-99, :128-134, :168-169)
+ * and their dX / dW products, for which the vendor GEMM launches a single workgroup (see csrc/small_gemm.hip).
+ * Reproducible (split reductions are summed in a fixed order).  workspace: fsg_gemm_small_workspace_bytes(I,J,K)
+ * bytes (0 when the shape needs no split), 4-byte aligned.
+ */
+size_t fsg_gemm_small_workspace_bytes(int I, int J, int K);
+int fsg_gemm_small_f32(const float *A, int64_t sa_i, int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_j,
+                       const float *bias, float *C, int64_t ldc, int I, int J, int K, void *workspace,
+                       fsg_stream_t stream);
+
+/*
  * Fused PointTransformerLayer body: replaces models/pointtransformer/seg_model.py:38-53 after the three
  * q/k/v Linears (:37), i.e. neighbour grouping of keys, values and coordinates, linear_p (Linear(3,3) -> BatchNorm1d(3)
  * -> ReLU -> Linear(3,c)), w = k_j - q_i + p_r, linear_w (BatchNorm1d(c) -> ReLU -> Linear(c,c/8) -> BatchNorm1d(c/8) ->

@@ -292,6 +292,30 @@ def test_knn_segment_cross_sets_and_fps(fsg, device):
     assert np.array_equal(N(idx), ridx) and np.array_equal(N(d2).view(np.uint32), rd2.view(np.uint32))
 
 
+@pytest.mark.parametrize("M,Nn,K", [(256, 256, 256), (64, 512, 512), (16384, 96, 32), (65536, 64, 35), (1000, 13, 7),
+                                   (1, 4, 32), (4096, 192, 64), (77, 130, 259)])
+def test_small_gemm_linear(fsg, device, M, Nn, K):
+    """fsg_gemm_small_f32 through linear_pm: y = x W^T + b, dX = dY W, dW = dY^T X (the last with the reduction over all M
+    rows split across workgroups) against fp64 matmuls; fp32 fma chains -> 1e-5 relative; reproducible."""
+    rng = np.random.default_rng(M + Nn + K)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((Nn, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(Nn).astype(np.float32)
+    g = rng.standard_normal((M, Nn)).astype(np.float32)
+    assert 2.0 * M * Nn * K < fsg.functional.SMALL_GEMM_FLOPS
+    xt, wt, bt = (G(a, device).requires_grad_(True) for a in (x, w, b))
+    fsg._lib.start_timing()
+    y = fsg.functional.linear_pm(xt, wt, bt)
+    y.backward(G(g, device))
+    assert set(fsg._lib.stop_timing()) == {"fsg_gemm_small_f32"}          # three products, none through the vendor GEMM
+    x64, w64, g64 = x.astype(np.float64), w.astype(np.float64), g.astype(np.float64)
+    for got, ref in [(y, x64 @ w64.T + b), (xt.grad, g64 @ w64), (wt.grad, g64.T @ x64), (bt.grad, g64.sum(0))]:
+        assert np.abs(N(got) - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()) * max(1.0, np.sqrt(max(M, K) / 256))
+    x2, w2 = G(x, device).requires_grad_(True), G(w, device).requires_grad_(True)
+    fsg.functional.linear_pm(x2, w2, None).backward(G(g, device))
+    assert torch.equal(w2.grad, wt.grad) and torch.equal(x2.grad, xt.grad)
+
+
 @pytest.mark.parametrize("sizes", [[2048] * 8, [512, 100, 7, 513], [3000, 64, 2049], [1, 2, 65]])
 def test_fps_exact(fsg, device, sizes):
     """farthest point sampling (pointops.py:16-39), a quarter of every segment: single-wave register path (<= 512 and
