@@ -2,9 +2,10 @@
 //
 // The point-wise Linears of the PointTransformer path (models/pointtransformer/seg_model.py: linear_q/k/v, linear1/3,
 // TransitionDown/Up) are tiny: at the coarse levels the whole product is one 256 x 256 x 256 block, and its weight
-// gradient dW = dY^T X has a few thousand outputs behind a reduction over all points.  The vendor library answers these
-// shapes with ONE 256x256 macro-tile = one workgroup = one of 256 CUs (measured 64-175 us per call on MI355X, 3.6 ms of
-// a 15 ms step).  This kernel tiles the output 64 x 64 per workgroup (four waves, one 32 x 32 v_mfma_f32_32x32x2_f32
+// gradient dW = dY^T X has a few thousand outputs behind a reduction over all points.  Whenever BOTH output dimensions
+// are <= 256 the vendor library answers with ONE 256x256 macro-tile = one workgroup = one of 256 CUs, so its time grows
+// with I*J*K (tools/probe_vendor_gemm.py on MI355X: 22 us at 256x256x64, 63 us at x256, 173 us at x768; 4-6 us as soon
+// as one dimension exceeds 256) -- 3.6 ms of a 15 ms PointTransformer step.  This kernel tiles the output 64 x 64 per workgroup (four waves, one 32 x 32 v_mfma_f32_32x32x2_f32
 // accumulator each), stages both operands through LDS with whatever orientation is contiguous in memory (generic
 // element strides: X W^T, dY W and dY^T X are the same kernel), and splits the reduction dimension over blockIdx.z
 // when the output alone cannot fill the chip; the partial products are then summed in split order by a second
@@ -16,7 +17,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int TI = 64, TJ = 64, TK = 16, LDT = 65;  // k-major LDS tiles [TK][64 + 1]
+constexpr int TI = 64, TJ = 64, TK = 32, LDT = 65;  // k-major LDS tiles [TK][64 + 1]
+constexpr int LPT = TI * TK / 256;                  // tile elements per thread and operand
 
 __global__ __launch_bounds__(256) void gemm_small_kernel(const float *__restrict__ A, long sai, long sak,
                                                          const float *__restrict__ B, long sbk, long sbj,
@@ -32,19 +34,23 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const float *__restrict
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    for (int k0 = kbeg; k0 < kend; k0 += TK) {
-        float av[4], bv[4];
+    // software pipeline: the global loads of tile t+1 are in flight while tile t runs on the matrix cores
+    float av[LPT], bv[LPT];
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < LPT; ++r) {
             const int t = r * 256 + tid;
             const int ai = a_kfast ? t / TK : t % TI, ak = a_kfast ? t % TK : t / TI;
             const int bj = b_kfast ? t / TK : t % TJ, bk = b_kfast ? t % TK : t / TJ;
             av[r] = (i0 + ai < I && k0 + ak < kend) ? A[(long)(i0 + ai) * sai + (long)(k0 + ak) * sak] : 0.f;
             bv[r] = (j0 + bj < J && k0 + bk < kend) ? B[(long)(k0 + bk) * sbk + (long)(j0 + bj) * sbj] : 0.f;
         }
+    };
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += TK) {
         __syncthreads();  // previous tile consumed
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < LPT; ++r) {
             const int t = r * 256 + tid;
             const int ai = a_kfast ? t / TK : t % TI, ak = a_kfast ? t % TK : t / TI;
             const int bj = b_kfast ? t / TK : t % TJ, bk = b_kfast ? t % TK : t / TJ;
@@ -52,6 +58,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const float *__restrict
             Bs[bk * LDT + bj] = bv[r];
         }
         __syncthreads();
+        if (k0 + TK < kend) fetch(k0 + TK);
 #pragma unroll
         for (int s = 0; s < TK / 2; ++s)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(2 * s + half) * LDT + wi + ql], Bs[(2 * s + half) * LDT + wj + ql],
@@ -76,10 +83,12 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const float *__restrict
     }
 }
 
-__global__ __launch_bounds__(256) void gemm_small_reduce_kernel(const float *__restrict__ part, int S, long IJ, int J,
-                                                                const float *__restrict__ bias, float *__restrict__ C,
-                                                                long ldc) {
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+// partial products [S][I*J] -> C: 16 outputs x 16 slices of the split range per workgroup (the slices of one output are
+// combined in slice order through LDS: fixed order, reproducible)
+__global__ __launch_bounds__(256) void gemm_small_reduce_flat_kernel(const float *__restrict__ part, int S, long IJ, int J,
+                                                                     const float *__restrict__ bias, float *__restrict__ C,
+                                                                     long ldc) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;   // few splits: one thread per output
     if (t >= IJ) return;
     float a = 0.f;
     for (int s = 0; s < S; ++s) a += part[(long)s * IJ + t];
@@ -88,14 +97,36 @@ __global__ __launch_bounds__(256) void gemm_small_reduce_kernel(const float *__r
     C[row * ldc + col] = a + (bias ? bias[col] : 0.f);
 }
 
-// number of reduction splits: enough workgroups to occupy the chip, at least 64 reduction steps each
+__global__ __launch_bounds__(256) void gemm_small_reduce_kernel(const float *__restrict__ part, int S, long IJ, int J,
+                                                                const float *__restrict__ bias, float *__restrict__ C,
+                                                                long ldc) {
+    __shared__ float red[16][17];
+    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long t = (long)blockIdx.x * 16 + o;
+    float a = 0.f;
+    if (t < IJ)
+        for (int s = sl; s < S; s += 16) a += part[(long)s * IJ + t];
+    red[sl][o] = a;
+    __syncthreads();
+    if (sl == 0 && t < IJ) {
+        float r = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) r += red[i][o];
+        const long row = t / J;
+        const int col = (int)(t - row * J);
+        C[row * ldc + col] = r + (bias ? bias[col] : 0.f);
+    }
+}
+
+// number of reduction splits: several workgroups per CU (the kernel is latency-bound: co-resident workgroups hide
+// the operand loads), at least 64 reduction steps each
 inline int splits_for(int I, int J, int K) {
     const long tiles = (long)fsg_cdiv(I, TI) * fsg_cdiv(J, TJ);
-    if (tiles >= 192 || K < 128) return 1;
-    long s = (256 + tiles - 1) / tiles;
+    if (tiles >= 256 || K < 128) return 1;
+    long s = (1024 + tiles - 1) / tiles;
     const long smax = K / 64;
     if (s > smax) s = smax;
-    if (s > 64) s = 64;
+    if (s > 128) s = 128;
     return s < 1 ? 1 : (int)s;
 }
 
@@ -124,8 +155,12 @@ extern "C" int fsg_gemm_small_f32(const float *A, int64_t sa_i, int64_t sa_k, co
     FSG_CHECK_LAUNCH("fsg_gemm_small_f32");
     if (part) {
         const long IJ = (long)I * J;
-        hipLaunchKernelGGL(gemm_small_reduce_kernel, dim3(fsg_cdiv(IJ, 256)), dim3(256), 0, st, part, S_eff, IJ, J, bias, C,
-                           (long)ldc);
+        if (S_eff >= 16)
+            hipLaunchKernelGGL(gemm_small_reduce_kernel, dim3(fsg_cdiv(IJ, 16)), dim3(256), 0, st, part, S_eff, IJ, J, bias, C,
+                               (long)ldc);
+        else
+            hipLaunchKernelGGL(gemm_small_reduce_flat_kernel, dim3(fsg_cdiv(IJ, 256)), dim3(256), 0, st, part, S_eff, IJ, J,
+                               bias, C, (long)ldc);
         FSG_CHECK_LAUNCH("fsg_gemm_small_f32/reduce");
     }
     return FSG_OK;

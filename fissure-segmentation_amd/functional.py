@@ -85,6 +85,8 @@ def edge_features(x, idx):
 
 
 # ------------------------------------------------------------------ point-major linear layer (1x1 conv as one GEMM)
+from os import environ as _environ
+_os_environ_get = _environ.get
 SMALL_GEMM_FLOPS = 6e8   # below this the vendor GEMM tends to pick one huge macro-tile (one workgroup): use fsg_gemm_small_f32
 
 
@@ -98,9 +100,14 @@ def gemm_small(a, sa_i, sa_k, b, sb_k, sb_j, bias, I, J, K):
     return out
 
 
-def _small(x2, n_out):
-    return (x2.is_cuda and x2.dtype == torch.float32 and x2.is_contiguous()
-            and 2.0 * x2.shape[0] * x2.shape[1] * n_out < SMALL_GEMM_FLOPS and x2.shape[0] > 0)
+def _small(I, J, K, *tensors):
+    """Route the product C (I,J) = A (I,K) B (K,J) to fsg_gemm_small_f32?  Yes when both output dimensions are <= 256 --
+    the vendor library then runs ONE workgroup and its time grows with I*J*K (tools/probe_vendor_gemm.py) -- and the
+    product is big enough for that to cost more than the ~8 us of the small kernel, yet below SMALL_GEMM_FLOPS."""
+    if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in tensors):
+        return False
+    vol = float(I) * J * K
+    return 0 < I <= 256 and 0 < J <= 256 and (1 << 21) <= vol and 2.0 * vol < SMALL_GEMM_FLOPS
 
 
 class _LinearPM(torch.autograd.Function):
@@ -115,8 +122,9 @@ class _LinearPM(torch.autograd.Function):
         ctx.has_bias = b is not None
         x2 = x.reshape(-1, x.shape[-1])
         N, K = w.shape
-        if _small(x2, N) and w.is_contiguous() and w.dtype == torch.float32:
-            y = gemm_small(x2, K, 1, w, 1, K, b.contiguous() if b is not None else None, x2.shape[0], N, K)
+        M = x2.shape[0]
+        if _small(M, N, K, x2, w):
+            y = gemm_small(x2, K, 1, w, 1, K, b.contiguous() if b is not None else None, M, N, K)
             return y.view(*x.shape[:-1], N)
         return torch.nn.functional.linear(x, w, b)
 
@@ -128,16 +136,15 @@ class _LinearPM(torch.autograd.Function):
         gx = gw = gb = None
         N, K = w.shape
         M = g2.shape[0]
-        small = _small(x2, N) and w.is_contiguous() and g2.dtype == torch.float32
-        if small and not g2.is_contiguous():
+        if not g2.is_contiguous():
             g2 = g2.contiguous()
         if ctx.needs_input_grad[0]:
-            gx = (gemm_small(g2, N, 1, w, K, 1, None, M, K, N) if small else g2 @ w).view_as(x)
+            gx = (gemm_small(g2, N, 1, w, K, 1, None, M, K, N) if _small(M, K, N, g2, w) else g2 @ w).view_as(x)
         if ctx.needs_input_grad[1]:
             S = 16 if (M % 16 == 0 and M >= 4096) else 1
-            if small:
+            if _small(N, K, M, g2, x2):
                 gw = gemm_small(g2, 1, N, x2, K, 1, None, N, K, M)
-            elif S > 1 and g2.is_contiguous() and x2.is_contiguous():
+            elif S > 1 and x2.is_contiguous():
                 gw = torch.bmm(g2.view(S, M // S, -1).transpose(1, 2), x2.view(S, M // S, -1)).sum(0)
             else:
                 gw = g2.t() @ x2

@@ -292,28 +292,37 @@ def test_knn_segment_cross_sets_and_fps(fsg, device):
     assert np.array_equal(N(idx), ridx) and np.array_equal(N(d2).view(np.uint32), rd2.view(np.uint32))
 
 
-@pytest.mark.parametrize("M,Nn,K", [(256, 256, 256), (64, 512, 512), (16384, 96, 32), (65536, 64, 35), (1000, 13, 7),
-                                   (1, 4, 32), (4096, 192, 64), (77, 130, 259)])
-def test_small_gemm_linear(fsg, device, M, Nn, K):
-    """fsg_gemm_small_f32 through linear_pm: y = x W^T + b, dX = dY W, dW = dY^T X (the last with the reduction over all M
-    rows split across workgroups) against fp64 matmuls; fp32 fma chains -> 1e-5 relative; reproducible."""
-    rng = np.random.default_rng(M + Nn + K)
-    x = rng.standard_normal((M, K)).astype(np.float32)
-    w = (rng.standard_normal((Nn, K)) / np.sqrt(K)).astype(np.float32)
-    b = rng.standard_normal(Nn).astype(np.float32)
-    g = rng.standard_normal((M, Nn)).astype(np.float32)
-    assert 2.0 * M * Nn * K < fsg.functional.SMALL_GEMM_FLOPS
-    xt, wt, bt = (G(a, device).requires_grad_(True) for a in (x, w, b))
-    fsg._lib.start_timing()
-    y = fsg.functional.linear_pm(xt, wt, bt)
-    y.backward(G(g, device))
-    assert set(fsg._lib.stop_timing()) == {"fsg_gemm_small_f32"}          # three products, none through the vendor GEMM
-    x64, w64, g64 = x.astype(np.float64), w.astype(np.float64), g.astype(np.float64)
-    for got, ref in [(y, x64 @ w64.T + b), (xt.grad, g64 @ w64), (wt.grad, g64.T @ x64), (bt.grad, g64.sum(0))]:
-        assert np.abs(N(got) - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()) * max(1.0, np.sqrt(max(M, K) / 256))
-    x2, w2 = G(x, device).requires_grad_(True), G(w, device).requires_grad_(True)
-    fsg.functional.linear_pm(x2, w2, None).backward(G(g, device))
-    assert torch.equal(w2.grad, wt.grad) and torch.equal(x2.grad, xt.grad)
+@pytest.mark.parametrize("I,J,K,sa,sb", [(256, 256, 256, "ik", "jk"), (64, 512, 512, "ik", "kj"), (96, 32, 16384, "ki", "kj"),
+                                         (64, 35, 65536, "ki", "kj"), (1000, 13, 7, "ik", "jk"), (1, 4, 32, "ik", "jk"),
+                                         (192, 64, 4096, "ki", "kj"), (77, 130, 259, "ik", "kj"), (256, 256, 768, "ik", "kj")])
+def test_small_gemm(fsg, device, I, J, K, sa, sb):
+    """fsg_gemm_small_f32 with every operand orientation (x W^T, dY W, dY^T X incl. reductions over all rows split across
+    workgroups) against fp64; fp32 fma chains -> ~1e-6 relative per term; bit-reproducible."""
+    rng = np.random.default_rng(I + J + K)
+    a = rng.standard_normal((I, K) if sa == "ik" else (K, I)).astype(np.float32)
+    b = rng.standard_normal((K, J) if sb == "kj" else (J, K)).astype(np.float32)
+    bias = rng.standard_normal(J).astype(np.float32)
+    at, bt = G(a, device), G(b, device)
+    args = (at, K if sa == "ik" else 1, 1 if sa == "ik" else I, bt, J if sb == "kj" else 1, 1 if sb == "kj" else K)
+    c = fsg.functional.gemm_small(*args, G(bias, device), I, J, K)
+    ref = (a if sa == "ik" else a.T).astype(np.float64) @ (b if sb == "kj" else b.T).astype(np.float64) + bias
+    assert np.abs(N(c) - ref).max() <= 3e-7 * np.sqrt(K) * max(1.0, np.abs(ref).max())
+    assert torch.equal(c, fsg.functional.gemm_small(*args, G(bias, device), I, J, K))
+
+
+def test_linear_pm_routing_and_grads(fsg, device):
+    """linear_pm sends exactly the products whose output fits one 256x256 vendor macro-tile to the small kernel"""
+    for M, Nn, K, n_small in [(256, 256, 256, 3), (256, 768, 256, 1), (16384, 96, 32, 1), (1024, 384, 128, 0)]:
+        rng = np.random.default_rng(M)
+        x, w, b = rng.standard_normal((M, K)), rng.standard_normal((Nn, K)) / np.sqrt(K), rng.standard_normal(Nn)
+        g = rng.standard_normal((M, Nn))
+        xt, wt, bt = (G(v.astype(np.float32), device).requires_grad_(True) for v in (x, w, b))
+        fsg._lib.start_timing()
+        y = fsg.functional.linear_pm(xt, wt, bt)
+        y.backward(G(g.astype(np.float32), device))
+        assert len(fsg._lib.stop_timing().get("fsg_gemm_small_f32", [])) == n_small, (M, Nn, K)
+        for got, ref in [(y, x @ w.T + b), (xt.grad, g @ w), (wt.grad, g.T @ x), (bt.grad, g.sum(0))]:
+            assert np.abs(N(got) - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
 
 
 @pytest.mark.parametrize("sizes", [[2048] * 8, [512, 100, 7, 513], [3000, 64, 2049], [1, 2, 65]])
