@@ -11,6 +11,16 @@ from ... import functional as F_hip
 from . import pointops
 
 
+class Linear(nn.Linear):
+    """nn.Linear (same parameters / state_dict keys) whose products go through functional.linear_pm: vendor GEMM for
+    the large ones, fsg_gemm_small_f32 where the vendor library would run a single workgroup."""
+
+    def forward(self, x):
+        if not x.is_cuda:
+            return super().forward(x)
+        return _lin(self, x)
+
+
 def _lin(layer, x):
     """nn.Linear applied as a point-major GEMM with the split-K weight gradient (functional.linear_pm)."""
     shape = x.shape
@@ -25,15 +35,15 @@ class PointTransformerLayer(nn.Module):
         super().__init__()
         self.mid_planes = mid_planes = out_planes // 1
         self.out_planes, self.share_planes, self.nsample = out_planes, share_planes, nsample
-        self.linear_q = nn.Linear(in_planes, mid_planes)
-        self.linear_k = nn.Linear(in_planes, mid_planes)
-        self.linear_v = nn.Linear(in_planes, out_planes)
-        self.linear_p = nn.Sequential(nn.Linear(3, 3), BatchNorm1d(3), nn.ReLU(inplace=True),
-                                      nn.Linear(3, out_planes))
+        self.linear_q = Linear(in_planes, mid_planes)
+        self.linear_k = Linear(in_planes, mid_planes)
+        self.linear_v = Linear(in_planes, out_planes)
+        self.linear_p = nn.Sequential(Linear(3, 3), BatchNorm1d(3), nn.ReLU(inplace=True),
+                                      Linear(3, out_planes))
         self.linear_w = nn.Sequential(BatchNorm1d(mid_planes), nn.ReLU(inplace=True),
-                                      nn.Linear(mid_planes, mid_planes // share_planes),
+                                      Linear(mid_planes, mid_planes // share_planes),
                                       BatchNorm1d(mid_planes // share_planes), nn.ReLU(inplace=True),
-                                      nn.Linear(out_planes // share_planes, out_planes // share_planes))
+                                      Linear(out_planes // share_planes, out_planes // share_planes))
         self.softmax = nn.Softmax(dim=1)
 
     @staticmethod
@@ -72,10 +82,10 @@ class TransitionDown(nn.Module):
         super().__init__()
         self.stride, self.nsample = stride, nsample
         if stride != 1:
-            self.linear = nn.Linear(3 + in_planes, out_planes, bias=False)
+            self.linear = Linear(3 + in_planes, out_planes, bias=False)
             self.pool = nn.MaxPool1d(nsample)
         else:
-            self.linear = nn.Linear(in_planes, out_planes, bias=False)
+            self.linear = Linear(in_planes, out_planes, bias=False)
         self.bn = BatchNorm1d(out_planes)
         self.relu = nn.ReLU(inplace=True)
 
@@ -104,13 +114,13 @@ class TransitionUp(nn.Module):
     def __init__(self, in_planes, out_planes=None):
         super().__init__()
         if out_planes is None:
-            self.linear1 = nn.Sequential(nn.Linear(2 * in_planes, in_planes), BatchNorm1d(in_planes),
+            self.linear1 = nn.Sequential(Linear(2 * in_planes, in_planes), BatchNorm1d(in_planes),
                                          nn.ReLU(inplace=True))
-            self.linear2 = nn.Sequential(nn.Linear(in_planes, in_planes), nn.ReLU(inplace=True))
+            self.linear2 = nn.Sequential(Linear(in_planes, in_planes), nn.ReLU(inplace=True))
         else:
-            self.linear1 = nn.Sequential(nn.Linear(out_planes, out_planes), BatchNorm1d(out_planes),
+            self.linear1 = nn.Sequential(Linear(out_planes, out_planes), BatchNorm1d(out_planes),
                                          nn.ReLU(inplace=True))
-            self.linear2 = nn.Sequential(nn.Linear(in_planes, out_planes), BatchNorm1d(out_planes),
+            self.linear2 = nn.Sequential(Linear(in_planes, out_planes), BatchNorm1d(out_planes),
                                          nn.ReLU(inplace=True))
 
     def forward(self, pxo1, pxo2=None):
@@ -133,11 +143,11 @@ class PointTransformerBlock(nn.Module):
 
     def __init__(self, in_planes, planes, share_planes=8, nsample=16):
         super().__init__()
-        self.linear1 = nn.Linear(in_planes, planes, bias=False)
+        self.linear1 = Linear(in_planes, planes, bias=False)
         self.bn1 = BatchNorm1d(planes)
         self.transformer2 = PointTransformerLayer(planes, planes, share_planes, nsample)
         self.bn2 = BatchNorm1d(planes)
-        self.linear3 = nn.Linear(planes, planes * self.expansion, bias=False)
+        self.linear3 = Linear(planes, planes * self.expansion, bias=False)
         self.bn3 = BatchNorm1d(planes * self.expansion)
         self.relu = nn.ReLU(inplace=True)
 
@@ -162,8 +172,8 @@ class PointTransformerSeg(nn.Module):
         for lvl in range(4, -1, -1):
             setattr(self, f'dec{lvl + 1}', self._make_dec(block, planes[lvl], 2, share_planes, nsample[lvl],
                                                           is_head=(lvl == 4)))
-        self.cls = nn.Sequential(nn.Linear(planes[0], planes[0]), BatchNorm1d(planes[0]), nn.ReLU(inplace=True),
-                                 nn.Linear(planes[0], k))
+        self.cls = nn.Sequential(Linear(planes[0], planes[0]), BatchNorm1d(planes[0]), nn.ReLU(inplace=True),
+                                 Linear(planes[0], k))
 
     def _make_enc(self, block, planes, blocks, share_planes=8, stride=1, nsample=16):
         mods = [TransitionDown(self.in_planes, planes * block.expansion, stride, nsample)]
