@@ -12,6 +12,8 @@
 // d = (xx_i - 2*dot) + xx_j.
 #include <float.h>
 
+#include <stdlib.h>
+
 #include "fsg_common.h"
 
 namespace {
@@ -117,6 +119,8 @@ int fsg_knn_pipe_launch(const float *x, int B, int N, int64_t stride_b, int64_t 
                         int32_t *idx_out, float *dist_out, float *xx_scratch, hipStream_t st);
 int fsg_knn_mfma_launch(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k, int flags,
                         int32_t *idx_out, float *dist_out, float *xx_scratch, hipStream_t st);  // knn_mfma.hip
+int fsg_knn_filter_launch(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k, int flags,
+                          int32_t *idx_out, float *dist_out, float *xx_scratch, hipStream_t st);  // knn_filter.hip
 
 extern "C" int fsg_knn_dense_f32(const float *x, int B, int N, int64_t stride_b, int64_t stride_c,
                                  int c_knn, int k, int flags, int32_t *idx_out, float *dist_out,
@@ -137,6 +141,11 @@ extern "C" int fsg_knn_dense_f32(const float *x, int B, int N, int64_t stride_b,
         // LDS block) was MEASURED SLOWER than the two-phase kernel (C=3: 85 vs 65 us, C=64: 147 vs 136 us): the selection is
         // VALU-throughput-bound (~1000 vector ops per query and chunk), so overlapping it with the MFMA phase buys nothing
         // while 512-candidate chunks double the number of selection passes.  Opt-in (flag 4096) for tests/experiments.
+        static const bool filter_default = getenv("FSG_KNN_FILTER") != nullptr;
+        if ((flags & 16384) || (filter_default && !(flags & 32768))) {   // 16384: filter kernel, 32768: two-phase kernel
+            const int rc = fsg_knn_filter_launch(x, B, N, stride_b, stride_c, c_knn, k, flags, idx_out, dist_out, xx_scratch, st);
+            if (rc != FSG_ERR_UNSUPPORTED) return rc;
+        }
         if (flags & 4096) {
             const int rc = fsg_knn_pipe_launch(x, B, N, stride_b, stride_c, c_knn, k, flags, idx_out, dist_out, xx_scratch, st);
             if (rc != FSG_ERR_UNSUPPORTED) return rc;

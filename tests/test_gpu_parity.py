@@ -54,8 +54,9 @@ def test_knn_mfma_kernel_equals_rows_kernel_at_full_size(fsg, device, B, C, Np, 
     x = G(cloud(5000 + Np + C, B, C, Np), device)
     r = fsg.functional.knn_graph(x, k, c_knn=c_knn, fix_diag=fix, drop_first=drop, return_dist=True,
                                  force_rows_kernel=True)
-    # two-phase kernel (production), its 512-candidate-chunk variant, wave-specialised pipeline (4096), first MFMA design (8)
-    for dbg in (0, 2048, 4096, 8):
+    # two-phase kernel (production), its 512-candidate-chunk variant, wave-specialised pipeline (4096), first MFMA design (8),
+    # threshold-filter design (16384)
+    for dbg in (0, 2048, 4096, 8, 16384):
         a = fsg.functional.knn_graph(x, k, c_knn=c_knn, fix_diag=fix, drop_first=drop, return_dist=True, _debug_flags=dbg)
         assert torch.equal(a[0], r[0]), dbg
         assert torch.equal(a[1].view(torch.int32), r[1].view(torch.int32)), dbg
@@ -66,9 +67,10 @@ def test_knn_massive_ties_take_the_slow_exact_path(fsg, device):
     x = np.zeros((2, 3, 2100), np.float32)
     x[:, :, 2000:] = np.random.default_rng(0).uniform(-1, 1, (2, 3, 100)).astype(np.float32)
     for k, drop in ((20, False), (40, True), (63, True)):
-        idx, dist = fsg.functional.knn_graph(G(x, device), k, drop_first=drop, return_dist=True)
         ridx, rdist = c_api.knn_dense(x, k, drop_first=drop)
-        assert np.array_equal(N(idx), ridx) and np.array_equal(N(dist).view(np.uint32), rdist.view(np.uint32))
+        for dbg in (0, 16384):   # production kernel; threshold-filter kernel (every candidate survives `d <= tau`)
+            idx, dist = fsg.functional.knn_graph(G(x, device), k, drop_first=drop, return_dist=True, _debug_flags=dbg)
+            assert np.array_equal(N(idx), ridx) and np.array_equal(N(dist).view(np.uint32), rdist.view(np.uint32)), dbg
 
 
 def test_knn_dense_ties_and_duplicates(fsg, device):
