@@ -238,8 +238,9 @@ def _build_csr(idx):
     B, N, k = idx.shape
     rowptr = torch.empty(B, N + 1, dtype=torch.int32, device=idx.device)
     col = torch.empty(B, N * k, dtype=torch.int32, device=idx.device)
+    ws = torch.empty(_lib.lib.fsg_graph_reverse_csr_workspace_bytes(B, N, k) // 4, dtype=torch.int32, device=idx.device)
     with torch.cuda.device(idx.device):
-        _lib.call("fsg_graph_reverse_csr", _p(idx), B, N, k, _p(rowptr), _p(col), _stream())
+        _lib.call("fsg_graph_reverse_csr", _p(idx), B, N, k, _p(rowptr), _p(col), _p(ws), _stream())
     return rowptr, col
 
 

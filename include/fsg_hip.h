@@ -71,9 +71,12 @@ int fsg_edge_gather_bwd_f32(const float *grad_edge, const int32_t *idx, float *g
  * Reverse graph (CSR by destination) of a kNN graph -- needed by the gather-style backward below.
  *   idx (B,N,k) int32 -> rowptr (B,N+1) int32, col (B,N*k) int32 with col = (source point << 6) | slot.
  *   The order of the in-edges of one destination is not deterministic (filled with LDS atomics).
+ *   workspace: fsg_graph_reverse_csr_workspace_bytes(B,N,k) bytes, or NULL (then one workgroup per cloud builds the
+ *   graph; with the workspace 16 workgroups per cloud share the edge list: count / scan / fill).
  */
+size_t fsg_graph_reverse_csr_workspace_bytes(int B, int N, int k);
 int fsg_graph_reverse_csr(const int32_t *idx, int B, int N, int k, int32_t *rowptr, int32_t *col,
-                          fsg_stream_t stream);
+                          void *workspace, fsg_stream_t stream);
 
 /*
  * Fused EdgeConv with ONE shared-MLP layer: replaces models/dgcnn.py:234-241 (gather, 1x1 Conv2d, BatchNorm2d,

@@ -172,6 +172,43 @@ def test_edge_features_vs_c_oracle(fsg, device, B, C, Np, k):
     np.testing.assert_allclose(N(xt.grad), c_api.edge_features_bwd(gr, idx), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,Np,k", [(8, 2048, 20), (4, 8192, 40), (3, 77, 5), (1, 1, 1)])
+def test_reverse_graph_csr(fsg, device, B, Np, k):
+    """CSR by destination (fsg_graph_reverse_csr): both builders (16 workgroups per cloud with a workspace, one without)
+    must hold exactly the in-edges (source << 6 | slot) of every destination; their order inside a row is free."""
+    import ctypes
+    rng = np.random.default_rng(B * Np + k)
+    idx = rng.integers(0, Np, (B, Np, k)).astype(np.int32)
+    idx[:, :, 0] = np.arange(Np)                       # self loops like a real kNN graph
+    if Np > 10:
+        idx[0, : Np // 2, 1] = 3                       # a hub: in-degree far above k
+    flat = idx.reshape(B, -1)
+    src = (np.arange(Np * k) // k) << 6 | (np.arange(Np * k) % k)
+    it = G(idx, device)
+    for use_ws in (True, False):
+        rowptr = torch.empty(B, Np + 1, dtype=torch.int32, device=device)
+        col = torch.full((B, Np * k), -1, dtype=torch.int32, device=device)
+        ws = torch.empty(fsg._lib.lib.fsg_graph_reverse_csr_workspace_bytes(B, Np, k) // 4 + 1, dtype=torch.int32, device=device)
+        fsg._lib.call("fsg_graph_reverse_csr", ctypes.c_void_p(it.data_ptr()), B, Np, k, ctypes.c_void_p(rowptr.data_ptr()),
+                      ctypes.c_void_p(col.data_ptr()), ctypes.c_void_p(ws.data_ptr() if use_ws else 0),
+                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        rp, cl = N(rowptr), N(col)
+        for b in range(B):
+            deg = np.bincount(flat[b], minlength=Np)
+            assert np.array_equal(rp[b], np.concatenate([[0], np.cumsum(deg)])), use_ws
+            order = np.argsort(flat[b], kind="stable")
+            want = src[order]                          # in-edges grouped by destination, ascending inside a group
+            got = cl[b].copy()
+            for j in np.nonzero(deg > 1)[0][:: max(1, Np // 64)]:      # sort a sample of rows + the hub
+                got[rp[b, j]:rp[b, j + 1]].sort()
+            got[rp[b, 3]:rp[b, 4]].sort() if Np > 10 else None
+            sel = np.zeros(Np * k, bool)
+            for j in list(np.nonzero(deg > 1)[0][:: max(1, Np // 64)]) + ([3] if Np > 10 else []):
+                sel[rp[b, j]:rp[b, j + 1]] = True
+            assert np.array_equal(got[sel], want[sel]), use_ws
+            assert np.array_equal(np.sort(cl[b]), np.sort(want)), use_ws
+
+
 # --------------------------------------------------------------------------- Chamfer
 @pytest.mark.parametrize("B,Np,M", [(2, 512, 384), (1, 1, 5), (3, 1500, 2048), (1, 4096, 4096)])
 def test_chamfer_nn_exact(fsg, device, B, Np, M):
