@@ -25,6 +25,7 @@ from fissure_segmentation_amd.losses.nnu_loss import NNULoss  # noqa: E402
 from fissure_segmentation_amd.models.dgcnn import DGCNNSeg  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_16x16x4_f32 / 32x32x2, exact fp32)
 WORKLOADS = {
     # name: (clouds per GPU, points, k, description)
     "c2": (8, 2048, 20, "DGCNN-seg N=2048 k=20, 8 clouds/GPU, dynamic graph, fp32 (BASELINE configs[1])"),
@@ -251,15 +252,30 @@ def main():
                     "timed_as": "HIP events around each C-ABI entry point on its stream, summed over the group",
                     "us_per_step_graph_replay": None if group_us is None else round(group_us, 1),
                     "kernels": {n: {k2: round(v, 2) for k2, v in d.items()} for n, d in sorted(per_kernel.items())}}
+        # the graph builds alone against the roofline that actually bounds them (VALU/MFMA-, not HBM-bound): the
+        # feature-space builds (C = 64; calls 2 and 3 of every step) do 2*B*N^2*C flop on the fp32 matrix cores
+        knn_calls = kernel_ms.get("fsg_knn_dense_f32", [])
+        roofline_knn = None
+        if len(knn_calls) >= 3 * n_timed:
+            feat = [v for i, v in enumerate(knn_calls) if i % 3 != 0]
+            avg_ms = sum(feat) / len(feat)
+            flops = 2.0 * B * N * N * 64
+            tf = flops / (avg_ms * 1e-3) / 1e12
+            roofline_knn = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(tf / MFMA_FP32_PEAK_TFLOPS, 4),
+                            "kernel": "fsg_knn_dense_f32 on 64 feature channels (knn_rows_mfma_kernel<16,...> + squared norms): "
+                                      "distance block on v_mfma_f32_16x16x4_f32 + exact top-k selection",
+                            "flops_per_launch": flops, "avg_us": round(1e3 * avg_ms, 1),
+                            "candidates_per_s": round(B * N * N / (avg_ms * 1e-3), 1)}
         out = {"metric": "points/sec fwd+bwd DGCNN-seg N=2048 k=20", "value": round(points / elapsed, 1),
                "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": desc, "clouds_per_gpu": B, "points_per_cloud": N, "k": k,
-                          "global_batch": B * world, "step": "fwd + cross-entropy + bwd + grad all-reduce + Adam",
+                          "global_batch": B * world, "step": "fwd + (cross-entropy + generalised Dice) + bwd + grad all-reduce + Adam",
                           "launch": launch,
                           "parallelism": f"dp{world}"},
-               "roofline": roofline}
+               "roofline": roofline, "roofline_knn": roofline_knn}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, N, k, classes)
         print(json.dumps(out))
