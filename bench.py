@@ -30,7 +30,12 @@ WORKLOADS = {
     # name: (clouds per GPU, points, k, description)
     "c2": (8, 2048, 20, "DGCNN-seg N=2048 k=20, 8 clouds/GPU, dynamic graph, fp32 (BASELINE configs[1])"),
     "c4": (4, 8192, 40, "DGCNN-seg N=8192 k=40, 4 clouds/GPU, dynamic graph (BASELINE configs[3] shape, fp32)"),
+    # secondary rows, same step definition and JSON line, no roofline object:
+    "c3": (8, 2048, None, "PointTransformer seg N=2048, 8 clouds/GPU, nsample 8/16 (BASELINE configs[2] shape, fp32)"),
+    "c5": (8, 4096, 20, "PC-AE DGCNNFoldingNet + Chamfer N=4096, 8 clouds/GPU, k=20 (BASELINE configs[4] shape, fp32)"),
 }
+METRIC = {"c2": "points/sec fwd+bwd DGCNN-seg N=2048 k=20", "c4": "points/sec fwd+bwd DGCNN-seg N=8192 k=40",
+          "c3": "points/sec fwd+bwd PointTransformer-seg N=2048", "c5": "points/sec fwd+bwd PC-AE FoldingNet+Chamfer N=4096"}
 EDGE_LAYERS_C = (3, 64, 64)  # input channels of ec1/ec2/ec3 (models/dgcnn.py:130-132 of the reference)
 
 
@@ -106,24 +111,38 @@ def main():
     classes = 4
 
     torch.manual_seed(0)
-    net = DGCNNSeg(k=k, in_features=3, num_classes=classes).to(device).train()
+    dgcnn = args.workload in ("c2", "c4")
+    if dgcnn:
+        net = DGCNNSeg(k=k, in_features=3, num_classes=classes).to(device).train()
+    elif args.workload == "c3":
+        from fissure_segmentation_amd.models.pointtransformer.seg_model import PointTransformerCompatibility
+        net = PointTransformerCompatibility(3, classes).to(device).train()
+    else:
+        from fissure_segmentation_amd.losses.chamfer_loss import ChamferLoss
+        from fissure_segmentation_amd.models.folding_net import DGCNNFoldingNet
+        net = DGCNNFoldingNet(k=k, n_embedding=512, shape_type="plane", n_input_points=N, decode_mesh=True).to(device).train()
     D.broadcast_parameters(net)
     use_graph = not args.eager
     # eager mode overlaps the head bucket's all-reduce with the EdgeConv backward through autograd hooks; under hipGraph
     # replay no Python runs inside the step, so the gradients go out as one bucket between the two graphs
     averager = D.BucketedGradAverager(
         net, early=(lambda n: False) if use_graph else
-        (lambda n: n.startswith("segmentation") or n.startswith("global_feature")))
+        (lambda n: dgcnn and (n.startswith("segmentation") or n.startswith("global_feature"))))
     # fused=True: one multi-tensor kernel for the whole model (the foreach/capturable path issues ~65 tiny kernels)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=use_graph, fused=True)
     x, y = synthetic_batch(B, N, classes, 1234 + rank, device)
     # the criterion train.py:38 builds by default (--loss nnunet, cli_args.py:16-17): class-weighted cross-entropy +
     # generalised Dice, here on the fused HIP loss kernel; weights as ds.get_class_weights() would hand over (train.py:34)
     criterion = NNULoss(torch.tensor([0.4, 1.2, 1.2, 1.2][:classes])).to(device)
+    if args.workload == "c5":     # train_pc_ae.py:172-185: reconstruct the input cloud, Chamfer loss (target = input)
+        chamfer = ChamferLoss()
 
     def fwd_bwd():
         averager.zero_grad()
-        loss, _parts = criterion(net(x), y)
+        if args.workload == "c5":
+            loss = chamfer(net(x), x)
+        else:
+            loss, _parts = criterion(net(x), y)
         loss.backward()
         return loss
 
@@ -196,6 +215,9 @@ def main():
     # inside the replayed training step
     group_us = None
     try:
+        if not dgcnn:
+            raise LookupError("no EdgeConv group in this workload")
+
         def group():
             with torch.no_grad():
                 x1 = net.ec1(x)
@@ -216,6 +238,8 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         group_us = 1e3 * e0.elapsed_time(e1) / reps
+    except LookupError:
+        pass
     except Exception as e:
         print(f"[bench] group timing by graph replay failed ({type(e).__name__}: {e})", file=sys.stderr)
     if not torch.isfinite(loss):
@@ -236,7 +260,7 @@ def main():
         # shared MLP, BatchNorm statistics and the max over k, so the group time is an upper bound of "kNN + gather"
         grp = ["fsg_knn_dense_f32", "fsg_edge_gather_fwd_f32", "fsg_edgeconv1_fwd_f32", "fsg_edgeconv2_fwd_f32"]
         grp_ms_per_step = sum(sum(kernel_ms.get(n, [])) for n in grp) / n_timed     # eager entry points, with launch gaps
-        alg_bytes = knn_gather_bytes_per_point(k) * B * N      # per step and GPU (3 EdgeConv layers)
+        alg_bytes = knn_gather_bytes_per_point(k or 0) * B * N      # per step and GPU (3 EdgeConv layers)
         achieved = alg_bytes / (grp_ms_per_step * 1e-3) / 1e9 if grp_ms_per_step > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -256,7 +280,9 @@ def main():
         # feature-space builds (C = 64; calls 2 and 3 of every step) do 2*B*N^2*C flop on the fp32 matrix cores
         knn_calls = kernel_ms.get("fsg_knn_dense_f32", [])
         roofline_knn = None
-        if len(knn_calls) >= 3 * n_timed:
+        if not dgcnn:
+            roofline = None   # secondary workloads: step time and per-entry-point timings only
+        if dgcnn and len(knn_calls) >= 3 * n_timed:
             feat = [v for i, v in enumerate(knn_calls) if i % 3 != 0]
             avg_ms = sum(feat) / len(feat)
             flops = 2.0 * B * N * N * 64
@@ -267,7 +293,7 @@ def main():
                                       "distance block on v_mfma_f32_16x16x4_f32 + exact top-k selection",
                             "flops_per_launch": flops, "avg_us": round(1e3 * avg_ms, 1),
                             "candidates_per_s": round(B * N * N / (avg_ms * 1e-3), 1)}
-        out = {"metric": "points/sec fwd+bwd DGCNN-seg N=2048 k=20", "value": round(points / elapsed, 1),
+        out = {"metric": METRIC[args.workload], "value": round(points / elapsed, 1),
                "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -276,7 +302,11 @@ def main():
                           "launch": launch,
                           "parallelism": f"dp{world}"},
                "roofline": roofline, "roofline_knn": roofline_knn}
-        if world == 1 and not args.no_cpu_baseline:
+        if not dgcnn:
+            out["config"]["step"] = ("fwd + cross-entropy + generalised Dice + bwd + Adam" if args.workload == "c3"
+                                     else "fwd + Chamfer(reconstruction, input) + bwd + Adam")
+            out["entry_points"] = {n: {k2: round(v, 2) for k2, v in d.items()} for n, d in sorted(per_kernel.items())}
+        if world == 1 and not args.no_cpu_baseline and dgcnn:
             out["cpu_baseline"] = cpu_baseline(B, N, k, classes)
         print(json.dumps(out))
     if world > 1:
