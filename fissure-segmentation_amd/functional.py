@@ -544,6 +544,63 @@ def bn_act(y, bn, slope):
                         float(slope))
 
 
+# ------------------------------------------------------------------ BatchNorm (+ residual) (+ ReLU) over packed rows
+BN_ROWS_WIDTHS = (32, 64, 128, 256, 512)
+
+
+class _BNRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, rm, rv, training, momentum, eps, relu):
+        M, C = x.shape
+        dev = x.device
+        out = torch.empty_like(x)
+        if training:
+            mean = torch.empty(C, dtype=torch.float32, device=dev)
+            rstd = torch.empty(C, dtype=torch.float32, device=dev)
+            ws = torch.empty(_lib.lib.fsg_bn_rows_workspace_bytes(M, C) // 8, dtype=torch.float64, device=dev)
+        else:
+            mean, rstd, ws = rm.detach().float().contiguous(), torch.rsqrt(rv.detach().float() + eps).contiguous(), None
+        with torch.cuda.device(dev):
+            _lib.call("fsg_bn_rows_fwd_f32", _p(x), _p(res), _p(gamma), _p(beta), _p(rm if training else None),
+                      _p(rv if training else None), M, C, int(training), momentum, eps, int(relu), _p(out), _p(mean),
+                      _p(rstd), _p(ws), _stream())
+        ctx.save_for_backward(x, out, gamma, mean, rstd)
+        ctx.meta = (M, C, bool(training), bool(relu), res is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, out, gamma, mean, rstd = ctx.saved_tensors
+        M, C, training, relu, has_res = ctx.meta
+        g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
+        gx = torch.empty_like(x)
+        gres = torch.empty_like(x) if has_res else None
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        ws = torch.empty(_lib.lib.fsg_bn_rows_workspace_bytes(M, C) // 8, dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.call("fsg_bn_rows_bwd_f32", _p(g), _p(x), _p(out), _p(gamma), _p(mean), _p(rstd), M, C, int(training),
+                      int(relu), _p(gx), _p(gres), _p(dgamma), _p(dbeta), _p(ws), _stream())
+        return gx, gres, dgamma, dbeta, None, None, None, None, None, None
+
+
+def bn_rows_supported(x, bn):
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] in BN_ROWS_WIDTHS and x.shape[0] > 0
+            and bn.affine and (bn.training or bn.running_mean is not None))
+
+
+def bn_rows(x, bn, relu=True, residual=None):
+    """[relu]( BatchNorm1d(x) [+ residual] ) for packed point rows x (M, C): one fused HIP stage (3 launches forward,
+    3 backward) instead of ATen's 4-5 + 3-5.  Same running-statistics semantics as torch.nn.BatchNorm1d."""
+    _need_gpu(x)
+    training, momentum = _bn_step(bn)
+    track = training and bn.track_running_stats
+    x = x if x.is_contiguous() else x.contiguous()
+    if residual is not None and not residual.is_contiguous():
+        residual = residual.contiguous()
+    return _BNRows.apply(x, residual, bn.weight, bn.bias, bn.running_mean if (track or not training) else None,
+                         bn.running_var if (track or not training) else None, training, momentum, float(bn.eps), relu)
+
+
 # ------------------------------------------------------------------ Chamfer (losses/chamfer_loss.py:19)
 class _ChamferNN(torch.autograd.Function):
     @staticmethod

@@ -28,6 +28,21 @@ def _lin(layer, x):
     return y.view(*shape[:-1], -1)
 
 
+def _bn_relu(bn, x, relu=True, residual=None):
+    """[relu](bn(x) [+ residual]) on packed rows: fused HIP stage when the width allows, plain modules otherwise."""
+    if F_hip.bn_rows_supported(x, bn):
+        return F_hip.bn_rows(x, bn, relu=relu, residual=residual)
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    return torch.relu(y) if relu else y
+
+
+def _lin_bn_relu(seq, x):
+    """nn.Sequential(Linear, BatchNorm1d, ReLU) -> fused glue"""
+    return _bn_relu(seq[1], seq[0](x))
+
+
 class PointTransformerLayer(nn.Module):
     """Vector attention over the nsample nearest neighbours (seg_model.py:17-53)."""
 
@@ -92,7 +107,7 @@ class TransitionDown(nn.Module):
     def forward(self, pxo):
         p, x, o = pxo
         if self.stride == 1:
-            return [p, self.relu(self.bn(_lin(self.linear, x))), o]
+            return [p, _bn_relu(self.bn, _lin(self.linear, x)), o]
         ends = pointops.host_offsets(o)
         new_ends, prev, total = [], 0, 0
         for e in ends:
@@ -104,7 +119,7 @@ class TransitionDown(nn.Module):
         n_p = p[idx.long(), :].contiguous()
         g = pointops.queryandgroup(self.nsample, p, n_p, x, None, o, n_o, use_xyz=True)  # (m, ns, 3+c)
         m, ns, c = g.shape
-        y = self.relu(self.bn(_lin(self.linear, g).reshape(m * ns, -1))).view(m, ns, -1)
+        y = _bn_relu(self.bn, _lin(self.linear, g).reshape(m * ns, -1)).view(m, ns, -1)
         return [n_p, y.max(dim=1)[0], n_o]
 
 
@@ -131,10 +146,10 @@ class TransitionUp(nn.Module):
             seg = pointops.segment_ids(ends, x.device)
             mean = torch.zeros(len(ends), x.shape[1], device=x.device, dtype=x.dtype).index_add_(0, seg, x)
             mean = mean / counts.unsqueeze(1).to(x.dtype)
-            return self.linear1(torch.cat((x, self.linear2(mean)[seg]), dim=1))
+            return _lin_bn_relu(self.linear1, torch.cat((x, self.linear2(mean)[seg]), dim=1))
         p1, x1, o1 = pxo1
         p2, x2, o2 = pxo2
-        return self.linear1(x1) + pointops.interpolation(p2, p1, self.linear2(x2), o2, o1)
+        return _lin_bn_relu(self.linear1, x1) + pointops.interpolation(p2, p1, _lin_bn_relu(self.linear2, x2), o2, o1)
 
 
 class PointTransformerBlock(nn.Module):
@@ -153,9 +168,9 @@ class PointTransformerBlock(nn.Module):
 
     def forward(self, pxo):
         p, x, o = pxo
-        y = self.relu(self.bn1(_lin(self.linear1, x)))
-        y = self.relu(self.bn2(self.transformer2([p, y, o])))
-        return [p, self.relu(self.bn3(_lin(self.linear3, y)) + x), o]
+        y = _bn_relu(self.bn1, _lin(self.linear1, x))
+        y = _bn_relu(self.bn2, self.transformer2([p, y, o]))
+        return [p, _bn_relu(self.bn3, _lin(self.linear3, y), residual=x), o]
 
 
 class PointTransformerSeg(nn.Module):
@@ -202,7 +217,7 @@ class PointTransformerSeg(nn.Module):
                 p, x, o = levels[lvl]
                 dec = getattr(self, f'dec{lvl + 1}')
                 coarse = [p, dec[1:]([p, dec[0]([p, x, o], coarse), o])[1], o]
-        return self.cls(coarse[1])
+        return self.cls[3](_bn_relu(self.cls[1], self.cls[0](coarse[1])))
 
 
 def pointtransformer_seg_repro(**kwargs):

@@ -233,6 +233,25 @@ int fsg_vec_attn_bwd_f32(const float *v, const float *pos, const float *w, const
                          int ns, int c, int cw, fsg_stream_t stream);
 
 /*
+ * BatchNorm1d (+ residual) (+ ReLU) over packed point rows: the `relu(bn(linear(x)))` / `relu(bn(linear(y)) + identity)`
+ * glue of models/pointtransformer/seg_model.py (:66, :82, :92-99, :138-141, :168).
+ *   x, residual (nullable), out: (M,C) fp32 row-major, C in {32,64,128,256,512};  out = [relu]( bn(x) [+ residual] )
+ *   training: batch statistics (fp64 sums, fixed order), running buffers updated with torch's rule (nullable);
+ *   eval: the caller provides mean / rstd.  workspace: fsg_bn_rows_workspace_bytes(M,C), 8-byte aligned.
+ * _bwd: grad_out (M,C) -> grad_x, grad_residual (nullable; = grad_out masked by the ReLU), grad_gamma, grad_beta,
+ *   all overwritten; `out` is the forward result (the ReLU mask), needed when relu != 0.
+ */
+size_t fsg_bn_rows_workspace_bytes(long M, int C);
+int fsg_bn_rows_fwd_f32(const float *x, const float *residual, const float *gamma, const float *beta,
+                        float *running_mean, float *running_var, long M, int C, int training, float momentum,
+                        float eps, int relu, float *out, float *mean, float *rstd, void *workspace,
+                        fsg_stream_t stream);
+int fsg_bn_rows_bwd_f32(const float *grad_out, const float *x, const float *out, const float *gamma,
+                        const float *mean, const float *rstd, long M, int C, int training, int relu,
+                        float *grad_x, float *grad_residual, float *grad_gamma, float *grad_beta,
+                        void *workspace, fsg_stream_t stream);
+
+/*
  * Small / skinny fp32 GEMM:  C[i,j] = sum_k A(i,k) * B(k,j) (+ bias[j]),  A(i,k) = A[i*sa_i + k*sa_k],
  * B(k,j) = B[k*sb_k + j*sb_j] (element strides: any transposition), C row-major with row stride ldc.
  * Carries the point-wise Linears of models/pointtransformer/seg_model.py (:25-33, :64-69, :92-99, :128-134, :168-169)

@@ -364,6 +364,43 @@ def test_linear_pm_routing_and_grads(fsg, device):
             assert np.abs(N(got) - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("M,C,relu,res,train", [(16384, 32, True, False, True), (4096, 64, True, True, True),
+                                                (65536, 64, True, False, True), (257, 128, False, False, True),
+                                                (256, 256, True, True, True), (64, 512, True, True, True),
+                                                (1000, 64, True, True, False), (3, 32, True, False, True)])
+def test_bn_rows_fused_vs_torch(fsg, device, M, C, relu, res, train):
+    """fsg_bn_rows_{fwd,bwd}: [relu](BatchNorm1d(x) [+ residual]) against torch's BatchNorm1d in fp64 (output, all
+    gradients, running statistics, num_batches_tracked)."""
+    rng = np.random.default_rng(M + C)
+    x = (rng.standard_normal((M, C)) * rng.uniform(0.05, 3, C) + rng.uniform(-5, 5, C)).astype(np.float32)
+    r = rng.standard_normal((M, C)).astype(np.float32)
+    g = rng.standard_normal((M, C)).astype(np.float32)
+    ref = torch.nn.BatchNorm1d(C).double()
+    ref.weight.data = torch.from_numpy(rng.uniform(-2, 2, C)); ref.bias.data = torch.from_numpy(rng.standard_normal(C))
+    ref.running_mean.data = torch.from_numpy(rng.standard_normal(C)); ref.running_var.data = torch.from_numpy(rng.uniform(0.5, 2, C))
+    from fissure_segmentation_amd.norm import BatchNorm1d
+    bn = BatchNorm1d(C)
+    bn.load_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in ref.state_dict().items()})
+    bn = bn.to(device)
+    ref.train(train), bn.train(train)
+    xr, rr = torch.from_numpy(x).double().requires_grad_(True), torch.from_numpy(r).double().requires_grad_(True)
+    yr = ref(xr) + (rr if res else 0)
+    yr = torch.relu(yr) if relu else yr
+    yr.backward(torch.from_numpy(g).double())
+    xt, rt = G(x, device).requires_grad_(True), G(r, device).requires_grad_(True)
+    y = fsg.functional.bn_rows(xt, bn, relu=relu, residual=rt if res else None)
+    y.backward(G(g, device))
+    tol = 2e-5 * max(1.0, float(yr.abs().max()))
+    assert np.abs(N(y) - yr.detach().numpy()).max() <= tol
+    for got, want in [(xt.grad, xr.grad), (bn.weight.grad, ref.weight.grad), (bn.bias.grad, ref.bias.grad)] + \
+                     ([(rt.grad, rr.grad)] if res else []):
+        want = want.numpy()
+        assert np.abs(N(got) - want).max() <= 1e-4 * max(1e-3, np.abs(want).max()), (got.shape,)
+    np.testing.assert_allclose(N(bn.running_mean), ref.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(N(bn.running_var), ref.running_var.numpy(), rtol=1e-5, atol=1e-6)
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
+
+
 @pytest.mark.parametrize("sizes", [[2048] * 8, [512, 100, 7, 513], [3000, 64, 2049], [1, 2, 65]])
 def test_fps_exact(fsg, device, sizes):
     """farthest point sampling (pointops.py:16-39), a quarter of every segment: single-wave register path (<= 512 and
