@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 import fissure_segmentation_amd as fsg  # noqa: E402
 from fissure_segmentation_amd import _lib, distributed as D  # noqa: E402
 from fissure_segmentation_amd.losses.nnu_loss import NNULoss  # noqa: E402
+from fissure_segmentation_amd.optim import FlatAdam  # noqa: E402
 from fissure_segmentation_amd.models.dgcnn import DGCNNSeg  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
@@ -99,6 +100,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam over the separate tensors instead of FlatAdam")
     args = ap.parse_args()
 
     torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)  # warm-up and capture use side streams
@@ -129,7 +131,10 @@ def main():
         net, early=(lambda n: False) if use_graph else
         (lambda n: dgcnn and (n.startswith("segmentation") or n.startswith("global_feature"))))
     # fused=True: one multi-tensor kernel for the whole model (the foreach/capturable path issues ~65 tiny kernels)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=use_graph, fused=True)
+    if args.torch_adam:
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=use_graph, fused=True)
+    else:   # same update, parameters re-pointed into one flat buffer: one cat + one fused kernel per step (optim.py)
+        opt = FlatAdam(net.parameters(), lr=1e-3, capturable=use_graph)
     x, y = synthetic_batch(B, N, classes, 1234 + rank, device)
     # the criterion train.py:38 builds by default (--loss nnunet, cli_args.py:16-17): class-weighted cross-entropy +
     # generalised Dice, here on the fused HIP loss kernel; weights as ds.get_class_weights() would hand over (train.py:34)
@@ -299,7 +304,8 @@ def main():
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": desc, "clouds_per_gpu": B, "points_per_cloud": N, "k": k,
                           "global_batch": B * world, "step": "fwd + (cross-entropy + generalised Dice) + bwd + grad all-reduce + Adam",
-                          "launch": launch,
+                          "launch": launch, "optimizer": "torch.optim.Adam(fused)" if args.torch_adam else
+                          "Adam over one flat parameter buffer (optim.FlatAdam: torch's fused Adam kernel, one launch)",
                           "parallelism": f"dp{world}"},
                "roofline": roofline, "roofline_knn": roofline_knn}
         if not dgcnn:

@@ -106,3 +106,23 @@ def test_plane_grids_match_reference_geometry():
     pts, faces = get_plane_mesh(n=16, xrange=(-0.3, 0.3), yrange=(-0.3, 0.3))
     assert pts.shape == (16, 2) and faces.shape == (18, 3)
     assert faces[:2].tolist() == [[0, 1, 4], [1, 4, 5]] and int(faces.max()) == 15
+
+
+def test_flat_adam_equals_torch_adam():
+    """optim.FlatAdam (one flat buffer, one fused kernel) == torch.optim.Adam over the separate tensors, step by step"""
+    import copy
+    from fissure_segmentation_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    a = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.BatchNorm1d(7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    b = copy.deepcopy(a)
+    oa, ob = torch.optim.Adam(a.parameters(), lr=1e-2), FlatAdam(b.parameters(), lr=1e-2)
+    keys = list(b.state_dict().keys())
+    for step in range(4):
+        x = torch.randn(16, 5)
+        for net, opt in ((a, oa), (b, ob)):
+            opt.zero_grad(set_to_none=True)
+            net(x).square().mean().backward()
+            opt.step()
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            torch.testing.assert_close(pa, pb, rtol=1e-6, atol=1e-7)
+    assert list(b.state_dict().keys()) == keys
