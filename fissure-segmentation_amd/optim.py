@@ -47,10 +47,20 @@ class FlatAdam:
             elif p.grad is not None:
                 p.grad.zero_()
 
-    def step(self):
+    def gather_grads(self):
+        """concatenate the parameters' gradients into the flat gradient buffer (`self.flat.grad`); under data parallelism
+        that buffer is what gets all-reduced -- one collective, no unflatten"""
         grads = [p.grad.reshape(-1) if p.grad is not None else torch.zeros_like(v) for p, v in zip(self.params, self._views)]
         torch.cat(grads, out=self.flat.grad)
+        return self.flat.grad
+
+    def step_flat(self):
+        """Adam update from the flat gradient buffer as it stands"""
         self.inner.step()
+
+    def step(self):
+        self.gather_grads()
+        self.step_flat()
 
     def state_dict(self):
         return self.inner.state_dict()
