@@ -1,44 +1,76 @@
 // Chamfer nearest neighbour + its gradient -- include/fsg_hip.h: fsg_chamfer_nn_f32 / _bwd_f32.
 // Replaces the pytorch3d.loss.chamfer_distance call of losses/chamfer_loss.py:19.
 //
-// VALU-bound (B*N*M pair evaluations, ~8 flop each; inputs are a few hundred KB): one lane per query
-// point, the other cloud streamed through LDS in 1024-point tiles that every lane reads as a
-// broadcast.  d = fma(dz,dz, fma(dy,dy, dx*dx)) -- bit-exact with oracle/fsg_oracle.c.
+// VALU-bound (B*N*M pair evaluations, ~8 flop each; inputs are a few hundred KB): two query points per lane, the other
+// cloud streamed through LDS in 1024-point tiles (float4 per point: one broadcast ds_read_b128 per candidate) that the
+// eight waves of a workgroup split between them.  d = fma(dz,dz, fma(dy,dy, dx*dx)) -- bit-exact with
+// oracle/fsg_oracle.c.  (First version: one lane per query, 128-thread workgroups = 2 waves per CU at 8 x 4096 points:
+// 122 us; the backward used atomicAdd = CAS loops: 123 us.)
 #include "fsg_common.h"
 
 namespace {
 
-constexpr int BLOCK = 128;
-constexpr int TILE = 1024;
+__device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
 
-__global__ __launch_bounds__(BLOCK) void chamfer_nn_kernel(const float *__restrict__ x, const float *__restrict__ y,
-                                                            int N, int M, float *__restrict__ dist,
-                                                            int32_t *__restrict__ arg) {
-    __shared__ float ty[TILE * 3];
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
+constexpr int WAVES = 8;             // 512 threads
+constexpr int QW = 128;              // queries per workgroup: two per lane
+constexpr int TILE = 1024;           // candidates staged in LDS per sweep step; each wave scans TILE / WAVES of them
+
+// One workgroup = 128 query points (two per lane, so a candidate read from LDS serves two distance updates) x eight
+// waves that split every 1024-candidate tile between them; the eight partial (distance, index) minima of a query are
+// merged at the end (lower index on equal distance, like the sequential scan of the oracle).
+__global__ __launch_bounds__(WAVES * 64) void chamfer_nn_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                                 int N, int M, float *__restrict__ dist,
+                                                                 int32_t *__restrict__ arg) {
+    __shared__ float4 ty[TILE];
+    __shared__ float pd[WAVES][QW];
+    __shared__ int pj[WAVES][QW];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.x * QW + lane, i1 = i0 + 64;
     const float *yb = y + (long)b * M * 3;
-    float px = 0.f, py = 0.f, pz = 0.f;
-    if (i < N) {
-        const float *p = x + ((long)b * N + i) * 3;
-        px = p[0]; py = p[1]; pz = p[2];
-    }
-    float best = INFINITY;
-    int bj = 0;
-    for (int j0 = 0; j0 < M; j0 += TILE) {
-        const int cnt = min(TILE, M - j0);
+    float ax = 0.f, ay = 0.f, az = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
+    if (i0 < N) { const float *p = x + ((long)b * N + i0) * 3; ax = p[0]; ay = p[1]; az = p[2]; }
+    if (i1 < N) { const float *p = x + ((long)b * N + i1) * 3; bx = p[0]; by = p[1]; bz = p[2]; }
+    float best0 = INFINITY, best1 = INFINITY;
+    int j0b = 0, j1b = 0;
+    constexpr int PER = TILE / WAVES;
+    for (int t0 = 0; t0 < M; t0 += TILE) {
+        const int cnt = min(TILE, M - t0);
         __syncthreads();
-        for (int t = threadIdx.x; t < cnt * 3; t += BLOCK) ty[t] = yb[(long)j0 * 3 + t];
+        for (int t = tid; t < cnt; t += WAVES * 64) {
+            const float *q = yb + (long)(t0 + t) * 3;
+            ty[t] = make_float4(q[0], q[1], q[2], 0.f);
+        }
         __syncthreads();
-        for (int j = 0; j < cnt; ++j) {
-            const float dx = px - ty[3 * j], dy = py - ty[3 * j + 1], dz = pz - ty[3 * j + 2];
-            const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-            if (d < best) { best = d; bj = j0 + j; }
+        const int lo = wave * PER, hi = min(cnt, lo + PER);
+#pragma unroll 4
+        for (int j = lo; j < hi; ++j) {
+            const float4 c = ty[j];   // same address in every lane: LDS broadcast
+            const float d0 = sqdist3(ax, ay, az, c.x, c.y, c.z), d1 = sqdist3(bx, by, bz, c.x, c.y, c.z);
+            if (d0 < best0) { best0 = d0; j0b = t0 + j; }
+            if (d1 < best1) { best1 = d1; j1b = t0 + j; }
         }
     }
-    if (i < N) {
-        dist[(long)b * N + i] = best;
-        arg[(long)b * N + i] = bj;
+    pd[wave][lane] = best0; pj[wave][lane] = j0b;
+    pd[wave][lane + 64] = best1; pj[wave][lane + 64] = j1b;
+    __syncthreads();
+    if (tid < QW) {
+        float bd = pd[0][tid];
+        int bj = pj[0][tid];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) {
+            const float d = pd[w][tid];
+            const int j = pj[w][tid];
+            if (d < bd || (d == bd && j < bj)) { bd = d; bj = j; }
+        }
+        const int i = blockIdx.x * QW + tid;
+        if (i < N) {
+            dist[(long)b * N + i] = bd;
+            arg[(long)b * N + i] = bj;
+        }
     }
 }
 
@@ -56,8 +88,8 @@ __global__ __launch_bounds__(256) void chamfer_bwd_kernel(const float *__restric
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const float v = s * (x[xi + d] - y[ya + d]);
-        atomicAdd(gx + xi + d, v);
-        atomicAdd(gy + ya + d, -v);
+        gx[xi + d] += v;                       // this thread is the only writer of its own point in this launch
+        unsafeAtomicAdd(gy + ya + d, -v);      // hardware fp32 atomic (the default atomicAdd compiles to a CAS loop)
     }
 }
 
@@ -68,7 +100,7 @@ extern "C" int fsg_chamfer_nn_f32(const float *x, const float *y, int B, int N, 
     FSG_REQUIRE(x && y && dist && arg, "fsg_chamfer_nn_f32: NULL pointer");
     FSG_REQUIRE(B >= 0 && N > 0 && M > 0 && B <= 65535, "fsg_chamfer_nn_f32: bad shape B=%d N=%d M=%d", B, N, M);
     if (B == 0) return FSG_OK;
-    hipLaunchKernelGGL(chamfer_nn_kernel, dim3(fsg_cdiv(N, BLOCK), B), dim3(BLOCK), 0, (hipStream_t)stream, x, y, N, M,
+    hipLaunchKernelGGL(chamfer_nn_kernel, dim3(fsg_cdiv(N, QW), B), dim3(WAVES * 64), 0, (hipStream_t)stream, x, y, N, M,
                        dist, arg);
     FSG_CHECK_LAUNCH("fsg_chamfer_nn_f32");
     return FSG_OK;
