@@ -98,7 +98,10 @@ struct SegArgs {
     int nseg;
 };
 
-template <int KS, int WAVES, int SURV, int CH, int CK, bool SEG = false>
+// QAL = true: the query (A) operand lives in LDS instead of 2*KS registers per lane and the two 16-query blocks run one
+// after the other -- the register budget then allows 16 waves per workgroup at 64 channels (128 VGPRs), and both phases
+// are latency-bound, i.e. scale with the number of resident waves.
+template <int KS, int WAVES, int SURV, int CH, int CK, bool SEG = false, bool QAL = false>
 __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *__restrict__ x, const float *__restrict__ xx,
                                                              int N, long sb, long sc, int c_knn, int k, int flags,
                                                              int32_t *__restrict__ idx_out,
@@ -110,6 +113,8 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
     u64 *carry = reinterpret_cast<u64 *>(smem + sizeof(float) * QB * STRIDE);             // [QB][CK] best list so far
     u64 *surv = carry + QB * CK;                                                          // [WAVES][SURV]
     int *ccount = reinterpret_cast<int *>(surv + WAVES * SURV);                           // [QB]
+    constexpr int QS = QB + 1;                                                            // row stride of the A operand copy
+    float *qal = reinterpret_cast<float *>(ccount + QB);                                  // [4*KS][QS] (QAL only)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -141,14 +146,22 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
     if (tid < QB) ccount[tid] = 0;
 
     // A operand: queries, rows l15 of the two 16-row blocks, channel 4s + l4; resident for the whole sweep
-    float qa[2][KS];
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int ch = 4 * s + l4, q = q0 + blk * 16 + l15;
-            qa[blk][s] = (!SEG && ch < c_knn && q < N) ? xb[ch * sc + q] : 0.f;
+    float qa[QAL ? 1 : 2][QAL ? 1 : KS];
+    if (QAL) {
+        for (int t = tid; t < 4 * KS * QB; t += WAVES * 64) {
+            const int ch = t / QB, qq = t % QB;
+            qal[ch * QS + qq] = (ch < c_knn && q0 + qq < N) ? xb[ch * sc + q0 + qq] : 0.f;
         }
+        qa[0][0] = 0.f;
+    } else {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int ch = 4 * s + l4, q = q0 + blk * 16 + l15;
+                qa[QAL ? 0 : blk][QAL ? 0 : s] = (!SEG && ch < c_knn && q < N) ? xb[ch * sc + q] : 0.f;
+            }
+    }
     __shared__ float qsh[SEG ? QB * 3 : 1];   // SEG: coordinates of the 32 queries
     if (SEG) {
         if (tid < QB * 3) {
@@ -166,6 +179,7 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
             xxq[blk][e] = (!SEG && q < N) ? xxb[q] : 0.f;
         }
     const bool fix_diag = (flags & FSG_KNN_FIX_DIAG) != 0;
+    if (QAL) __syncthreads();   // A operand copy complete
 
     for (int c0 = 0; c0 < N; c0 += CH) {
         const int len = min(CH, N - c0);
@@ -195,7 +209,7 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
             }
             xn = jc < N ? xxb[jc] : 0.f;
         };
-        constexpr bool PREFETCH = KS <= 16;  // the 128-channel instantiation has no registers to spare
+        constexpr bool PREFETCH = KS <= 16 && !QAL;  // no registers to spare at 128 channels / in the 16-wave variant
         if (!SEG && PREFETCH && wave < ntile && !(flags & 512)) load_tile(wave);
         for (int t = wave; t < (SEG ? 0 : CH / 16); t += WAVES) {
             if (t >= ntile || (flags & 512)) {  // beyond the cloud (flag 512: timing ablation of phase A)
@@ -215,10 +229,22 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
             // two independent accumulator chains (the two 16-query blocks) interleaved: a dependent 16x16x4 MFMA issues
             // every 40 cycles, two alternating chains keep the pipe at its 32-cycle rate
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            if (QAL) {
+                float qh[KS];
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[0][s], bv[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[1][s], bv[s], acc1, 0, 0, 0);
+                for (int s = 0; s < KS; ++s) qh[s] = qal[(4 * s + l4) * QS + l15];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qh[s], bv[s], acc0, 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) qh[s] = qal[(4 * s + l4) * QS + 16 + l15];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qh[s], bv[s], acc1, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[0][QAL ? 0 : s], bv[s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[QAL ? 0 : 1][QAL ? 0 : s], bv[s], acc1, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
@@ -399,19 +425,22 @@ int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int
                        (long)stride_c, c_knn, xx_scratch);
     FSG_CHECK_LAUNCH("fsg_knn_dense_f32/sqnorm");
     dim3 grid(fsg_cdiv(N, QB), B);
-#define FSG_KNN_RM(KS, WV, SV, CHK, CKK)                                                                               \
+#define FSG_KNN_RM(KS, WV, SV, CHK, CKK) FSG_KNN_RMQ(KS, WV, SV, CHK, CKK, false)
+#define FSG_KNN_RMQ(KS, WV, SV, CHK, CKK, QL)                                                                          \
     do {                                                                                                               \
-        const size_t lds = sizeof(float) * QB * ((CHK) + 4) + sizeof(u64) * (QB * (CKK) + (WV) * (SV)) + sizeof(int) * QB; \
+        const size_t lds = sizeof(float) * QB * ((CHK) + 4) + sizeof(u64) * (QB * (CKK) + (WV) * (SV)) + sizeof(int) * QB + \
+                           ((QL) ? sizeof(float) * 4 * (KS) * (QB + 1) : 0);                                           \
         static bool granted = false;                                                                                   \
         if (!granted) {                                                                                                \
-            if (hipFuncSetAttribute((const void *)knn_rows_mfma_kernel<KS, WV, SV, CHK, CKK>,                          \
+            if (hipFuncSetAttribute((const void *)knn_rows_mfma_kernel<KS, WV, SV, CHK, CKK, false, QL>,               \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {             \
                 fsg_set_error("fsg_knn_dense_f32: cannot raise dynamic LDS to %zu", lds);                              \
                 return FSG_ERR_HIP;                                                                                    \
             }                                                                                                          \
             granted = true;                                                                                            \
         }                                                                                                              \
-        hipLaunchKernelGGL((knn_rows_mfma_kernel<KS, WV, SV, CHK, CKK>), grid, dim3((WV) * 64), lds, st, x, xx_scratch, N, \
+        hipLaunchKernelGGL((knn_rows_mfma_kernel<KS, WV, SV, CHK, CKK, false, QL>), grid, dim3((WV) * 64), lds, st, x,      \
+                           xx_scratch, N,                                                                              \
                            (long)stride_b, (long)stride_c, c_knn, k, flags, idx_out, dist_out, SegArgs{});             \
     } while (0)
     const bool small_k = k + drop <= 32;                      // carried list fits 32 slots
@@ -420,9 +449,14 @@ int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int
     const bool half = small_k && (flags & 2048);
     if (c_knn <= 4) { if (small_k) FSG_KNN_RM(1, 16, 96, 1024, 64); else FSG_KNN_RM(1, 8, 128, 1024, 64); }
     else if (c_knn <= 16) FSG_KNN_RM(4, 8, 128, 1024, 64);
-    else if (c_knn <= 64) { if (half) FSG_KNN_RM(16, 8, 64, 512, 32); else FSG_KNN_RM(16, 8, 128, 1024, 64); }
+    else if (c_knn <= 64) {
+        if (half) FSG_KNN_RM(16, 8, 64, 512, 32);
+        else if (small_k && !(flags & 8192)) FSG_KNN_RMQ(16, 16, 96, 1024, 32, true);   // flag 8192: the 8-wave variant
+        else FSG_KNN_RM(16, 8, 128, 1024, 64);
+    }
     else { if (half) FSG_KNN_RM(32, 8, 64, 512, 32); else FSG_KNN_RM(32, 8, 128, 1024, 64); }
 #undef FSG_KNN_RM
+#undef FSG_KNN_RMQ
     FSG_CHECK_LAUNCH("fsg_knn_dense_f32/rows_mfma");
     return FSG_OK;
 }
