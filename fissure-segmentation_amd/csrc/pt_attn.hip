@@ -478,8 +478,7 @@ __global__ __launch_bounds__(Geo<C>::NT) void pt_b1_kernel(const float *__restri
     for (int r = 0; r < NPAIR; ++r)
         if (r * G::NT + tid < CS * CS) my[r * G::NT + tid] = dwb[r];
     __syncthreads();
-    float *RED = SM;  // NT*3 floats needed: EMAX*RS >= NT/8*... not guaranteed -> use PROD thrice
-    (void)RED;
+    // the three per-output sums go through PROD one after the other (NT floats)
     for (int which = 0; which < 3; ++which) {
         PROD[tid] = which == 0 ? dbb : (which == 1 ? dg2 : db2);
         __syncthreads();

@@ -1,6 +1,8 @@
 """Tensor-level entry points over the C ABI: argument checking, output allocation, stream/device
 plumbing and the autograd glue.  Every function requires CUDA (HIP) tensors -- no CPU path."""
+import contextlib as _contextlib
 import ctypes
+import os as _os
 
 import torch
 
@@ -85,8 +87,6 @@ def edge_features(x, idx):
 
 
 # ------------------------------------------------------------------ point-major linear layer (1x1 conv as one GEMM)
-from os import environ as _environ
-_os_environ_get = _environ.get
 SMALL_GEMM_FLOPS = 6e8   # below this the vendor GEMM tends to pick one huge macro-tile (one workgroup): use fsg_gemm_small_f32
 
 
@@ -173,8 +173,6 @@ class _EdgeWeights(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------ BatchNorm call counters
-import contextlib as _contextlib
-
 _deferred_counters = None
 
 
@@ -219,7 +217,6 @@ def with_deferred_bn_counters(forward):
 
 
 # ------------------------------------------------------------------ fused EdgeConv (models/dgcnn.py:234-241)
-import os as _os
 
 # Building the reverse graphs on a side stream during the forward was MEASURED SLOWER inside the replayed hipGraph
 # (2.06 vs 1.83 ms/step on MI355X: the fork/join edges cost more than the ~30 us builder hides), so it is opt-in.
