@@ -60,6 +60,33 @@ __global__ __launch_bounds__(BLOCK) void knn_segment_kernel(const float *__restr
         }
 }
 
+// wave arg-max of a 64-bit key on the DPP network (6 VALU steps instead of 6 LDS-crossbar shuffles); the result is valid in
+// lanes 48..63.  Key = float bits of a non-negative value << 32 | (0x7fffffff - index): larger value wins, lower index
+// on ties.
+__device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long k, const int ctrl, const int row_mask) {
+    const int lo = (int)(unsigned)k, hi = (int)(unsigned)(k >> 32);
+    int olo, ohi;
+    switch (ctrl) {   // the control word must be a compile-time constant
+        case 0: olo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xf, 0xf, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xf, 0xf, false); break;
+        case 1: olo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xf, 0xf, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xf, 0xf, false); break;
+        case 2: olo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xf, 0xf, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xf, 0xf, false); break;
+        case 3: olo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xf, 0xf, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xf, 0xf, false); break;
+        case 4: olo = __builtin_amdgcn_update_dpp(lo, lo, 0x142, 0xa, 0xf, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0x142, 0xa, 0xf, false); break;
+        default: olo = __builtin_amdgcn_update_dpp(lo, lo, 0x143, 0xc, 0xf, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0x143, 0xc, 0xf, false); break;
+    }
+    (void)row_mask;
+    const unsigned long long o = ((unsigned long long)(unsigned)ohi << 32) | (unsigned)olo;
+    return o > k ? o : k;
+}
+__device__ __forceinline__ unsigned long long wave_argmax_key(float bv, int bj) {
+    unsigned long long k = bv >= 0.f ? (((unsigned long long)__float_as_uint(bv) << 32) | (unsigned)(0x7fffffff - bj)) : 0ull;
+#pragma unroll
+    for (int st = 0; st < 6; ++st) k = dpp_max_step(k, st, 0);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;   // wave-uniform
+}
+
 // Farthest point sampling of one segment by ONE wave: the segment's points and running minimum distances live in
 // registers (PPL per lane, point j = start + lane + 64 r), the coordinates also in LDS so that the next pivot is a
 // broadcast LDS read instead of a dependent global load; an iteration is PPL distance updates + a 6-step shuffle
@@ -94,20 +121,77 @@ __device__ __forceinline__ void fps_one_wave(const float *__restrict__ xyz, int 
             md[r] = v;
             if (j < len && v > bv) { bv = v; bj = j; }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float ov = __shfl_xor(bv, off);
-            const int oj = __shfl_xor(bj, off);
-            if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
-        }
-        cur = bj;
+        cur = 0x7fffffff - (int)(unsigned)wave_argmax_key(bv, bj);
         if (lane == 0) idx[t] = st + cur;
     }
 }
 
+// Same, one WORKGROUP of FW waves per segment (segments up to 64*FW*PPL points): every wave keeps PPL points per lane in
+// registers, the per-wave arg-max goes through LDS and one barrier per iteration.  Shorter serial chain than the
+// single-wave version for the 2048-point segments of BASELINE config 3 (4 instead of 32 distance updates per lane).
+constexpr int FW = 8;
+template <int PPL>
+__device__ __forceinline__ void fps_multi_wave(const float *__restrict__ xyz, int st, int len, int qs, int qe,
+                                               int32_t *__restrict__ idx, float *lds, unsigned long long *wkey) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float px[PPL], py[PPL], pz[PPL], md[PPL];
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+        const int j = tid + 64 * FW * r;
+        const bool ok = j < len;
+        px[r] = ok ? xyz[3L * (st + j)] : 0.f;
+        py[r] = ok ? xyz[3L * (st + j) + 1] : 0.f;
+        pz[r] = ok ? xyz[3L * (st + j) + 2] : 0.f;
+        md[r] = 1e10f;
+        if (ok) { lds[3 * j] = px[r]; lds[3 * j + 1] = py[r]; lds[3 * j + 2] = pz[r]; }
+    }
+    __syncthreads();
+    int cur = 0;
+    if (tid == 0) idx[qs] = st;
+    for (int t = qs + 1; t < qe; ++t) {
+        const float cx = lds[3 * cur], cy = lds[3 * cur + 1], cz = lds[3 * cur + 2];
+        float bv = -1.f;
+        int bj = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < PPL; ++r) {
+            const int j = tid + 64 * FW * r;
+            const float d = sqdist3(px[r], py[r], pz[r], cx, cy, cz);
+            const float v = fminf(d, md[r]);
+            md[r] = v;
+            if (j < len && v > bv) { bv = v; bj = j; }
+        }
+        const unsigned long long wk = wave_argmax_key(bv, bj);
+        const int slot = (t & 1) * FW;   // double-buffered: the next iteration's writes cannot overtake this one's reads
+        if (lane == 0) wkey[slot + wave] = wk;
+        __syncthreads();
+        unsigned long long best = wkey[slot];
+#pragma unroll
+        for (int w = 1; w < FW; ++w) best = wkey[slot + w] > best ? wkey[slot + w] : best;
+        bj = 0x7fffffff - (int)(unsigned)best;
+        cur = bj;
+        if (tid == 0) idx[t] = st + cur;
+    }
+}
+
+__global__ __launch_bounds__(FW * 64) void fps_kernel_mw(const float *__restrict__ xyz, const int32_t *__restrict__ offset,
+                                                         const int32_t *__restrict__ new_offset, int32_t *__restrict__ idx) {
+    __shared__ float pts[2048 * 3];
+    __shared__ unsigned long long wkey[2 * FW];
+    const int s = blockIdx.x;
+    const int st = s ? offset[s - 1] : 0, en = offset[s];
+    const int qs = s ? new_offset[s - 1] : 0, qe = new_offset[s];
+    if (qe <= qs || en <= st) return;
+    const int len = en - st;   // host guarantees len <= 2048 for this kernel (it only knows n: n <= 2048 * segments is
+                               // not enough, so oversized segments are left to the generic kernel via the flag array)
+    if (len > 2048) return;
+    if (len <= 512) fps_multi_wave<1>(xyz, st, len, qs, qe, idx, pts, wkey);
+    else if (len <= 1024) fps_multi_wave<2>(xyz, st, len, qs, qe, idx, pts, wkey);
+    else fps_multi_wave<4>(xyz, st, len, qs, qe, idx, pts, wkey);
+}
+
 __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ offset,
                                                      const int32_t *__restrict__ new_offset, float *__restrict__ md,
-                                                     int32_t *__restrict__ idx) {
+                                                     int32_t *__restrict__ idx, int mw_done) {
     __shared__ float wv[BLOCK / 64];
     __shared__ int wj[BLOCK / 64];
     __shared__ float pts[2048 * 3];
@@ -115,7 +199,9 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
     const int st = s ? offset[s - 1] : 0, en = offset[s];
     const int qs = s ? new_offset[s - 1] : 0, qe = new_offset[s];
     if (qe <= qs || en <= st) return;
-    if (en - st <= 2048) {  // register-resident single-wave path (uniform per workgroup: the other waves just leave)
+    if (en - st <= 2048) {
+        if (mw_done) return;   // already sampled by fps_kernel_mw (eight waves per segment)
+        // register-resident single-wave path (uniform per workgroup: the other waves just leave)
         if (wave != 0) return;
         if (en - st <= 512) fps_one_wave<8>(xyz, st, en - st, qs, qe, idx, pts);
         else fps_one_wave<32>(xyz, st, en - st, qs, qe, idx, pts);
@@ -250,8 +336,18 @@ extern "C" int fsg_fps_f32(const float *xyz, const int32_t *offset, const int32_
                            int32_t *idx, fsg_stream_t stream) {
     FSG_REQUIRE(xyz && offset && new_offset && tmp && idx, "fsg_fps_f32: NULL pointer");
     FSG_REQUIRE(b > 0 && n > 0, "fsg_fps_f32: bad shape b=%d n=%d", b, n);
-    hipLaunchKernelGGL(fps_kernel, dim3(b), dim3(BLOCK), 0, (hipStream_t)stream, xyz, offset, new_offset, tmp, idx);
-    FSG_CHECK_LAUNCH("fsg_fps_f32");
+    // segments of up to 2048 points: eight waves per segment, points in registers; longer ones: the generic kernel, which
+    // skips what the first launch already sampled.  n <= 2048 means no segment can be longer: one launch.
+    static const bool one_wave = getenv("FSG_FPS_ONE_WAVE") != nullptr;   // cross-check: the single-wave path
+    if (!one_wave) {
+        hipLaunchKernelGGL(fps_kernel_mw, dim3(b), dim3(FW * 64), 0, (hipStream_t)stream, xyz, offset, new_offset, idx);
+        FSG_CHECK_LAUNCH("fsg_fps_f32/mw");
+    }
+    if (one_wave || n > 2048) {
+        hipLaunchKernelGGL(fps_kernel, dim3(b), dim3(BLOCK), 0, (hipStream_t)stream, xyz, offset, new_offset, tmp, idx,
+                           one_wave ? 0 : 1);
+        FSG_CHECK_LAUNCH("fsg_fps_f32");
+    }
     return FSG_OK;
 }
 
