@@ -11,6 +11,8 @@
 // when the output alone cannot fill the chip; the partial products are then summed in split order by a second
 // kernel (no atomics: reproducible).  MFMA fp32 is an exact fp32 fma chain, so results match a plain fp32 GEMM up to
 // summation order.
+#include <stdlib.h>
+
 #include "fsg_common.h"
 
 namespace {
@@ -119,12 +121,13 @@ __global__ __launch_bounds__(256) void gemm_small_reduce_kernel(const float *__r
 }
 
 // number of reduction splits: several workgroups per CU (the kernel is latency-bound: co-resident workgroups hide
-// the operand loads), at least 64 reduction steps each
+// the operand loads), at least FSG_GEMM_SPLIT_MIN (default 64) reduction steps each (measured on the PointTransformer step: 32: 8.9, 64: 8.9, 128: 9.05, 256: 9.5 ms)
 inline int splits_for(int I, int J, int K) {
+    static const int min_k = getenv("FSG_GEMM_SPLIT_MIN") ? atoi(getenv("FSG_GEMM_SPLIT_MIN")) : 64;
     const long tiles = (long)fsg_cdiv(I, TI) * fsg_cdiv(J, TJ);
-    if (tiles >= 256 || K < 128) return 1;
+    if (tiles >= 256 || K < 2 * min_k) return 1;
     long s = (1024 + tiles - 1) / tiles;
-    const long smax = K / 64;
+    const long smax = K / min_k;
     if (s > smax) s = smax;
     if (s > 128) s = 128;
     return s < 1 ? 1 : (int)s;
