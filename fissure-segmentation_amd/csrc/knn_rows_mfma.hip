@@ -200,16 +200,18 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
             }
         }
         float bn[KS], xn = 0.f;   // operand of the NEXT tile of this wave: its loads fly while the current MFMAs run
+        // 32-bit element offsets from the (uniform) cloud base: one VGPR per address instead of a 64-bit pair
+        const unsigned sc32 = (unsigned)sc;
         auto load_tile = [&](int t) {
             const int jc = c0 + t * 16 + l15;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int ch = 4 * s + l4;
-                bn[s] = (ch < c_knn && jc < N) ? xb[ch * sc + jc] : 0.f;
+                bn[s] = (ch < c_knn && jc < N) ? xb[(unsigned)ch * sc32 + (unsigned)jc] : 0.f;
             }
-            xn = jc < N ? xxb[jc] : 0.f;
+            xn = jc < N ? xxb[(unsigned)jc] : 0.f;
         };
-        constexpr bool PREFETCH = KS <= 16 && !QAL;  // no registers to spare at 128 channels / in the 16-wave variant
+        constexpr bool PREFETCH = KS <= 16;  // no registers to spare at 128 channels
         if (!SEG && PREFETCH && wave < ntile && !(flags & 512)) load_tile(wave);
         for (int t = wave; t < (SEG ? 0 : CH / 16); t += WAVES) {
             if (t >= ntile || (flags & 512)) {  // beyond the cloud (flag 512: timing ablation of phase A)
