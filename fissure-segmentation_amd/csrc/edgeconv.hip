@@ -246,22 +246,26 @@ __global__ __launch_bounds__(512) void ec1_stats_select_kernel(const float *__re
     }
 }
 
-// BatchNorm statistics from R per-workgroup records (n, mean, M2) per channel, in fp64, in two small launches:
-//   stage 1 (S workgroups per channel group): A = sum n, Bm = sum n*mean, Cm = sum (M2 + n*mean^2) over a slice of the
-//            records (one workgroup reading all records was bandwidth-bound on a single CU: 22 us for 1024 records);
-//   stage 2: mean = Bm/A, M2 = Cm - Bm^2/A (fp64: the subtraction is benign), invstd, running-statistics update.
+// BatchNorm statistics from R per-workgroup records (n, mean, M2) per channel, in fp64:
+//   A = sum n, Bm = sum n*mean, Cm = sum (M2 + n*mean^2) over the records, then mean = Bm/A, M2 = Cm - Bm^2/A (fp64: the
+//   subtraction is benign), invstd, running-statistics update.  (A 64-thread workgroup reading all records alone took
+//   22 us for 1024 records: load latency, one record in flight per lane.)
 constexpr int FIN_S = 16;
 
-__global__ __launch_bounds__(256) void bn_partial_sums_kernel(const float *__restrict__ partials, int R, int Co,
-                                                               double *__restrict__ stage) {
-    __shared__ double red[3][4][64];
+// One launch: a 1024-thread workgroup per 64 channels; sixteen 64-lane groups stride over the records (Chan's merge in
+// fp64), the sixteen partial triples meet in LDS and the first group finalises.  (Two launches -- 16 workgroups of
+// partial sums, then a merge -- cost one more ~4 us dependent-launch boundary per BatchNorm.)
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restrict__ partials, int R, int Co, float eps,
+                                                            float momentum, float *__restrict__ mean_out,
+                                                            float *__restrict__ invstd_out,
+                                                            float *__restrict__ running_mean,
+                                                            float *__restrict__ running_var) {
+    __shared__ double red[3][FIN_S][64];
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    const int per = (R + FIN_S - 1) / FIN_S;
-    const int r0 = blockIdx.y * per, r1 = min(R, r0 + per);
     double a = 0.0, bm = 0.0, cm = 0.0;
 #pragma unroll 4
-    for (int r = r0 + sub; r < r1; r += 4) {
+    for (int r = sub; r < R; r += FIN_S) {
         const float *pr = partials + (long)r * 3 * Co;
         const double n = pr[c], mu = pr[Co + c];
         a += n;
@@ -272,27 +276,15 @@ __global__ __launch_bounds__(256) void bn_partial_sums_kernel(const float *__res
     red[1][sub][lane] = bm;
     red[2][sub][lane] = cm;
     __syncthreads();
-    if (sub == 0) {
-        double *st = stage + ((long)blockIdx.y * 3) * Co;
-        st[c] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
-        st[Co + c] = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
-        st[2 * Co + c] = red[2][0][lane] + red[2][1][lane] + red[2][2][lane] + red[2][3][lane];
-    }
-}
-
-__global__ __launch_bounds__(64) void bn_merge_finalize_kernel(const double *__restrict__ stage, int Co, float eps,
-                                                                float momentum, float *__restrict__ mean_out,
-                                                                float *__restrict__ invstd_out,
-                                                                float *__restrict__ running_mean,
-                                                                float *__restrict__ running_var) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    double n = 0.0, bm = 0.0, cm = 0.0;
+    if (sub != 0) return;
+    double n = 0.0;
+    bm = 0.0;
+    cm = 0.0;
 #pragma unroll
-    for (int s = 0; s < FIN_S; ++s) {
-        const double *st = stage + ((long)s * 3) * Co;
-        n += st[c];
-        bm += st[Co + c];
-        cm += st[2 * Co + c];
+    for (int s2 = 0; s2 < FIN_S; ++s2) {
+        n += red[0][s2][lane];
+        bm += red[1][s2][lane];
+        cm += red[2][s2][lane];
     }
     const double mu = n > 0.0 ? bm / n : 0.0;
     double M2 = n > 0.0 ? cm - bm * mu : 0.0;
@@ -463,11 +455,7 @@ size_t fsg_ec_finalize_stage_floats(int Co) { return (size_t)FIN_S * 3 * Co * 2 
 
 int fsg_ec_finalize_launch(const float *partials, int R, int Co, float eps, float momentum, float *mean, float *invstd,
                            float *running_mean, float *running_var, hipStream_t st) {
-    uintptr_t addr = (uintptr_t)(partials + (size_t)R * 3 * Co);
-    double *stage = (double *)((addr + 7) & ~(uintptr_t)7);
-    hipLaunchKernelGGL(bn_partial_sums_kernel, dim3(Co / 64, FIN_S), dim3(256), 0, st, partials, R, Co, stage);
-    FSG_CHECK_LAUNCH("edgeconv/partial_sums");
-    hipLaunchKernelGGL(bn_merge_finalize_kernel, dim3(Co / 64), dim3(64), 0, st, stage, Co, eps, momentum, mean, invstd,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(Co / 64), dim3(1024), 0, st, partials, R, Co, eps, momentum, mean, invstd,
                        running_mean, running_var);
     FSG_CHECK_LAUNCH("edgeconv/finalize");
     return FSG_OK;
