@@ -113,8 +113,9 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
     u64 *carry = reinterpret_cast<u64 *>(smem + sizeof(float) * QB * STRIDE);             // [QB][CK] best list so far
     u64 *surv = carry + QB * CK;                                                          // [WAVES][SURV]
     int *ccount = reinterpret_cast<int *>(surv + WAVES * SURV);                           // [QB]
-    constexpr int QS = QB + 1;                                                            // row stride of the A operand copy
-    float *qal = reinterpret_cast<float *>(ccount + QB);                                  // [4*KS][QS] (QAL only)
+    // A operand copy (QAL only): [2 query halves][4*KS channels][16 queries].  Lane (l4, l15) reads channel 4s + l4,
+    // query l15 of a half -> word 16 (4s + l4) + l15: the 64 lanes of a wave hit the 64 LDS banks exactly once.
+    float *qal = reinterpret_cast<float *>(ccount + QB);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
     if (QAL) {
         for (int t = tid; t < 4 * KS * QB; t += WAVES * 64) {
             const int ch = t / QB, qq = t % QB;
-            qal[ch * QS + qq] = (ch < c_knn && q0 + qq < N) ? xb[ch * sc + q0 + qq] : 0.f;
+            qal[(qq >> 4) * (64 * KS) + ch * 16 + (qq & 15)] = (ch < c_knn && q0 + qq < N) ? xb[ch * sc + q0 + qq] : 0.f;
         }
         qa[0][0] = 0.f;
     } else {
@@ -234,11 +235,11 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
             if (QAL) {
                 float qh[KS];
 #pragma unroll
-                for (int s = 0; s < KS; ++s) qh[s] = qal[(4 * s + l4) * QS + l15];
+                for (int s = 0; s < KS; ++s) qh[s] = qal[(4 * s + l4) * 16 + l15];
 #pragma unroll
                 for (int s = 0; s < KS; ++s) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qh[s], bv[s], acc0, 0, 0, 0);
 #pragma unroll
-                for (int s = 0; s < KS; ++s) qh[s] = qal[(4 * s + l4) * QS + 16 + l15];
+                for (int s = 0; s < KS; ++s) qh[s] = qal[64 * KS + (4 * s + l4) * 16 + l15];
 #pragma unroll
                 for (int s = 0; s < KS; ++s) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qh[s], bv[s], acc1, 0, 0, 0);
             } else {
@@ -431,7 +432,7 @@ int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int
 #define FSG_KNN_RMQ(KS, WV, SV, CHK, CKK, QL)                                                                          \
     do {                                                                                                               \
         const size_t lds = sizeof(float) * QB * ((CHK) + 4) + sizeof(u64) * (QB * (CKK) + (WV) * (SV)) + sizeof(int) * QB + \
-                           ((QL) ? sizeof(float) * 4 * (KS) * (QB + 1) : 0);                                           \
+                           ((QL) ? sizeof(float) * 4 * (KS) * QB : 0);                                                 \
         static bool granted = false;                                                                                   \
         if (!granted) {                                                                                                \
             if (hipFuncSetAttribute((const void *)knn_rows_mfma_kernel<KS, WV, SV, CHK, CKK, false, QL>,               \
