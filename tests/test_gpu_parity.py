@@ -870,3 +870,38 @@ def test_hipgraph_replay_matches_eager_training(fsg, device):
     # of random sign, so the bar is 3 steps x lr; the loss trajectory above is the sharp check
     for a, b in zip(w0, w1):
         torch.testing.assert_close(a, b, rtol=5e-3, atol=3.5e-3)
+
+
+def test_graphed_train_step_helper(fsg, device):
+    """fissure_segmentation_amd.graph.GraphedTrainStep: the captured step (DGCNN-seg, CE + generalised Dice, FlatAdam)
+    must follow the same loss trajectory as the eager loop, also when fresh batches are copied into its static buffers."""
+    import copy
+    from fissure_segmentation_amd.graph import GraphedTrainStep
+    from fissure_segmentation_amd.losses.nnu_loss import NNULoss
+    from fissure_segmentation_amd.models.dgcnn import DGCNNSeg
+    from fissure_segmentation_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    base = DGCNNSeg(k=8, in_features=3, num_classes=4).to(device).train()
+    crit = NNULoss(torch.tensor([0.5, 1.0, 1.5, 2.0])).to(device)
+    batches = [(G(cloud(20 + i, 2, 3, 256), device), torch.randint(0, 4, (2, 256), device=device)) for i in range(4)]
+
+    eager = copy.deepcopy(base)
+    opt_e = FlatAdam(eager.parameters(), lr=1e-3, capturable=True)
+    graphed = copy.deepcopy(base)
+    opt_g = FlatAdam(graphed.parameters(), lr=1e-3, capturable=True)
+    step = GraphedTrainStep(graphed, crit, opt_g, *batches[0], warmup=2)
+    assert step.captured
+    for _ in range(2):                                # the helper took 2 warm-up steps on batch 0 (capturing executes nothing)
+        opt_e.zero_grad()
+        crit(eager(batches[0][0]), batches[0][1])[0].backward()
+        opt_e.step()
+    le, lg = [], []
+    for xb, yb in batches[1:] + batches[1:]:
+        opt_e.zero_grad()
+        loss = crit(eager(xb), yb)[0]
+        loss.backward()
+        opt_e.step()
+        le.append(float(loss))
+        lg.append(float(step(xb, yb)))
+    np.testing.assert_allclose(lg, le, rtol=2e-3)
+    assert le[-1] < le[0]
