@@ -77,28 +77,36 @@ __global__ __launch_bounds__(256) void ec2_fwd_kernel(const float *__restrict__ 
 
     for (int tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
         const int i0 = tile * TP;
-        // ---- phase 1: z1 rows into LDS (lanes = layer-1 channels)
-        for (int p = wave; p < TP; p += 4) {
-            const int i = i0 + p;
-            if (i < N) {
-                const int myj = lane < k ? idx[((long)b * N + i) * k + lane] : 0;
-                const float q = Q[(long)i * ld + lane];
-                for (int s0 = 0; s0 < k; s0 += 4) {
-                    float y[4];
+        // ---- phase 1: z1 rows into LDS (lanes = layer-1 channels).  The R edge rows of a tile are contiguous in idx: every
+        // wave takes 16 of them per pass and has all 16 neighbour rows (+ their centre rows) in flight at once -- the
+        // gather is pure L2 latency, so the number of sequential round trips is what phase 1 costs.
+        {
+            const long ebase = ((long)b * N + i0) * k;
+            for (int r0 = wave * 16; r0 < Rpad; r0 += 64) {
+                const int rr = r0 + (lane & 15);
+                int myj = 0;
+                if (rr < R && i0 + rr / k < N) myj = idx[ebase + rr];
+                float y[16], qv[16];
+                int p = r0 / k, sl = r0 - p * k;   // point / slot of row r0 + u, advanced incrementally (uniform)
+                const int p_first = p, s_first = sl;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int j = __builtin_amdgcn_readlane(myj, min(s0 + u, k - 1));
-                        y[u] = P[(long)j * ld + lane];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)  // z1 = LeakyReLU(BN1(y1)), lane = layer-1 channel
-                        if (s0 + u < k) Y[(p * k + s0 + u) * LD1 + lane] = lrelu(__builtin_fmaf(y[u] + q, a1, b1), slope);
+                for (int u = 0; u < 16; ++u) {
+                    const bool ok = r0 + u < R && i0 + p < N;
+                    const int j = __builtin_amdgcn_readlane(myj, u);
+                    y[u] = ok ? P[(long)j * ld + lane] : 0.f;
+                    qv[u] = ok ? Q[(long)(i0 + p) * ld + lane] : 0.f;
+                    if (++sl == k) { sl = 0; ++p; }
                 }
-            } else {
-                for (int s = 0; s < k; ++s) Y[(p * k + s) * LD1 + lane] = 0.f;
+                p = p_first;
+                sl = s_first;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const bool ok = r0 + u < R && i0 + p < N;
+                    Y[(r0 + u) * LD1 + lane] = ok ? lrelu(__builtin_fmaf(y[u] + qv[u], a1, b1), slope) : 0.f;
+                    if (++sl == k) { sl = 0; ++p; }
+                }
             }
         }
-        for (int r = R + wave; r < Rpad; r += 4) Y[r * LD1 + lane] = 0.f;
         __syncthreads();
 
         // ---- phase 2: y2 = z1 W2^T on the matrix cores; wave takes (row tile, column tile) pairs
@@ -251,32 +259,35 @@ __global__ __launch_bounds__(256) void ec2_bwd_kernel(
         const int i0 = tile * TP;
         const int pvalid = min(TP, N - i0);   // valid points of this tile
         const int rvalid = pvalid * k;        // valid rows
-        // ---- phase 1: y1 rows (lanes = layer-1 channels), h2/arg2 rows of the tile's points
+        // ---- phase 1: y1 rows (lanes = layer-1 channels), 16 rows per wave and pass with all gathers in flight (see the
+        // forward kernel); h2/arg2 rows of the tile's points
+        {
+            const long ebase = ((long)b * N + i0) * k;
+            for (int r0 = wave * 16; r0 < Rpad; r0 += 64) {
+                const int rr = r0 + (lane & 15);
+                int myj = 0;
+                if (rr < R && i0 + rr / k < N) myj = idx[ebase + rr];
+                float y[16], qv[16];
+                int p = r0 / k, sl = r0 - p * k;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const bool ok = r0 + u < R && i0 + p < N;
+                    const int j = __builtin_amdgcn_readlane(myj, u);
+                    y[u] = ok ? P[(long)j * ld + lane] : 0.f;
+                    qv[u] = ok ? Q[(long)(i0 + p) * ld + lane] : 0.f;
+                    if (++sl == k) { sl = 0; ++p; }
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) Y1[(r0 + u) * LD1 + lane] = y[u] + qv[u];   // rows beyond the tile: 0 + 0
+            }
+        }
         for (int p = wave; p < TP; p += 4) {
             const int i = i0 + p;
-            if (i < N) {
-                const int myj = lane < k ? idx[((long)b * N + i) * k + lane] : 0;
-                const float q = Q[(long)i * ld + lane];
-                for (int s0 = 0; s0 < k; s0 += 4) {
-                    float y[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int j = __builtin_amdgcn_readlane(myj, min(s0 + u, k - 1));
-                        y[u] = P[(long)j * ld + lane];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (s0 + u < k) Y1[(p * k + s0 + u) * LD1 + lane] = y[u] + q;
-                }
-            } else {
-                for (int s = 0; s < k; ++s) Y1[(p * k + s) * LD1 + lane] = 0.f;
-            }
             for (int c = lane; c < C2; c += 64) {
                 Hs[p * C2 + c] = i < N ? h2[((long)b * N + i) * C2 + c] : 0.f;
                 As[p * C2 + c] = i < N ? arg2[((long)b * N + i) * C2 + c] : (uint8_t)255;
             }
         }
-        for (int r = R + wave; r < Rpad; r += 4) Y1[r * LD1 + lane] = 0.f;
         __syncthreads();
 
         // ---- phase 2+3: y2 = z1 W2^T (MFMA), then dy2 = a2 (h2[s=arg] - db2 - yhat2 dg2) -> D
