@@ -37,12 +37,16 @@ __device__ __forceinline__ float o2f(unsigned k) {
     return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 }
 
+// inclusive prefix sum over the 64 lanes on the DPP network (Kogge-Stone inside each row of 16, then the row totals are
+// broadcast down): 6 VALU steps; the shuffle version (ds_bpermute) paid ~100 cycles of LDS-crossbar latency per step
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(v, off);
-        if (lane >= off) v += o;
-    }
+    (void)lane;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2 and 3
     return v;
 }
 
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
                 mine += (v[e] <= tau_f && j < N) ? 1 : 0;
             }
             const int incl = wave_incl_scan(mine, lane);
-            const int total = cc + __shfl(incl, 63);
+            const int total = cc + __builtin_amdgcn_readlane(incl, 63);
             if (total <= SURV) {
                 int pos = cc + incl - mine;
 #pragma unroll
@@ -328,23 +332,38 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
             }
             if (total <= SURV) {
                 __builtin_amdgcn_wave_barrier();
-                // rank by counting: every lane holds up to two survivors and counts how many of the `total` entries are
-                // smaller (entries are distinct: the index is part of the key); rank < K goes to slot `rank`
+                // rank of every entry among the `total` entries (distinct keys: the index is part of the key); rank < K goes
+                // to slot `rank`.  sv[0..cc) is the carried best list, ascending, so only the NEW survivors sv[cc..total) are
+                // counted by looping (LDS broadcast reads); against the sorted prefix a carried entry knows its rank (its
+                // position) and a survivor finds it with a 7-step binary search.
+                auto prefix_rank = [&](int i, u64 e) {
+                    if (i < cc) return i;
+                    int lo = 0;
+#pragma unroll
+                    for (int step = 64; step >= 1; step >>= 1) {
+                        const int m = lo + step;
+                        if (m <= cc && sv[m - 1] < e) lo = m;
+                    }
+                    return lo;
+                };
                 const u64 e0 = lane < total ? sv[lane] : ~0ull;
                 int r0 = 0;
-                if (SURV <= 64 || total <= 64) {   // the usual case: one survivor per lane
+                if (SURV <= 64 || total <= 64) {   // the usual case: one entry per lane
 #pragma unroll 8
-                    for (int t = 0; t < total; ++t) r0 += sv[t] < e0 ? 1 : 0;   // same address in every lane: LDS broadcast
+                    for (int t = cc; t < total; ++t) r0 += sv[t] < e0 ? 1 : 0;   // same address in every lane
+                    r0 += prefix_rank(lane, e0);
                     if (lane < total && r0 < KK) carry[qi * CK + r0] = e0;
                 } else {
                     const u64 e1 = (64 + lane) < total ? sv[(64 + lane) % SURV] : ~0ull;
                     int r1 = 0;
 #pragma unroll 8
-                    for (int t = 0; t < total; ++t) {
+                    for (int t = cc; t < total; ++t) {
                         const u64 xk = sv[t];
                         r0 += xk < e0 ? 1 : 0;
                         r1 += xk < e1 ? 1 : 0;
                     }
+                    r0 += prefix_rank(lane, e0);
+                    r1 += prefix_rank(64 + lane, e1);
                     if (lane < total && r0 < KK) carry[qi * CK + r0] = e0;
                     if ((64 + lane) < total && r1 < KK) carry[qi * CK + r1] = e1;
                 }

