@@ -159,6 +159,34 @@ __global__ __launch_bounds__(1024) void csr_fill_kernel(const int32_t *__restric
     }
 }
 
+// In-edge order: the slots of a destination are handed out by LDS atomics, i.e. in no particular order, and the backward
+// sums its in-edges in slot order -- the gradients would differ in the last bits from run to run.  One wave per
+// destination sorts its slice ascending by (source, slot) (rank by counting through an LDS copy), which makes the
+// reverse graph, and with it the whole EdgeConv backward, reproducible.  Rows above CSR_SORT_CAP in-edges stay as filled.
+constexpr int CSR_SORT_CAP = 1024;
+__global__ __launch_bounds__(256) void csr_sort_rows_kernel(const int32_t *__restrict__ rowptr, int32_t *__restrict__ col, int N,
+                                                            int NK) {
+    __shared__ int32_t buf[4][CSR_SORT_CAP];
+    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + wave;
+    if (j >= N) return;
+    const int32_t *rp = rowptr + (long)b * (N + 1);
+    const int beg = rp[j], deg = rp[j + 1] - beg;
+    if (deg < 2 || deg > CSR_SORT_CAP) return;
+    int32_t *row = col + (long)b * NK + beg;
+    int32_t *mine = buf[wave];
+    for (int t = lane; t < deg; t += 64) mine[t] = row[t];
+    __builtin_amdgcn_wave_barrier();
+    for (int t0 = 0; t0 < deg; t0 += 64) {
+        const int t = t0 + lane;
+        const int32_t e = t < deg ? mine[t] : 0x7fffffff;
+        int rank = 0;
+#pragma unroll 8
+        for (int u = 0; u < deg; ++u) rank += mine[u] < e ? 1 : 0;   // entries are distinct: (source << 6 | slot)
+        if (t < deg) row[rank] = e;
+    }
+}
+
 // ------------------------------------------------------------------ forward
 __global__ __launch_bounds__(512) void ec1_stats_select_kernel(const float *__restrict__ pq,
                                                                 const int32_t *__restrict__ idx,
@@ -509,6 +537,8 @@ extern "C" int fsg_graph_reverse_csr(const int32_t *idx, int B, int N, int k, in
         FSG_CHECK_LAUNCH("fsg_graph_reverse_csr/scan");
         hipLaunchKernelGGL(csr_fill_kernel, dim3(B, G), dim3(1024), ldsN, st, idx, N, k, G, cnt, col);
         FSG_CHECK_LAUNCH("fsg_graph_reverse_csr/fill");
+        hipLaunchKernelGGL(csr_sort_rows_kernel, dim3(fsg_cdiv(N, 4), B), dim3(256), 0, st, rowptr, col, N, N * k);
+        FSG_CHECK_LAUNCH("fsg_graph_reverse_csr/sort");
         return FSG_OK;
     }
     const size_t lds = sizeof(int) * ((size_t)N + 1024);
@@ -523,6 +553,8 @@ extern "C" int fsg_graph_reverse_csr(const int32_t *idx, int B, int N, int k, in
     }
     hipLaunchKernelGGL(csr_build_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, idx, N, k, rowptr, col);
     FSG_CHECK_LAUNCH("fsg_graph_reverse_csr");
+    hipLaunchKernelGGL(csr_sort_rows_kernel, dim3(fsg_cdiv(N, 4), B), dim3(256), 0, (hipStream_t)stream, rowptr, col, N, N * k);
+    FSG_CHECK_LAUNCH("fsg_graph_reverse_csr/sort");
     return FSG_OK;
 }
 

@@ -242,7 +242,6 @@ __global__ __launch_bounds__(256) void ec2_bwd_kernel(
         A1s[threadIdx.x] = a;
         A1s[C1 + threadIdx.x] = beta1[threadIdx.x] - mean1[threadIdx.x] * a;
     }
-    if (threadIdx.x < 2 * C1) red1[threadIdx.x] = 0.f;
     for (int r = threadIdx.x; r < Rpad; r += 256) {
         const int p = r / k;
         rowp[r] = (uint8_t)p;
@@ -253,6 +252,11 @@ __global__ __launch_bounds__(256) void ec2_bwd_kernel(
     for (int wi = 0; wi < WPW; ++wi)
 #pragma unroll
         for (int e = 0; e < 16; ++e) accw[wi][e] = 0.f;
+    // dbeta1 / dgamma1 partial sums of this lane's layer-1 channel c1 = (wave % CT1) * 32 + ql: the (row tile, column tile)
+    // pairs of a wave all share the column tile (4 waves, CT1 = 2), so the sums live in registers across every tile of
+    // the workgroup and are folded in wave order at the end -- no LDS float atomics, the result is reproducible
+    static_assert(4 % CT1 == 0, "a wave must keep its layer-1 column tile");
+    float sb_acc = 0.f, sg_acc = 0.f;
     __syncthreads();
 
     for (int tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
@@ -352,8 +356,8 @@ __global__ __launch_bounds__(256) void ec2_bwd_kernel(
                     sg = __builtin_fmaf(du, (y1 - mu1) * r1, sg);
                 }
             }
-            atomicAdd(&red1[c1], sb);
-            atomicAdd(&red1[C1 + c1], sg);
+            sb_acc += sb;
+            sg_acc += sg;
         }
 
         // ---- phase 5: dW2 += dy2^T z1 (MFMA, K = rows); accumulators live across the tiles of this workgroup
@@ -390,8 +394,24 @@ __global__ __launch_bounds__(256) void ec2_bwd_kernel(
             }
         }
     }
-    __syncthreads();
-    if (threadIdx.x < 2 * C1) part1[rec * 2 * C1 + threadIdx.x] = red1[threadIdx.x];
+    __syncthreads();   // the tiles are done: D is free
+    {
+        float *redw = D;   // [4 waves][2][C1]
+        for (int t = threadIdx.x; t < 4 * 2 * C1; t += 256) redw[t] = 0.f;
+        __syncthreads();
+        const float sbw = sb_acc + __shfl_xor(sb_acc, 32), sgw = sg_acc + __shfl_xor(sg_acc, 32);   // the two k-halves
+        if (half == 0) {
+            const int c1 = (wave % CT1) * 32 + ql;
+            redw[(wave * 2) * C1 + c1] = sbw;
+            redw[(wave * 2 + 1) * C1 + c1] = sgw;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * C1) {
+            const int which = threadIdx.x / C1, c = threadIdx.x % C1;
+            part1[rec * 2 * C1 + threadIdx.x] = redw[(0 * 2 + which) * C1 + c] + redw[(1 * 2 + which) * C1 + c] +
+                                                redw[(2 * 2 + which) * C1 + c] + redw[(3 * 2 + which) * C1 + c];
+        }
+    }
 }
 
 // one wave per destination point j: dP_j from the in-edges' du1 rows (reverse graph), dQ_j from its own k rows

@@ -175,7 +175,8 @@ def test_edge_features_vs_c_oracle(fsg, device, B, C, Np, k):
 @pytest.mark.parametrize("B,Np,k", [(8, 2048, 20), (4, 8192, 40), (3, 77, 5), (1, 1, 1)])
 def test_reverse_graph_csr(fsg, device, B, Np, k):
     """CSR by destination (fsg_graph_reverse_csr): both builders (16 workgroups per cloud with a workspace, one without)
-    must hold exactly the in-edges (source << 6 | slot) of every destination; their order inside a row is free."""
+    must hold exactly the in-edges (source << 6 | slot) of every destination, ascending inside a row (rows above 1024
+    in-edges excepted): the graph, and the backward that walks it, is reproducible."""
     import ctypes
     rng = np.random.default_rng(B * Np + k)
     idx = rng.integers(0, Np, (B, Np, k)).astype(np.int32)
@@ -199,14 +200,9 @@ def test_reverse_graph_csr(fsg, device, B, Np, k):
             order = np.argsort(flat[b], kind="stable")
             want = src[order]                          # in-edges grouped by destination, ascending inside a group
             got = cl[b].copy()
-            for j in np.nonzero(deg > 1)[0][:: max(1, Np // 64)]:      # sort a sample of rows + the hub
+            for j in np.nonzero(deg > 1024)[0]:        # hubs above the sort cap: any order
                 got[rp[b, j]:rp[b, j + 1]].sort()
-            got[rp[b, 3]:rp[b, 4]].sort() if Np > 10 else None
-            sel = np.zeros(Np * k, bool)
-            for j in list(np.nonzero(deg > 1)[0][:: max(1, Np // 64)]) + ([3] if Np > 10 else []):
-                sel[rp[b, j]:rp[b, j + 1]] = True
-            assert np.array_equal(got[sel], want[sel]), use_ws
-            assert np.array_equal(np.sort(cl[b]), np.sort(want)), use_ws
+            assert np.array_equal(got, want), use_ws
 
 
 # --------------------------------------------------------------------------- Chamfer
@@ -909,3 +905,24 @@ def test_graphed_train_step_helper(fsg, device):
     np.testing.assert_allclose(lg[:3], le[:3], rtol=5e-4)
     np.testing.assert_allclose(lg, le, rtol=2e-2)
     assert le[-1] < le[0]
+
+
+def test_dgcnn_backward_is_bitwise_reproducible(fsg, device):
+    """No float atomics on the DGCNN path and a sorted reverse graph: two backward passes from the same state give
+    bit-identical gradients (BASELINE config 2 shape)."""
+    from fissure_segmentation_amd.losses.nnu_loss import NNULoss
+    from fissure_segmentation_amd.models.dgcnn import DGCNNSeg
+    torch.manual_seed(0)
+    net = DGCNNSeg(k=20, in_features=3, num_classes=4).to(device).train()
+    crit = NNULoss(torch.tensor([0.4, 1.2, 1.2, 1.2])).to(device)
+    x = G(cloud(77, 8, 3, 2048), device)
+    y = torch.randint(0, 4, (8, 2048), device=device)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    grads = []
+    for _ in range(2):
+        net.load_state_dict(state)
+        net.zero_grad(set_to_none=True)
+        crit(net(x), y)[0].backward()
+        grads.append([p.grad.clone() for p in net.parameters()])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
