@@ -93,7 +93,51 @@ __global__ __launch_bounds__(256) void chamfer_bwd_kernel(const float *__restric
     }
 }
 
+// deterministic variant: every target point sums its in-edges (the query points whose nearest neighbour it is) in
+// ascending query order through the reverse graph of `arg` -- no atomics
+__global__ __launch_bounds__(256) void chamfer_bwd_x_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                             const int32_t *__restrict__ arg, const float *__restrict__ g, int N,
+                                                             int M, float *__restrict__ gx) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const long xi = ((long)b * N + i) * 3, ya = ((long)b * M + arg[(long)b * N + i]) * 3;
+    const float s = 2.0f * g[(long)b * N + i];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) gx[xi + d] += s * (x[xi + d] - y[ya + d]);
+}
+
+__global__ __launch_bounds__(256) void chamfer_bwd_y_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                             const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                             const float *__restrict__ g, int N, int M, float *__restrict__ gy) {
+    const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= M) return;
+    const int32_t *rp = rowptr + (long)b * (M + 1);
+    const int32_t *cl = col + (long)b * N;
+    const long yj = ((long)b * M + j) * 3;
+    const float y0 = y[yj], y1 = y[yj + 1], y2 = y[yj + 2];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int t = rp[j]; t < rp[j + 1]; ++t) {
+        const int i = cl[t] >> 6;
+        const long xi = ((long)b * N + i) * 3;
+        const float s = 2.0f * g[(long)b * N + i];
+        a0 -= s * (x[xi] - y0);
+        a1 -= s * (x[xi + 1] - y1);
+        a2 -= s * (x[xi + 2] - y2);
+    }
+    gy[yj] += a0;
+    gy[yj + 1] += a1;
+    gy[yj + 2] += a2;
+}
+
 }  // namespace
+
+int fsg_csr_bipartite_launch(const int32_t *idx, int B, int NS, int N, int k, int32_t *rowptr, int32_t *col, int32_t *cnt,
+                             hipStream_t st);   // edgeconv.hip
+
+extern "C" size_t fsg_chamfer_nn_bwd_workspace_bytes(int B, int N, int M) {
+    if (B <= 0 || N <= 0 || M <= 0) return 0;
+    return sizeof(int32_t) * ((size_t)B * (M + 1) + (size_t)B * N + (size_t)B * 16 * M);
+}
 
 extern "C" int fsg_chamfer_nn_f32(const float *x, const float *y, int B, int N, int M, float *dist, int32_t *arg,
                                   fsg_stream_t stream) {
@@ -107,10 +151,23 @@ extern "C" int fsg_chamfer_nn_f32(const float *x, const float *y, int B, int N, 
 }
 
 extern "C" int fsg_chamfer_nn_bwd_f32(const float *x, const float *y, const int32_t *arg, const float *g_dist, int B,
-                                      int N, int M, float *grad_x, float *grad_y, fsg_stream_t stream) {
+                                      int N, int M, float *grad_x, float *grad_y, void *workspace, fsg_stream_t stream) {
     FSG_REQUIRE(x && y && arg && g_dist && grad_x && grad_y, "fsg_chamfer_nn_bwd_f32: NULL pointer");
     FSG_REQUIRE(B >= 0 && N > 0 && M > 0 && B <= 65535, "fsg_chamfer_nn_bwd_f32: bad shape");
     if (B == 0) return FSG_OK;
+    if (workspace) {   // reproducible path: reverse graph of arg (N sources, one slot each -> M targets), ordered sums
+        int32_t *rowptr = (int32_t *)workspace, *col = rowptr + (size_t)B * (M + 1), *cnt = col + (size_t)B * N;
+        const int rc = fsg_csr_bipartite_launch(arg, B, N, M, 1, rowptr, col, cnt, (hipStream_t)stream);
+        if (rc == FSG_OK) {
+            hipLaunchKernelGGL(chamfer_bwd_x_kernel, dim3(fsg_cdiv(N, 256), B), dim3(256), 0, (hipStream_t)stream, x, y, arg,
+                               g_dist, N, M, grad_x);
+            hipLaunchKernelGGL(chamfer_bwd_y_kernel, dim3(fsg_cdiv(M, 256), B), dim3(256), 0, (hipStream_t)stream, x, y, rowptr,
+                               col, g_dist, N, M, grad_y);
+            FSG_CHECK_LAUNCH("fsg_chamfer_nn_bwd_f32/ordered");
+            return FSG_OK;
+        }
+        if (rc != FSG_ERR_UNSUPPORTED) return rc;
+    }
     hipLaunchKernelGGL(chamfer_bwd_kernel, dim3(fsg_cdiv(N, 256), B), dim3(256), 0, (hipStream_t)stream, x, y, arg,
                        g_dist, N, M, grad_x, grad_y);
     FSG_CHECK_LAUNCH("fsg_chamfer_nn_bwd_f32");

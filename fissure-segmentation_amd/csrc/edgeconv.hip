@@ -97,11 +97,12 @@ __global__ __launch_bounds__(1024) void csr_build_kernel(const int32_t *__restri
 //   csr_count: LDS histogram of the slice -> cnt[b][g][N]
 //   csr_scan : per cloud, rowptr = exclusive scan of sum_g cnt, and cnt[b][g][j] <- rowptr[j] + sum_{g' < g} cnt[b][g'][j]
 //   csr_fill : LDS cursors start at cnt[b][g][:], every edge of the slice takes the next slot of its destination
-__global__ __launch_bounds__(1024) void csr_count_kernel(const int32_t *__restrict__ idx, int N, int k, int G,
+// (bipartite form: NS source rows with k slots each point into N destinations; the kNN graph has NS == N)
+__global__ __launch_bounds__(1024) void csr_count_kernel(const int32_t *__restrict__ idx, int NS, int N, int k, int G,
                                                           int32_t *__restrict__ cnt) {
     extern __shared__ int sh[];
     const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
-    const long NK = (long)N * k;
+    const long NK = (long)NS * k;
     const long e0 = NK * g / G, e1 = NK * (g + 1) / G;
     const int32_t *ib = idx + b * NK;
     for (int j = tid; j < N; j += 1024) sh[j] = 0;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(1024) void csr_count_kernel(const int32_t *__restri
     for (int j = tid; j < N; j += 1024) out[j] = sh[j];
 }
 
-__global__ __launch_bounds__(1024) void csr_scan_kernel(int N, int k, int G, int32_t *__restrict__ cnt,
+__global__ __launch_bounds__(1024) void csr_scan_kernel(int NS, int N, int k, int G, int32_t *__restrict__ cnt,
                                                          int32_t *__restrict__ rowptr) {
     __shared__ int part[1024];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -139,14 +140,14 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(int N, int k, int G, int
             run += c;
         }
     }
-    if (tid == 0) rowptr[(long)b * (N + 1) + N] = N * k;
+    if (tid == 0) rowptr[(long)b * (N + 1) + N] = NS * k;
 }
 
-__global__ __launch_bounds__(1024) void csr_fill_kernel(const int32_t *__restrict__ idx, int N, int k, int G,
+__global__ __launch_bounds__(1024) void csr_fill_kernel(const int32_t *__restrict__ idx, int NS, int N, int k, int G,
                                                          const int32_t *__restrict__ cnt, int32_t *__restrict__ col) {
     extern __shared__ int sh[];
     const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
-    const long NK = (long)N * k;
+    const long NK = (long)NS * k;
     const long e0 = NK * g / G, e1 = NK * (g + 1) / G;
     const int32_t *ib = idx + b * NK;
     const int32_t *start = cnt + ((long)b * G + g) * N;
@@ -521,25 +522,31 @@ extern "C" size_t fsg_graph_reverse_csr_workspace_bytes(int B, int N, int k) {
     return sizeof(int32_t) * (size_t)(B > 0 ? B : 0) * FSG_CSR_SPLIT * (size_t)(N > 0 ? N : 0);
 }
 
+// shared with chamfer.hip: reverse of a bipartite graph (NS sources x k slots -> N destinations), multi-workgroup builder
+int fsg_csr_bipartite_launch(const int32_t *idx, int B, int NS, int N, int k, int32_t *rowptr, int32_t *col, int32_t *cnt,
+                             hipStream_t st) {
+    const int G = FSG_CSR_SPLIT;
+    const size_t ldsN = sizeof(int) * (size_t)N;
+    if (ldsN > 64 * 1024 || B > 65535) return FSG_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(csr_count_kernel, dim3(B, G), dim3(1024), ldsN, st, idx, NS, N, k, G, cnt);
+    FSG_CHECK_LAUNCH("fsg_graph_reverse_csr/count");
+    hipLaunchKernelGGL(csr_scan_kernel, dim3(B), dim3(1024), 0, st, NS, N, k, G, cnt, rowptr);
+    FSG_CHECK_LAUNCH("fsg_graph_reverse_csr/scan");
+    hipLaunchKernelGGL(csr_fill_kernel, dim3(B, G), dim3(1024), ldsN, st, idx, NS, N, k, G, cnt, col);
+    FSG_CHECK_LAUNCH("fsg_graph_reverse_csr/fill");
+    hipLaunchKernelGGL(csr_sort_rows_kernel, dim3(fsg_cdiv(N, 4), B), dim3(256), 0, st, rowptr, col, N, NS * k);
+    FSG_CHECK_LAUNCH("fsg_graph_reverse_csr/sort");
+    return FSG_OK;
+}
+
 extern "C" int fsg_graph_reverse_csr(const int32_t *idx, int B, int N, int k, int32_t *rowptr, int32_t *col,
                                      void *workspace, fsg_stream_t stream) {
     FSG_REQUIRE(idx && rowptr && col, "fsg_graph_reverse_csr: NULL pointer");
     FSG_REQUIRE(B >= 0 && N > 0 && k > 0 && k <= 64 && N <= 8192 * 4, "fsg_graph_reverse_csr: bad shape N=%d k=%d", N, k);
     if (B == 0) return FSG_OK;
-    if (workspace && (size_t)N * sizeof(int) <= 64 * 1024 && B <= 65535) {
-        hipStream_t st = (hipStream_t)stream;
-        const int G = FSG_CSR_SPLIT;
-        int32_t *cnt = (int32_t *)workspace;
-        const size_t ldsN = sizeof(int) * (size_t)N;
-        hipLaunchKernelGGL(csr_count_kernel, dim3(B, G), dim3(1024), ldsN, st, idx, N, k, G, cnt);
-        FSG_CHECK_LAUNCH("fsg_graph_reverse_csr/count");
-        hipLaunchKernelGGL(csr_scan_kernel, dim3(B), dim3(1024), 0, st, N, k, G, cnt, rowptr);
-        FSG_CHECK_LAUNCH("fsg_graph_reverse_csr/scan");
-        hipLaunchKernelGGL(csr_fill_kernel, dim3(B, G), dim3(1024), ldsN, st, idx, N, k, G, cnt, col);
-        FSG_CHECK_LAUNCH("fsg_graph_reverse_csr/fill");
-        hipLaunchKernelGGL(csr_sort_rows_kernel, dim3(fsg_cdiv(N, 4), B), dim3(256), 0, st, rowptr, col, N, N * k);
-        FSG_CHECK_LAUNCH("fsg_graph_reverse_csr/sort");
-        return FSG_OK;
+    if (workspace) {
+        const int rc = fsg_csr_bipartite_launch(idx, B, N, N, k, rowptr, col, (int32_t *)workspace, (hipStream_t)stream);
+        if (rc != FSG_ERR_UNSUPPORTED) return rc;
     }
     const size_t lds = sizeof(int) * ((size_t)N + 1024);
     static size_t granted = 64 * 1024;

@@ -167,11 +167,15 @@ int fsg_bn_act_max_bwd_f32(const float *grad_out, const float *y, const float *y
  *   x (B,N,3), y (B,M,3) fp32 -> dist (B,N) = min_j |x_i - y_j|^2, arg (B,N) int32 (lowest j on ties)
  * _bwd: given g = dLoss/d dist (B,N) and arg, ACCUMULATES into grad_x (B,N,3) and grad_y (B,M,3)
  *   grad_x[i] += 2 g_i (x_i - y_arg) ; grad_y[arg] -= 2 g_i (x_i - y_arg)      (caller zero-fills)
+ *   workspace (fsg_chamfer_nn_bwd_workspace_bytes, 4-byte aligned): grad_y is summed per target in ascending query order
+ *   through the reverse graph of arg (reproducible); NULL: scattered with hardware fp32 atomics.
  */
+size_t fsg_chamfer_nn_bwd_workspace_bytes(int B, int N, int M);
 int fsg_chamfer_nn_f32(const float *x, const float *y, int B, int N, int M, float *dist,
                        int32_t *arg, fsg_stream_t stream);
 int fsg_chamfer_nn_bwd_f32(const float *x, const float *y, const int32_t *arg, const float *g_dist,
-                           int B, int N, int M, float *grad_x, float *grad_y, fsg_stream_t stream);
+                           int B, int N, int M, float *grad_x, float *grad_y, void *workspace,
+                           fsg_stream_t stream);
 
 /*
  * Segmentation loss, value and gradient: replaces losses/nnu_loss.py:6-19, i.e.

@@ -926,3 +926,31 @@ def test_dgcnn_backward_is_bitwise_reproducible(fsg, device):
         grads.append([p.grad.clone() for p in net.parameters()])
     for a, b in zip(*grads):
         assert torch.equal(a, b)
+
+
+def test_chamfer_backward_is_reproducible_and_matches_autograd(fsg, device):
+    """ordered (reverse-graph) Chamfer backward: bit-identical between runs, equal to torch autograd of the same loss"""
+    from fissure_segmentation_amd.losses.chamfer_loss import ChamferLoss
+    rng = np.random.default_rng(9)
+    a = rng.uniform(-1, 1, (3, 700, 3)).astype(np.float32)
+    b = rng.uniform(-1, 1, (3, 450, 3)).astype(np.float32)
+    b[:, 5] = b[:, 4]   # duplicate targets: ties go to the lower index, the other one receives no gradient
+    grads = []
+    fsg.functional.set_deterministic(True)
+    try:
+        for _ in range(2):
+            at, bt = G(a, device).requires_grad_(True), G(b, device).requires_grad_(True)
+            ChamferLoss()(at, bt).backward()
+            grads.append((at.grad.clone(), bt.grad.clone()))
+    finally:
+        fsg.functional.set_deterministic(False)
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    at, bt = G(a, device).requires_grad_(True), G(b, device).requires_grad_(True)
+    ChamferLoss()(at, bt).backward()          # default: atomics for the scattered half
+    torch.testing.assert_close(at.grad, grads[0][0], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(bt.grad, grads[0][1], rtol=1e-5, atol=1e-7)
+    ar, br = torch.from_numpy(a).double().requires_grad_(True), torch.from_numpy(b).double().requires_grad_(True)
+    d = ((ar[:, :, None, :] - br[:, None, :, :]) ** 2).sum(-1)
+    (d.min(2).values.mean(1).mean() + d.min(1).values.mean(1).mean()).backward()
+    np.testing.assert_allclose(N(grads[0][0]), ar.grad.numpy(), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(N(grads[0][1]), br.grad.numpy(), rtol=1e-4, atol=1e-7)
