@@ -67,8 +67,9 @@ def usable_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(B, N, k, classes, steps=2):
-    """The oracle's pure-PyTorch CPU restatement (kind "port") on the host cores, same step definition."""
+def cpu_baseline(B, N, k, classes, budget_s=12.0, max_steps=8):
+    """The oracle's pure-PyTorch CPU restatement (kind "port") on the host cores, same step definition; a bounded sample:
+    whole steps of the same batch until ~budget_s seconds of CPU work are spent (at least 2, at most max_steps)."""
     from oracle import ref_cpu
     cores = usable_cores()
     torch.set_num_threads(cores)
@@ -84,8 +85,10 @@ def cpu_baseline(B, N, k, classes, steps=2):
         opt.step()
     step()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    steps = 0
+    while steps < 2 or (steps < max_steps and time.perf_counter() - t0 < budget_s):
         step()
+        steps += 1
     dt = (time.perf_counter() - t0) / steps
     return {"value": B * N / dt, "unit": "points/s", "cores": cores, "kind": "port",
             "sample": f"{steps} steps of the same workload (B={B}, N={N}, k={k}) after 1 warm-up, "
