@@ -388,7 +388,7 @@ __global__ __launch_bounds__(Geo<C>::NT) void pt_b1_kernel(const float *__restri
     __shared__ int IDX[G::EMAX];
     __shared__ float T[G::EMAX * 4];
     __shared__ float SM[G::EMAX * RS], DS[G::EMAX * RS], H2[G::EMAX * RS], UH[G::EMAX * RS], WB[CS * RS];
-    __shared__ float PROD[G::NT];
+    __shared__ float PROD[MAXNS * G::NT];   // g (v + p_r) of every (neighbour, point slot, channel) of the tile
     const Stats S = split_stats(stats, C);
     const int tid = threadIdx.x, ps = tid / C, ch = tid % C;
     const float w20 = P.lp2_w[3 * ch], w21 = P.lp2_w[3 * ch + 1], w22 = P.lp2_w[3 * ch + 2], b2 = P.lp2_b[ch];
@@ -427,17 +427,17 @@ __global__ __launch_bounds__(Geo<C>::NT) void pt_b1_kernel(const float *__restri
                 unsafeAtomicAdd(dv + (long)j * ldg + ch, gch * SM[e * RS + ch % CS]);
                 prod = gch * (v[(long)j * ld + ch] + pr);
             }
-            PROD[tid] = prod;
-            __syncthreads();
-            if (tid < G::PT * CS) {
-                const int pp = tid / CS, o = tid % CS;
-                float a = 0.f;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) a += PROD[pp * C + r * CS + o];
-                DS[(pp * ns + sI) * RS + o] = a;
-            }
-            __syncthreads();
+            PROD[sI * G::NT + tid] = prod;
         }
+        __syncthreads();   // one barrier for all neighbours (was two per neighbour)
+        for (int item = tid; item < ns * G::PT * CS; item += G::NT) {   // d softmax[e][o] = sum of the 8 channels sharing o
+            const int sI = item / (G::PT * CS), rem = item % (G::PT * CS), pp = rem / CS, o = rem % CS;
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) a += PROD[sI * G::NT + pp * C + r * CS + o];
+            DS[(pp * ns + sI) * RS + o] = a;
+        }
+        __syncthreads();
         if (tid < G::PT * CS) {  // softmax backward over the neighbours
             const int pp = tid / CS, o = tid % CS;
             float dot = 0.f;
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(Geo<C>::NT) void pt_b3_kernel(const float *__restri
     __shared__ int IDX[G::EMAX];
     __shared__ float T[G::EMAX * 4], AH[G::EMAX * 4], D[G::EMAX * 4], DT[G::EMAX * 4];
     __shared__ float DU1[G::EMAX * RS], SM[G::EMAX * RS];
-    __shared__ float REDH[HALVES * 4];
+    __shared__ float REDH[MAXNS * HALVES * 4];   // per neighbour: the 32-lane partial sums of W2^T dpr
     __shared__ float REDP[G::NT / 64][8];
     __shared__ float COMB[4 * G::NT];
     const Stats S = split_stats(stats, C);
@@ -663,16 +663,19 @@ __global__ __launch_bounds__(Geo<C>::NT) void pt_b3_kernel(const float *__restri
                 for (int off = 16; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
                 pm[m] = x;
             }
-            if ((tid & 31) == 0) { REDH[(tid >> 5) * 4] = pm[0]; REDH[(tid >> 5) * 4 + 1] = pm[1]; REDH[(tid >> 5) * 4 + 2] = pm[2]; }
-            __syncthreads();
-            if (tid < G::PT * 3) {
-                const int pp = tid / 3, m = tid % 3;
-                float a = 0.f;
-                for (int h = 0; h < GRP; ++h) a += REDH[(pp * GRP + h) * 4 + m];
-                DT[(pp * ns + sI) * 4 + m] = a;
+            if ((tid & 31) == 0) {
+                float *rh = REDH + (sI * HALVES + (tid >> 5)) * 4;
+                rh[0] = pm[0]; rh[1] = pm[1]; rh[2] = pm[2];
             }
-            __syncthreads();
         }
+        __syncthreads();   // one barrier for all neighbours (was two per neighbour)
+        for (int item = tid; item < ns * G::PT * 3; item += G::NT) {
+            const int sI = item / (G::PT * 3), rem = item % (G::PT * 3), pp = rem / 3, m = rem % 3;
+            float a = 0.f;
+            for (int h = 0; h < GRP; ++h) a += REDH[(sI * HALVES + pp * GRP + h) * 4 + m];
+            DT[(pp * ns + sI) * 4 + m] = a;
+        }
+        __syncthreads();
         if (ok) dq[(long)pt * ldg + ch] = dqa;
         if (tid < E && pt0 + tid / ns < n) {
             const int e = tid;
