@@ -954,3 +954,25 @@ def test_chamfer_backward_is_reproducible_and_matches_autograd(fsg, device):
     (d.min(2).values.mean(1).mean() + d.min(1).values.mean(1).mean()).backward()
     np.testing.assert_allclose(N(grads[0][0]), ar.grad.numpy(), rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(N(grads[0][1]), br.grad.numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_new_entry_points_reject_bad_arguments(fsg, device):
+    """error behaviour of the C ABI behind the Python wrappers: bad shapes raise, nothing is launched"""
+    F = fsg.functional
+    x = torch.randn(10, 48, device=device)
+    with pytest.raises(ValueError):                                   # plane width outside {32,...,512}
+        F.pt_attn(torch.randn(10, 3, device=device), torch.zeros(10, 8, dtype=torch.int32, device=device),
+                  torch.randn(10, 144, device=device), None, None)
+    with pytest.raises(ValueError):                                   # one class only
+        F.nnu_loss(torch.randn(2, 1, 16, device=device), torch.zeros(2, 16, dtype=torch.int64, device=device))
+    with pytest.raises(RuntimeError):                                 # CPU tensors: no fallback
+        F.nnu_loss(torch.randn(2, 4, 16), torch.zeros(2, 16, dtype=torch.int64))
+    import ctypes
+    rc = fsg._lib.lib.fsg_bn_rows_fwd_f32(ctypes.c_void_p(x.data_ptr()), None, ctypes.c_void_p(x.data_ptr()),
+                                          ctypes.c_void_p(x.data_ptr()), None, None, 10, 48, 0, 0.1, 1e-5, 1,
+                                          ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(x.data_ptr()),
+                                          ctypes.c_void_p(x.data_ptr()), None, None)
+    assert rc != 0 and b"C in {32,64,128,256,512}" in fsg._lib.lib.fsg_last_error()
+    rc = fsg._lib.lib.fsg_gemm_small_f32(ctypes.c_void_p(x.data_ptr()), 1, 1, ctypes.c_void_p(x.data_ptr()), 1, 1, None,
+                                         ctypes.c_void_p(x.data_ptr()), 1, 4, 4, 0, None, None)
+    assert rc != 0 and b"bad shape" in fsg._lib.lib.fsg_last_error()
