@@ -976,3 +976,50 @@ def test_new_entry_points_reject_bad_arguments(fsg, device):
     rc = fsg._lib.lib.fsg_gemm_small_f32(ctypes.c_void_p(x.data_ptr()), 1, 1, ctypes.c_void_p(x.data_ptr()), 1, 1, None,
                                          ctypes.c_void_p(x.data_ptr()), 1, 4, 4, 0, None, None)
     assert rc != 0 and b"bad shape" in fsg._lib.lib.fsg_last_error()
+
+
+@pytest.mark.parametrize("B,C,Np,k", [(8, 3, 2048, 20), (8, 64, 2048, 20), (4, 3, 8192, 40), (4, 64, 8192, 40), (8, 128, 4096, 20)])
+def test_knn_properties_at_full_size(fsg, device, B, C, Np, k):
+    """Size-independent properties at the BASELINE sizes (the oracle comparison runs on smaller clouds): every row is
+    sorted ascending by (distance, index), holds k distinct in-range indices, starts with the query itself at distance 0
+    (self loop, fix_diag), its distances agree with a direct fp64 evaluation, and no point outside the list is closer
+    than the k-th entry (checked on a sample of rows against the full distance row)."""
+    x = cloud(7000 + Np + C, B, C, Np)
+    xt = G(x, device)
+    idx, dist = fsg.functional.knn_graph(xt, k, return_dist=True)
+    idx_n, dist_n = N(idx), N(dist)
+    assert idx_n.min() >= 0 and idx_n.max() < Np
+    assert np.array_equal(idx_n[:, :, 0], np.broadcast_to(np.arange(Np), (B, Np))) and np.all(dist_n[:, :, 0] == 0)
+    d0, d1 = dist_n[:, :, :-1], dist_n[:, :, 1:]
+    assert np.all((d0 < d1) | ((d0 == d1) & (idx_n[:, :, :-1] < idx_n[:, :, 1:])))
+    assert np.all(np.sort(idx_n, axis=2)[:, :, 1:] != np.sort(idx_n, axis=2)[:, :, :-1])          # distinct
+    rng = np.random.default_rng(0)
+    x64 = x.astype(np.float64)
+    for b, i in zip(rng.integers(0, B, 24), rng.integers(0, Np, 24)):
+        full = ((x64[b] - x64[b][:, i:i + 1]) ** 2).sum(0)
+        full[i] = 0.0
+        got = dist_n[b, i].astype(np.float64)
+        scale = max(1.0, float(np.abs(x64[b]).max()) ** 2 * C)
+        assert np.abs(got - full[idx_n[b, i]]).max() <= 1e-5 * scale
+        outside = np.delete(full, idx_n[b, i])
+        assert outside.min() >= got[-1] - 1e-5 * scale
+
+
+def test_fps_and_segment_knn_properties(fsg, device):
+    """packed clouds at the PointTransformer sizes: samples are distinct and stay inside their segment; neighbour lists
+    are sorted, in-segment and start with the query point itself"""
+    sizes = [2048] * 8
+    xyz, _, off = packed(31, sizes)
+    new_off = np.cumsum([s // 4 for s in sizes]).astype(np.int32)
+    fi = N(fsg.functional.fps(G(xyz, device), G(off, device), G(new_off, device), int(new_off[-1])))
+    starts = np.concatenate([[0], off[:-1]])
+    qs = np.concatenate([[0], new_off[:-1]])
+    for s in range(len(sizes)):
+        seg = fi[qs[s]:new_off[s]]
+        assert seg[0] == starts[s] and seg.min() >= starts[s] and seg.max() < off[s] and len(np.unique(seg)) == len(seg)
+    idx, d2 = fsg.functional.knn_segment(16, G(xyz, device), G(xyz, device), G(off, device), G(off, device))
+    idx_n, d2_n = N(idx), N(d2)
+    seg_of = np.repeat(np.arange(len(sizes)), sizes)
+    assert np.array_equal(idx_n[:, 0], np.arange(len(xyz))) and np.all(d2_n[:, 0] == 0)
+    assert np.all(seg_of[idx_n] == seg_of[:, None])
+    assert np.all((d2_n[:, :-1] < d2_n[:, 1:]) | ((d2_n[:, :-1] == d2_n[:, 1:]) & (idx_n[:, :-1] < idx_n[:, 1:])))
