@@ -24,6 +24,8 @@ SIGNATURES = {
     "fsg_edge_gather_bwd_f32": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
     "fsg_graph_reverse_csr_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),
     "fsg_graph_reverse_csr": ([_P, _I, _I, _I, _P, _P, _P, _P], _I),
+    "fsg_edge_weights_fwd_f32": ([_P, _I, _I, _P, _P], _I),
+    "fsg_edge_weights_bwd_f32": ([_P, _I, _I, _P, _P], _I),
     "fsg_edgeconv1_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),
     "fsg_edgeconv1_fwd_f32": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
                               _I),

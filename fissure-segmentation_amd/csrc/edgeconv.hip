@@ -565,6 +565,37 @@ extern "C" int fsg_graph_reverse_csr(const int32_t *idx, int B, int N, int k, in
     return FSG_OK;
 }
 
+// W = [W_rel | W_ctr] (Co, 2C)  ->  [W_rel ; W_ctr - W_rel] (2Co, C): the weight of the per-point GEMM that produces the
+// [P | Q] rows, and its transpose rule for the gradient -- one tiny launch each (ATen: slice, subtract, cat = 2-4 launches)
+__global__ __launch_bounds__(256) void edge_weights_fwd_kernel(const float *__restrict__ W, int Co, int C,
+                                                               float *__restrict__ Wt) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= 2 * Co * C) return;
+    const int r = t / C, c = t - r * C;
+    Wt[t] = r < Co ? W[(long)r * 2 * C + c] : W[(long)(r - Co) * 2 * C + C + c] - W[(long)(r - Co) * 2 * C + c];
+}
+__global__ __launch_bounds__(256) void edge_weights_bwd_kernel(const float *__restrict__ g, int Co, int C,
+                                                               float *__restrict__ gW) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= 2 * Co * C) return;
+    const int r = t / (2 * C), c2 = t - r * 2 * C;
+    gW[t] = c2 < C ? g[(long)r * C + c2] - g[(long)(Co + r) * C + c2] : g[(long)(Co + r) * C + (c2 - C)];
+}
+
+extern "C" int fsg_edge_weights_fwd_f32(const float *W, int Co, int C, float *Wt, fsg_stream_t stream) {
+    FSG_REQUIRE(W && Wt && Co > 0 && C > 0, "fsg_edge_weights_fwd_f32: bad arguments");
+    hipLaunchKernelGGL(edge_weights_fwd_kernel, dim3(fsg_cdiv(2L * Co * C, 256)), dim3(256), 0, (hipStream_t)stream, W, Co, C, Wt);
+    FSG_CHECK_LAUNCH("fsg_edge_weights_fwd_f32");
+    return FSG_OK;
+}
+extern "C" int fsg_edge_weights_bwd_f32(const float *grad_Wt, int Co, int C, float *grad_W, fsg_stream_t stream) {
+    FSG_REQUIRE(grad_Wt && grad_W && Co > 0 && C > 0, "fsg_edge_weights_bwd_f32: bad arguments");
+    hipLaunchKernelGGL(edge_weights_bwd_kernel, dim3(fsg_cdiv(2L * Co * C, 256)), dim3(256), 0, (hipStream_t)stream, grad_Wt, Co,
+                       C, grad_W);
+    FSG_CHECK_LAUNCH("fsg_edge_weights_bwd_f32");
+    return FSG_OK;
+}
+
 extern "C" size_t fsg_edgeconv1_workspace_bytes(int B, int N, int Co) {
     const size_t rec = (size_t)B * (size_t)fsg_cdiv(N, TP * TPW);
     return sizeof(float) * (rec * 3 * (size_t)Co + fsg_ec_finalize_stage_floats(Co));

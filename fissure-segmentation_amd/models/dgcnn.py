@@ -233,7 +233,7 @@ class DGCNNSeg(DGCNNBase):
         # is constant per cloud, so its product is computed once per cloud instead of once per point
         seg0 = self.segmentation[0]
         w0 = seg0.layers[0].weight.view(seg0.layers[0].out_channels, -1)
-        y = F_hip.linear_pm(levels, w0[:, :192]).view(B, N, -1) + nn.functional.linear(g, w0[:, 192:]).unsqueeze(1)
+        y = F_hip.add_per_cloud(F_hip.linear_pm(levels, w0[:, :192]).view(B, N, -1), nn.functional.linear(g, w0[:, 192:]))
         y = _norm_act(y.view(B * N, -1), list(seg0.layers)[1:])
         for block in list(self.segmentation)[1:]:
             y = pointwise_block(y, block)

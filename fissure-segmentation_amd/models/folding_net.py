@@ -64,7 +64,7 @@ def _first_layer_split(conv, code, pts_pm):
     per_cloud = nn.functional.linear(code, w[:, :E], conv.bias)                         # (B, Cout)
     per_point = F_hip.linear_pm(pts_pm.reshape(-1, pts_pm.shape[-1]), w[:, E:].contiguous())   # (B*m, Cout)
     B, m = pts_pm.shape[0], pts_pm.shape[1]
-    return (per_point.view(B, m, -1) + per_cloud.unsqueeze(1)).view(B * m, -1)
+    return F_hip.add_per_cloud(per_point.view(B, m, -1), per_cloud).view(B * m, -1)
 
 
 def _lin(conv, x_pm):

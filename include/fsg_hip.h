@@ -80,6 +80,14 @@ int fsg_graph_reverse_csr(const int32_t *idx, int B, int N, int k, int32_t *rowp
                           void *workspace, fsg_stream_t stream);
 
 /*
+ * Weight of the per-point GEMM behind the fused EdgeConv: the first 1x1 conv over [x_j - x_i ; x_i] with
+ * W = [W_rel | W_ctr] (Co, 2C) (models/dgcnn.py:234-241, :282-323) equals P_j + Q_i with [P | Q] = x [W_rel ; W_ctr - W_rel]^T.
+ *   _fwd: W (Co,2C) -> Wt (2Co,C);   _bwd: grad_Wt (2Co,C) -> grad_W (Co,2C) (overwritten)
+ */
+int fsg_edge_weights_fwd_f32(const float *W, int Co, int C, float *Wt, fsg_stream_t stream);
+int fsg_edge_weights_bwd_f32(const float *grad_Wt, int Co, int C, float *grad_W, fsg_stream_t stream);
+
+/*
  * Fused EdgeConv with ONE shared-MLP layer: replaces models/dgcnn.py:234-241 (gather, 1x1 Conv2d, BatchNorm2d,
  * LeakyReLU, max over k) and the get_graph_feature -> conv -> max blocks of models/folding_net.py:120-133.
  * The caller supplies the per-point rows of the decomposed conv (W = [W_rel | W_ctr]):
