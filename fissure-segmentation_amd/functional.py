@@ -165,9 +165,7 @@ class _LinearPM(torch.autograd.Function):
             else:
                 gw = g2.t() @ x2
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            # a handful of output columns behind thousands of rows: ATen's column reduction takes 17 us for (16384, 4);
-            # the same sum as a one-row product is a ~5 us library launch
-            gb = (_ones(1, M, g2.device) @ g2).view(-1) if (N <= 16 and M >= 4096) else g2.sum(0)
+            gb = g2.sum(0)   # (a one-row product with ones is 3-15x slower: tools/probe_bias_grad.py)
         return gx, gw, gb
 
 
@@ -363,6 +361,7 @@ class _EdgeConv1(torch.autograd.Function):
                       _p(invstd), _p(ws), _stream())
         ctx.save_for_backward(pq, idx, gamma, beta, mean, invstd, ysel, arg, ssum)
         ctx.meta = (B, N, k, Co, bool(training), slope)
+        ctx.set_materialize_grads(False)   # the layout that only feeds the next graph build gets None, not a zero tensor
         return out, out_pm
 
     @staticmethod
@@ -445,6 +444,7 @@ class _EdgeConv2(torch.autograd.Function):
                       _p(ysel2), _p(arg2), _p(ssum2), _p(mean2), _p(invstd2), _p(ws), _stream())
         ctx.save_for_backward(pq, idx, w2, g1, b1, mean1, invstd1, ssum1, g2, b2, mean2, invstd2, ysel2, arg2)
         ctx.meta = (B, N, k, C2, t, slope)
+        ctx.set_materialize_grads(False)
         return out, out_pm
 
     @staticmethod
