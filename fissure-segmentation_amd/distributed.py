@@ -121,3 +121,7 @@ class BucketedGradAverager:
                 outs.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
             torch._foreach_copy_([p.grad for p in b["params"]], outs)
+        # ready for the next step even when zero_grad() is not called in between: under hipGraph replay the Python of the
+        # captured region (zero_grad included) does not run again, only finish() does
+        for b in self.buckets:
+            b["pending"], b["flat"], b["work"] = len(b["params"]), None, None

@@ -75,3 +75,39 @@ def test_shard_batch_tiles():
             spans = [D.shard_batch(gb, r, world) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == gb
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+
+
+def _worker_replay(rank, world, port, out):
+    """the hipGraph-replay pattern of bench.py at N > 1: gradients are rewritten IN PLACE by the replayed graph and only
+    finish() runs between replays -- zero_grad() belongs to the captured region and does not run again"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from fissure_segmentation_amd import distributed as D
+    D.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    model = _net()
+    avg = D.BucketedGradAverager(model)
+    avg.zero_grad()                                   # capture time
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    res = []
+    for step in range(3):                             # "replays"
+        for i, p in enumerate(model.parameters()):
+            p.grad.fill_(float((rank + 1) * (step + 1) + i))      # what the replayed backward would leave behind
+        avg.finish()
+        res.append([float(p.grad.flatten()[0]) for p in model.parameters()])
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_finish_without_zero_grad_between_steps():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_replay, args=(world, port, out), nprocs=world, join=True)
+    assert out[0] == out[1]
+    nparam = len(out[0][0])
+    for step in range(3):
+        for i in range(nparam):                       # mean over ranks of (rank+1)(step+1) + i
+            assert abs(out[0][step][i] - (1.5 * (step + 1) + i)) < 1e-6, (step, i, out[0][step][i])
