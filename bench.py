@@ -182,12 +182,15 @@ def main():
                     eager_step()
             torch.cuda.current_stream().wait_stream(side)
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
+            # with a process group alive its watchdog thread issues runtime calls of its own: capture in thread-local mode so
+            # that only this thread's calls are checked against the capture
+            cmode = os.environ.get("FSG_CAPTURE_MODE", "thread_local" if world > 1 else "global")
+            with torch.cuda.graph(g1, capture_error_mode=cmode):
                 static_loss = fwd_bwd()
                 if world == 1:
                     opt.step()
             if world > 1:
-                with torch.cuda.graph(g2, pool=g1.pool()):
+                with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode=cmode):
                     opt.step()
 
             def graph_step():
