@@ -311,7 +311,7 @@ def main():
                "config": {"workload": desc, "clouds_per_gpu": B, "points_per_cloud": N, "k": k,
                           "global_batch": B * world, "step": "fwd + (cross-entropy + generalised Dice) + bwd + grad all-reduce + Adam",
                           "launch": launch, "optimizer": "torch.optim.Adam(fused)" if args.torch_adam else
-                          "Adam over one flat parameter buffer (optim.FlatAdam: torch's fused Adam kernel, one launch)",
+                          "Adam over one flat parameter buffer (optim.FlatAdam: fsg_adam_flat_f32, one launch)",
                           "parallelism": f"dp{world}"},
                "roofline": roofline, "roofline_knn": roofline_knn}
         if not dgcnn:

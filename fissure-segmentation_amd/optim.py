@@ -4,9 +4,13 @@
 PointTransformer in 16 chunked multi-tensor launches (470 us per step on MI355X for 7.8 M parameters, launch-bound); the
 same arithmetic over one contiguous buffer is a single streaming kernel.  `FlatAdam` re-points every parameter at a view of
 one flat fp32 buffer (the modules, their `state_dict` and autograd are unaffected), gathers the gradients with one
-`torch.cat` per step and lets torch's own fused Adam kernel update the flat buffer: bit-identical to per-tensor Adam
-(element-wise update, same kernel), capturable into a hipGraph.
+`torch.cat` per step and updates the flat buffer with one launch of `fsg_adam_flat_f32` (csrc/adam.hip: float4 streaming,
+one workgroup per 1024 elements, step count on the device -- torch's fused kernel, also one launch here, runs 64 Ki
+elements per workgroup = 28 workgroups for DGCNN-seg).  Same update rule as torch/optim/adam.py; always capturable into
+a hipGraph.  On a CPU model (host-logic tests) the flat buffer is handed to torch.optim.Adam instead.
 """
+import ctypes
+
 import torch
 
 
@@ -33,12 +37,18 @@ class FlatAdam:
         for n in sizes:
             self._views.append(self.flat.grad[off:off + n])
             off += n
-        self.inner = torch.optim.Adam([self.flat], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
-                                      capturable=capturable, fused=dev.type == "cuda")
+        self.inner = None
+        if dev.type == "cuda":
+            # lr may be a float or a 1-element device tensor (then it is read on the device at every replay)
+            self._groups = [dict(params=[self.flat], lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)]
+            self.exp_avg, self.exp_avg_sq = torch.zeros_like(flat), torch.zeros_like(flat)
+            self._state = torch.zeros(2, dtype=torch.float32, device=dev)   # { step, ticket } of fsg_adam_flat_f32
+        else:
+            self.inner = torch.optim.Adam([self.flat], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
 
     @property
     def param_groups(self):
-        return self.inner.param_groups
+        return self.inner.param_groups if self.inner is not None else self._groups
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -56,14 +66,49 @@ class FlatAdam:
 
     def step_flat(self):
         """Adam update from the flat gradient buffer as it stands"""
-        self.inner.step()
+        if self.inner is not None:
+            self.inner.step()
+            return
+        from . import _lib
+        g = self._groups[0]
+        lr = g["lr"]
+        lr_dev = None
+        if isinstance(lr, torch.Tensor):
+            if lr.device != self.flat.device or lr.dtype != torch.float32 or lr.numel() != 1:
+                raise ValueError("a tensor learning rate must be one fp32 element on the parameters' device")
+            lr_dev, lr = ctypes.c_void_p(lr.data_ptr()), 0.0
+        P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        _lib.call("fsg_adam_flat_f32", P(self.flat.data), P(self.flat.grad), P(self.exp_avg), P(self.exp_avg_sq),
+                  P(self._state), self.flat.numel(), float(lr), lr_dev, float(g["betas"][0]), float(g["betas"][1]),
+                  float(g["eps"]), float(g["weight_decay"]), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
 
     def step(self):
         self.gather_grads()
         self.step_flat()
 
     def state_dict(self):
-        return self.inner.state_dict()
+        """same layout as torch.optim.Adam over the single flat parameter"""
+        if self.inner is not None:
+            return self.inner.state_dict()
+        group = {k: v for k, v in self._groups[0].items() if k != "params"}
+        group["params"] = [0]
+        return {"state": {0: {"step": self._state[0].clone(), "exp_avg": self.exp_avg.clone(),
+                              "exp_avg_sq": self.exp_avg_sq.clone()}},
+                "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self.inner.load_state_dict(sd)
+        if self.inner is not None:
+            self.inner.load_state_dict(sd)
+            return
+        st = sd["state"].get(0)
+        with torch.no_grad():
+            if st is None:
+                self._state.zero_(), self.exp_avg.zero_(), self.exp_avg_sq.zero_()
+            else:
+                self._state[0] = float(st["step"])
+                self._state[1] = 0.0
+                self.exp_avg.copy_(st["exp_avg"])
+                self.exp_avg_sq.copy_(st["exp_avg_sq"])
+        for k, v in sd["param_groups"][0].items():
+            if k != "params" and k in self._groups[0]:
+                self._groups[0][k] = v

@@ -325,6 +325,19 @@ int fsg_pt_attn_bwd_f32(const float *p, const int32_t *idx, const float *q, cons
                         float *grad_q, float *grad_k, float *grad_v, int64_t ldg, float *grad_p,
                         const fsg_pt_layer_grads *grads, void *workspace, fsg_stream_t stream);
 
+/*
+ * Adam over one flat fp32 buffer -- replaces torch.optim.Adam(model.parameters(), lr, weight_decay) of
+ * model_trainer.py:57 once the parameters live in one contiguous buffer (optim.FlatAdam).  Update rule of
+ * torch/optim/adam.py (L2 weight decay, no amsgrad, no maximize).  All four arrays (n) 16-byte aligned, updated in place.
+ *   state: 8 bytes, 8-byte aligned, zero-initialised by the caller once: { float step; uint32 ticket } -- the step count
+ *          lives on the device and is incremented by the call itself (the call is replayable inside a hipGraph).
+ *   lr_dev: nullable; when given, the learning rate is read from device memory (a scheduler can change it between
+ *          replays), otherwise `lr` is used.
+ */
+int fsg_adam_flat_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, void *state, int64_t n,
+                      float lr, const float *lr_dev, float beta1, float beta2, float eps, float weight_decay,
+                      fsg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1023,3 +1023,85 @@ def test_fps_and_segment_knn_properties(fsg, device):
     assert np.array_equal(idx_n[:, 0], np.arange(len(xyz))) and np.all(d2_n[:, 0] == 0)
     assert np.all(seg_of[idx_n] == seg_of[:, None])
     assert np.all((d2_n[:, :-1] < d2_n[:, 1:]) | ((d2_n[:, :-1] == d2_n[:, 1:]) & (idx_n[:, :-1] < idx_n[:, 1:])))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wd", [0.0, 1e-2])
+def test_flat_adam_matches_torch_adam(wd):
+    """optim.FlatAdam on the GPU (csrc/adam.hip, fsg_adam_flat_f32) == torch.optim.Adam over the separate tensors
+    (model_trainer.py:57), step by step; odd sizes exercise the non-float4 tail.  fp32 tolerance 1e-6 relative to the
+    update size (same rule, different association of the bias corrections)."""
+    from fissure_segmentation_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    shapes = [(7, 3), (5,), (33, 17), (1,), (64, 64, 1)]   # 4691 elements: 4691 % 4 == 3
+    a = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    oa = torch.optim.Adam(a, lr=1e-2, weight_decay=wd)
+    ob = FlatAdam(b, lr=1e-2, weight_decay=wd)
+    for step in range(12):
+        gs = [torch.randn_like(p) * (0.1 + step) for p in a]
+        for p, q, g in zip(a, b, gs):
+            p.grad, q.grad = g.clone(), g.clone()
+        oa.step(), ob.step()
+        for p, q in zip(a, b):
+            torch.testing.assert_close(q, p, rtol=1e-5, atol=2e-7)
+    assert float(ob.state_dict()["state"][0]["step"]) == 12.0
+    # state_dict round trip into a fresh optimizer continues identically
+    c = [torch.nn.Parameter(q.detach().clone()) for q in b]
+    oc = FlatAdam(c, lr=1e-2, weight_decay=wd)
+    oc.load_state_dict(ob.state_dict())
+    gs = [torch.randn_like(p) for p in a]
+    for q, r, g in zip(b, c, gs):
+        q.grad, r.grad = g.clone(), g.clone()
+    ob.step(), oc.step()
+    for q, r in zip(b, c):
+        assert torch.equal(q, r)
+
+
+@pytest.mark.gpu
+def test_flat_adam_graph_replay_and_device_lr():
+    """the update replayed inside a hipGraph advances its own device step count, and a tensor learning rate is re-read at
+    every replay (a scheduler can change it without re-capturing)"""
+    from fissure_segmentation_amd.optim import FlatAdam
+    torch.manual_seed(1)
+    w0 = torch.randn(5000, device="cuda")
+    ref_p = torch.nn.Parameter(w0.clone())
+    ref = torch.optim.Adam([ref_p], lr=1e-2)
+    p = torch.nn.Parameter(w0.clone())
+    lr = torch.tensor([1e-2], device="cuda")
+    opt = FlatAdam([p], lr=lr)
+    g = torch.randn(5000, device="cuda")
+    p.grad = g.clone()
+    opt.gather_grads()
+    graph = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(graph):
+            opt.step_flat()
+    torch.cuda.current_stream().wait_stream(s)
+    for step in range(6):
+        if step == 3:
+            lr.fill_(5e-3)
+            ref.param_groups[0]["lr"] = 5e-3
+        ref_p.grad = g.clone()
+        ref.step()
+        graph.replay()
+        torch.testing.assert_close(p, ref_p, rtol=1e-5, atol=2e-7)
+    assert float(opt.state_dict()["state"][0]["step"]) == 6.0
+
+
+@pytest.mark.gpu
+def test_flat_adam_error_paths():
+    from fissure_segmentation_amd import _lib
+    import ctypes
+    t = torch.zeros(64, device="cuda")
+    st = torch.zeros(2, device="cuda")
+    P = lambda x: ctypes.c_void_p(x.data_ptr())  # noqa: E731
+    with pytest.raises(RuntimeError, match="NULL"):
+        _lib.call("fsg_adam_flat_f32", P(t), None, P(t), P(t), P(st), 64, 1e-3, None, 0.9, 0.999, 1e-8, 0.0, None)
+    with pytest.raises(RuntimeError, match="aligned"):
+        _lib.call("fsg_adam_flat_f32", ctypes.c_void_p(t.data_ptr() + 4), P(t), P(t), P(t), P(st), 32, 1e-3, None, 0.9,
+                  0.999, 1e-8, 0.0, None)
+    with pytest.raises(RuntimeError, match="hyper"):
+        _lib.call("fsg_adam_flat_f32", P(t), P(t), P(t), P(t), P(st), 64, 1e-3, None, 1.0, 0.999, 1e-8, 0.0, None)
