@@ -172,7 +172,7 @@ def test_edge_features_vs_c_oracle(fsg, device, B, C, Np, k):
     np.testing.assert_allclose(N(xt.grad), c_api.edge_features_bwd(gr, idx), rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("B,Np,k", [(8, 2048, 20), (4, 8192, 40), (3, 77, 5), (1, 1, 1)])
+@pytest.mark.parametrize("B,Np,k", [(8, 2048, 20), (4, 8192, 40), (2, 9000, 8), (3, 77, 5), (1, 1, 1)])
 def test_reverse_graph_csr(fsg, device, B, Np, k):
     """CSR by destination (fsg_graph_reverse_csr): both builders (16 workgroups per cloud with a workspace, one without)
     must hold exactly the in-edges (source << 6 | slot) of every destination, ascending inside a row (rows above 1024
