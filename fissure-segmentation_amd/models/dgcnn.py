@@ -267,6 +267,15 @@ class DGCNNReg(DGCNNBase):
 
     def predict_full_pointcloud(self, pc, sample_points=1024, n_runs_min=50):
         acc = torch.zeros(pc.shape[0], self.num_classes, 1, device=pc.device)
+        if self._ensemble_batchable(pc):    # eval mode: the runs are independent clouds -> batches of runs, summed in run order
+            B, per = pc.shape[0], max(1, self.ensemble_max_clouds // max(pc.shape[0], 1))
+            pts = torch.stack([torch.randperm(pc.shape[-1], device=pc.device)[:sample_points] for _ in range(n_runs_min)])
+            for r0 in range(0, n_runs_min, per):
+                chunk = pts[r0:r0 + per]
+                x = pc[:, :, chunk].permute(2, 0, 1, 3).reshape(chunk.shape[0] * B, pc.shape[1], chunk.shape[1])
+                for o in self(x).view(chunk.shape[0], B, self.num_classes, 1):
+                    acc += o
+            return acc / n_runs_min
         for _ in range(n_runs_min):
             acc += self(pc[..., torch.randperm(pc.shape[-1], device=pc.device)[:sample_points]])
         return acc / n_runs_min

@@ -338,6 +338,20 @@ int fsg_adam_flat_f32(float *param, const float *grad, float *exp_avg, float *ex
                       float lr, const float *lr_dev, float beta1, float beta2, float eps, float weight_decay,
                       fsg_stream_t stream);
 
+/*
+ * Accumulation step of the test-time ensembling `predict_full_pointcloud` (models/point_seg_net.py:21-48; the loop body
+ * `softmax_accumulation[..., perm] += softmax(net(pc[..., perm]))` of :27-29 and :40-44) for R runs at once:
+ *   logits (R,B,cls,S) fp32 contiguous -- the net's output for the R subsets, run as one batch of R*B clouds
+ *   pts    (R,S) int64 -- the point indices of every run (indices outside [0,n_points) are ignored)
+ *   acc    (B,cls,n_points) fp32, updated in place:  acc[b,:,pts[r,s]] += softmax_c(logits[r,b,:,s]),  runs applied in
+ *          the order r = 0..R-1 per point (same association as the reference's loop; no float atomics).  When a run
+ *          names a point more than once, the highest slot s is the one added (the reference's indexed += also adds one).
+ *   cls <= 32.  workspace: fsg_ensemble_accumulate_workspace_bytes(R, n_points), 4-byte aligned.
+ */
+size_t fsg_ensemble_accumulate_workspace_bytes(int R, int64_t n_points);
+int fsg_ensemble_accumulate_f32(const float *logits, int R, int B, int cls, int S, const int64_t *pts, int64_t n_points,
+                                float *acc, void *workspace, fsg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

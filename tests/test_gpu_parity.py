@@ -644,6 +644,101 @@ def test_predict_full_pointcloud(fsg, device):
     torch.testing.assert_close(out.sum(1), torch.ones(1, 700, device=device))
 
 
+@pytest.mark.parametrize("model", ["dgcnn", "dgcnn_static", "pointnet", "pointtransformer"])
+def test_predict_full_pointcloud_batched_equals_sequential(fsg, device, model):
+    """eval-mode ensembling: the batched form (all runs of a phase in one forward + fsg_ensemble_accumulate_f32) against
+    the reference's sequential loop (point_seg_net.py:21-48) under the same generator state.  3000 points, 8 + 2 runs of
+    256: the first phase cannot see every point, so the fill-up phase (duplicated indices included) runs too.
+    Tolerance 1e-5 on the class probabilities (batch size changes the GEMM tiling, nothing else)."""
+    from fissure_segmentation_amd.models.dgcnn import DGCNNSeg
+    from fissure_segmentation_amd.models.point_net import PointNetSeg
+    from fissure_segmentation_amd.models.pointtransformer.seg_model import PointTransformerCompatibility
+    torch.manual_seed(3)
+    if model == "dgcnn":
+        net = DGCNNSeg(k=8, in_features=3, num_classes=4)
+    elif model == "dgcnn_static":
+        net = DGCNNSeg(k=8, in_features=3, num_classes=4, dynamic=False)
+    elif model == "pointnet":
+        net = PointNetSeg(3, 4)
+    else:
+        net = PointTransformerCompatibility(3, 4)
+    net = net.to(device)
+    pc = G(cloud(11, 1, 3, 3000), device)
+    net.train()
+    with torch.no_grad():                      # running statistics away from their initial values
+        for _ in range(2):
+            net(pc[..., :512].contiguous())
+    net.eval()
+    assert net._ensemble_batchable(pc) is False      # grad mode on: sequential form
+    with torch.no_grad():
+        assert net._ensemble_batchable(pc)
+        torch.manual_seed(77)
+        got = net.predict_full_pointcloud(pc, sample_points=256, n_runs_min=10)
+        net._ensemble_batchable = lambda _pc: False
+        torch.manual_seed(77)
+        want = net.predict_full_pointcloud(pc, sample_points=256, n_runs_min=10)
+    assert got.shape == want.shape == (1, 4, 3000)
+    torch.testing.assert_close(got, want, rtol=0, atol=1e-5)
+    net.train()
+    del net._ensemble_batchable
+    assert net._ensemble_batchable(pc) is False      # train mode couples the batch through BatchNorm
+
+
+def test_predict_full_pointcloud_regression_batched(fsg, device):
+    """DGCNNReg.predict_full_pointcloud (mean of the runs' outputs): batched eval-mode form == sequential loop, 1e-5"""
+    from fissure_segmentation_amd.models.dgcnn import DGCNNReg
+    torch.manual_seed(4)
+    net = DGCNNReg(k=8, in_features=3, num_classes=6).to(device)
+    pc = G(cloud(12, 2, 3, 1500), device)
+    net.train()
+    with torch.no_grad():
+        net(pc[..., :512].contiguous())
+    net.eval()
+    with torch.no_grad():
+        torch.manual_seed(5)
+        got = net.predict_full_pointcloud(pc, sample_points=256, n_runs_min=7)
+        net._ensemble_batchable = lambda _pc: False
+        torch.manual_seed(5)
+        want = net.predict_full_pointcloud(pc, sample_points=256, n_runs_min=7)
+    assert got.shape == want.shape == (2, 6, 1)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_ensemble_accumulate_kernel(fsg, device):
+    """fsg_ensemble_accumulate_f32 against the loop it replaces, in numpy: run order per point, duplicates inside a run
+    (highest slot wins), indices outside the cloud ignored, B = 2 clouds sharing the subsets, 5 classes"""
+    import ctypes
+    rng = np.random.default_rng(5)
+    R, B, cls, S, P_ = 7, 2, 5, 300, 1000
+    logits = rng.standard_normal((R, B, cls, S)).astype(np.float32) * 3
+    pts = np.stack([rng.permutation(P_)[:S] for _ in range(R)]).astype(np.int64)
+    pts[2, 10:20] = pts[2, 0]          # duplicates inside run 2
+    pts[4, 5] = P_ + 3                 # outside the cloud
+    pts[4, 6] = -1
+    acc0 = rng.standard_normal((B, cls, P_)).astype(np.float32)
+    want = acc0.copy()
+    for r in range(R):
+        e = np.exp(logits[r] - logits[r].max(1, keepdims=True))
+        sm = (e / e.sum(1, keepdims=True)).astype(np.float32)
+        last = {}
+        for s_, p in enumerate(pts[r]):
+            if 0 <= p < P_:
+                last[int(p)] = s_
+        for p, s_ in last.items():
+            want[:, :, p] += sm[:, :, s_]
+    lt, pt, acc = G(logits, device), torch.from_numpy(pts).to(device), G(acc0, device)
+    ws = torch.empty(fsg._lib.lib.fsg_ensemble_accumulate_workspace_bytes(R, P_) // 4, dtype=torch.int32, device=device)
+    Pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    fsg._lib.call("fsg_ensemble_accumulate_f32", Pp(lt), R, B, cls, S, Pp(pt), P_, Pp(acc), Pp(ws), st)
+    np.testing.assert_allclose(N(acc), want, rtol=1e-6, atol=1e-6)
+    fsg._lib.call("fsg_ensemble_accumulate_f32", Pp(lt), 0, B, cls, S, Pp(pt), P_, Pp(acc), Pp(ws), st)   # empty: no-op
+    with pytest.raises(RuntimeError, match="cls"):
+        fsg._lib.call("fsg_ensemble_accumulate_f32", Pp(lt), R, B, 33, S, Pp(pt), P_, Pp(acc), Pp(ws), st)
+    with pytest.raises(RuntimeError, match="NULL"):
+        fsg._lib.call("fsg_ensemble_accumulate_f32", Pp(lt), R, B, cls, S, Pp(pt), P_, Pp(acc), None, st)
+
+
 # --------------------------------------------------------------------------- fused EdgeConv vs unfused composition
 @pytest.mark.parametrize("B,C,Np,k,Co,train", [(2, 64, 300, 20, 64, True), (1, 3, 77, 7, 128, True),
                                                (3, 15, 513, 40, 64, False), (2, 128, 256, 8, 256, True)])
