@@ -124,6 +124,17 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     int b = blockIdx.y, q0 = blockIdx.x * QB;
+    if (!SEG && !(flags & 65536)) {   // flag 65536: plain placement (A/B timing)
+        // XCD-aware placement: workgroups go to the 8 XCDs round-robin by linear id, so consecutive ids of one cloud
+        // would spread every cloud over all eight L2s.  Renumber so that XCD x owns a contiguous 1/8 of the (cloud, tile)
+        // space: with 8 clouds each L2 holds exactly one cloud's features.
+        const unsigned L = blockIdx.x + gridDim.x * blockIdx.y, total = gridDim.x * gridDim.y;
+        if ((total & 7u) == 0) {
+            const unsigned V = (L & 7u) * (total >> 3) + (L >> 3);
+            b = (int)(V / gridDim.x);
+            q0 = (int)(V % gridDim.x) * QB;
+        }
+    }
     int NQ = N;             // queries of this cloud / segment
     long cbase = 0, qbase = 0;  // first candidate / query row of the segment (SEG)
     if (SEG) {
@@ -204,6 +215,96 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
                 }
             }
         }
+        // Fast path, chunk entirely inside the cloud (every chunk when N is a multiple of CH): the wave's CH/16/WAVES
+        // tiles fully unrolled over two operand register sets (no copies), unconditional loads off one per-lane element
+        // offset (the generic loop below spends ~230 VALU issues per tile on per-load predicates, address pairs and
+        // operand copies against 32 MFMAs: rocprofv3 SQ_INSTS_VALU 17.1 M vs SQ_INSTS_MFMA 2.1 M per launch at C=64),
+        // and the diagonal / out-of-range fix-ups only in the one or two tiles that can need them.  Same arithmetic.
+        const bool full_chunk = !SEG && KS <= 16 && c0 + CH <= N && (long)c_knn * sc < (1L << 29) &&
+                                !(flags & (512 | 32768));   // 32768: generic path (tests)
+        if (full_chunk) {
+            constexpr int TPW = CH / 16 / WAVES;
+            static_assert(TPW % 2 == 0, "tiles per wave must be even (two operand register sets)");
+            // operand loads through a buffer resource over the c_knn channel rows of this cloud: ONE per-lane byte offset
+            // (channel l4, candidate col) + a scalar offset of four channel rows per MFMA step, instead of 16 per-lane
+            // 64-bit pointers (32 VGPRs -- the compiler's choice for plain pointers); channels >= c_knn fall outside the
+            // resource and read as 0, which is exactly the zero padding of the last K group.
+            const uintptr_t xba = reinterpret_cast<uintptr_t>(xb);   // uniform by construction: tell the compiler so
+            const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xba);
+            const unsigned xhi = __builtin_amdgcn_readfirstlane((unsigned)(xba >> 32));
+            const int nrec = __builtin_amdgcn_readfirstlane((int)((long)c_knn * sc * 4));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<void *>(((uintptr_t)xhi << 32) | xlo), 0, nrec, 0x00020000);
+            const unsigned col0 = (unsigned)(c0 + wave * 16 + l15);   // this lane's candidate in the wave's first tile
+            const unsigned sc32f = (unsigned)sc;
+            float b0[KS], b1[KS], x0, x1;
+            auto ld = [&](float (&bt)[KS], float &xt, unsigned col) {
+                const unsigned vo = ((unsigned)l4 * sc32f + col) * 4u;
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+                    bt[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (unsigned)(16 * s) * sc32f, 0));
+                xt = xxb[col];
+            };
+            auto tile = [&](const float (&bt)[KS], float xc, int t) {
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                if (QAL) {
+                    // the A operand is re-read from LDS for every tile ON PURPOSE (it would cost 2 KS registers): the
+                    // offset goes through an empty asm so that the reads are not hoisted out of the tile loop
+                    int qoff = l4 * 16 + l15;
+                    asm volatile("" : "+v"(qoff));
+                    float qh[KS];
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) qh[s] = qal[64 * s + qoff];
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qh[s], bt[s], acc0, 0, 0, 0);
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) qh[s] = qal[64 * KS + 64 * s + qoff];
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qh[s], bt[s], acc1, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[0][QAL ? 0 : s], bt[s], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[QAL ? 0 : 1][QAL ? 0 : s], bt[s], acc1, 0, 0, 0);
+                    }
+                }
+                const int drel = c0 + t * 16 - q0;   // wave-uniform: columns drel .. drel+15 against the rows 0 .. 31
+                float *dst = rows + (l4 * 4) * STRIDE + t * 16 + l15;
+                if (fix_diag && drel > -16 && drel < QB) {
+                    const int jc = c0 + t * 16 + l15;
+#pragma unroll
+                    for (int blk = 0; blk < 2; ++blk) {
+                        const f32x4 acc = blk ? acc1 : acc0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int qr = blk * 16 + l4 * 4 + e;
+                            const float tt = xxq[blk][e] - 2.0f * acc[e];
+                            float d = tt + xc;
+                            if (jc == q0 + qr) d = 0.f;
+                            dst[(blk * 16 + e) * STRIDE] = d;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int blk = 0; blk < 2; ++blk) {
+                        const f32x4 acc = blk ? acc1 : acc0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float tt = xxq[blk][e] - 2.0f * acc[e];
+                            dst[(blk * 16 + e) * STRIDE] = tt + xc;
+                        }
+                    }
+                }
+            };
+            ld(b0, x0, col0);
+#pragma unroll 1
+            for (int i = 0; i < TPW; i += 2) {
+                ld(b1, x1, col0 + (unsigned)((i + 1) * WAVES * 16));
+                tile(b0, x0, wave + i * WAVES);
+                if (i + 2 < TPW) ld(b0, x0, col0 + (unsigned)((i + 2) * WAVES * 16));
+                tile(b1, x1, wave + (i + 1) * WAVES);
+            }
+        }
         float bn[KS], xn = 0.f;   // operand of the NEXT tile of this wave: its loads fly while the current MFMAs run
         // 32-bit element offsets from the (uniform) cloud base: one VGPR per address instead of a 64-bit pair
         const unsigned sc32 = (unsigned)sc;
@@ -217,8 +318,8 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
             xn = jc < N ? xxb[(unsigned)jc] : 0.f;
         };
         constexpr bool PREFETCH = KS <= 16;  // no registers to spare at 128 channels
-        if (!SEG && PREFETCH && wave < ntile && !(flags & 512)) load_tile(wave);
-        for (int t = wave; t < (SEG ? 0 : CH / 16); t += WAVES) {
+        if (!SEG && !full_chunk && PREFETCH && wave < ntile && !(flags & 512)) load_tile(wave);
+        for (int t = wave; t < ((SEG || full_chunk) ? 0 : CH / 16); t += WAVES) {
             if (t >= ntile || (flags & 512)) {  // beyond the cloud (flag 512: timing ablation of phase A)
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk)
