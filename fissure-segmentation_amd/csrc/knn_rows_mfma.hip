@@ -215,13 +215,14 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
                 }
             }
         }
-        // Fast path, chunk entirely inside the cloud (every chunk when N is a multiple of CH): the wave's CH/16/WAVES
-        // tiles fully unrolled over two operand register sets (no copies), unconditional loads off one per-lane element
-        // offset (the generic loop below spends ~230 VALU issues per tile on per-load predicates, address pairs and
-        // operand copies against 32 MFMAs: rocprofv3 SQ_INSTS_VALU 17.1 M vs SQ_INSTS_MFMA 2.1 M per launch at C=64),
-        // and the diagonal / out-of-range fix-ups only in the one or two tiles that can need them.  Same arithmetic.
-        const bool full_chunk = !SEG && KS <= 16 && c0 + CH <= N && (long)c_knn * sc < (1L << 29) &&
-                                !(flags & (512 | 32768));   // 32768: generic path (tests)
+        // Phase A proper (every variant up to 64 channels): the wave's CH/16/WAVES tiles over two operand register sets
+        // (no copies), unconditional loads off one per-lane offset, and the diagonal / out-of-range fix-ups only in the
+        // tiles that can need them (wave-uniform tests).  The first version of this loop spent ~230 VALU issues per
+        // tile on per-load predicates, 64-bit address pairs and operand copies against 32 MFMAs (rocprofv3:
+        // SQ_INSTS_VALU 17.1 M vs SQ_INSTS_MFMA 2.1 M per launch at C=64); it survives below for 128 channels only.
+        // (Requesting the next chunk's first tile before the end-of-chunk barrier was tried: the 17 registers held
+        // across the barrier cost more in spills at 64 channels than the hidden latency returns.)
+        constexpr bool full_chunk = !SEG && KS <= 16;   // (the launcher checks that c_knn * stride_c fits the resource)
         if (full_chunk) {
             constexpr int TPW = CH / 16 / WAVES;
             static_assert(TPW % 2 == 0, "tiles per wave must be even (two operand register sets)");
@@ -243,24 +244,27 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
 #pragma unroll
                 for (int s = 0; s < KS; ++s)
                     bt[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (unsigned)(16 * s) * sc32f, 0));
-                xt = xxb[col];
+                xt = xxb[min(col, (unsigned)(N - 1))];   // columns >= N: any finite value, the epilogue writes +inf
             };
             auto tile = [&](const float (&bt)[KS], float xc, int t) {
+                float *dst = rows + (l4 * 4) * STRIDE + t * 16 + l15;
+                if (c0 + t * 16 >= N || (flags & 512)) {   // tile beyond the cloud (wave-uniform): nothing to compute
+                                                           // (flag 512: timing ablation of phase A)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) dst[((r >> 2) * 16 + (r & 3)) * STRIDE] = INFINITY;
+                    return;
+                }
                 f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                 if (QAL) {
                     // the A operand is re-read from LDS for every tile ON PURPOSE (it would cost 2 KS registers): the
                     // offset goes through an empty asm so that the reads are not hoisted out of the tile loop
                     int qoff = l4 * 16 + l15;
                     asm volatile("" : "+v"(qoff));
-                    float qh[KS];
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) qh[s] = qal[64 * s + qoff];
-#pragma unroll
-                    for (int s = 0; s < KS; ++s) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qh[s], bt[s], acc0, 0, 0, 0);
-#pragma unroll
-                    for (int s = 0; s < KS; ++s) qh[s] = qal[64 * KS + 64 * s + qoff];
-#pragma unroll
-                    for (int s = 0; s < KS; ++s) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qh[s], bt[s], acc1, 0, 0, 0);
+                    for (int s = 0; s < KS; ++s) {   // two independent accumulator chains, alternating
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qal[64 * s + qoff], bt[s], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qal[64 * KS + 64 * s + qoff], bt[s], acc1, 0, 0, 0);
+                    }
                 } else {
 #pragma unroll
                     for (int s = 0; s < KS; ++s) {
@@ -269,8 +273,7 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
                     }
                 }
                 const int drel = c0 + t * 16 - q0;   // wave-uniform: columns drel .. drel+15 against the rows 0 .. 31
-                float *dst = rows + (l4 * 4) * STRIDE + t * 16 + l15;
-                if (fix_diag && drel > -16 && drel < QB) {
+                if ((fix_diag && drel > -16 && drel < QB) || c0 + t * 16 + 16 > N) {
                     const int jc = c0 + t * 16 + l15;
 #pragma unroll
                     for (int blk = 0; blk < 2; ++blk) {
@@ -280,7 +283,8 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
                             const int qr = blk * 16 + l4 * 4 + e;
                             const float tt = xxq[blk][e] - 2.0f * acc[e];
                             float d = tt + xc;
-                            if (jc == q0 + qr) d = 0.f;
+                            if (fix_diag && jc == q0 + qr) d = 0.f;
+                            if (jc >= N) d = INFINITY;
                             dst[(blk * 16 + e) * STRIDE] = d;
                         }
                     }
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
         };
         constexpr bool PREFETCH = KS <= 16;  // no registers to spare at 128 channels
         if (!SEG && !full_chunk && PREFETCH && wave < ntile && !(flags & 512)) load_tile(wave);
-        for (int t = wave; t < ((SEG || full_chunk) ? 0 : CH / 16); t += WAVES) {
+        for (int t = wave; t < ((SEG || full_chunk) ? 0 : CH / 16); t += WAVES) {   // 128 channels only
             if (t >= ntile || (flags & 512)) {  // beyond the cloud (flag 512: timing ablation of phase A)
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk)
@@ -544,6 +548,7 @@ int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int
                              int32_t *idx_out, float *dist_out, float *xx_scratch, hipStream_t st) {
     const int drop = (flags & FSG_KNN_DROP_FIRST) ? 1 : 0;
     if (c_knn > 128 || k + drop > 64 || N > 65535 * 16 || xx_scratch == nullptr) return FSG_ERR_UNSUPPORTED;
+    if (c_knn <= 64 && (long)c_knn * stride_c >= (1L << 29)) return FSG_ERR_UNSUPPORTED;   // buffer resource: 2 GB
     hipLaunchKernelGGL(knn_sqnorm2_kernel, dim3(fsg_cdiv(N, 256), B), dim3(256), 0, st, x, N, (long)stride_b,
                        (long)stride_c, c_knn, xx_scratch);
     FSG_CHECK_LAUNCH("fsg_knn_dense_f32/sqnorm");
