@@ -92,7 +92,7 @@ __device__ __forceinline__ void sort64(T &v, int lane) {
 }
 
 // WAVES waves per workgroup (16 when the register budget allows: everything here is latency-bound, so thread-level
-// parallelism is the lever), SURV = survivor slots per wave
+// parallelism is the lever), SURV = survivor slots per row (they live in the row's own LDS storage once it is read)
 // SEG = true: the packed-segment query of the PointTransformer path (fsg_knn_segment_f32): x = candidate coordinates
 // (n,3), xq = query coordinates (m,3), cumulative segment ends in seg_c / seg_q; phase A evaluates the direct form
 // fma(dz,dz, fma(dy,dy, dx*dx)) on the VALU (bit-identical to the oracle's orc_knn_segment_f32), phase B is shared.
@@ -115,8 +115,7 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *rows = reinterpret_cast<float *>(smem);                                        // [QB][STRIDE]
     u64 *carry = reinterpret_cast<u64 *>(smem + sizeof(float) * QB * STRIDE);             // [QB][CK] best list so far
-    u64 *surv = carry + QB * CK;                                                          // [WAVES][SURV]
-    int *ccount = reinterpret_cast<int *>(surv + WAVES * SURV);                           // [QB]
+    int *ccount = reinterpret_cast<int *>(carry + QB * CK);                               // [QB]
     // A operand copy (QAL only): [2 query halves][4*KS channels][16 queries].  Lane (l4, l15) reads channel 4s + l4,
     // query l15 of a half -> word 16 (4s + l4) + l15: the 64 lanes of a wave hit the 64 LDS banks exactly once.
     float *qal = reinterpret_cast<float *>(ccount + QB);
@@ -378,7 +377,6 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
         for (int qi = wave; qi < QB; qi += WAVES) {
             if (q0 + qi >= NQ || (flags & 256)) break;  // flag 256: timing ablation of phase B
             const float *row = rows + qi * STRIDE;
-            u64 *sv = surv + wave * SURV;
             float v[VPL];
 #pragma unroll
             for (int s = 0; s < VPL / 4; ++s) {
@@ -386,6 +384,11 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[4 * s + e] = w[e];
             }
+            // the row now lives in registers: its LDS storage (4 KB, 8-byte aligned) becomes the survivor buffer of this
+            // wave (up to SURV entries).  LDS serves a wave's instructions in order, so the reads above are ahead of every
+            // write below; the empty asm keeps the compiler from moving a store (different type: no alias assumed) up.
+            asm volatile("" ::: "memory");
+            u64 *sv = reinterpret_cast<u64 *>(rows + qi * STRIDE);
             const int cc = ccount[qi];
             unsigned tau;
             if (cc >= KK) {
@@ -556,7 +559,7 @@ int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int
 #define FSG_KNN_RM(KS, WV, SV, CHK, CKK) FSG_KNN_RMQ(KS, WV, SV, CHK, CKK, false)
 #define FSG_KNN_RMQ(KS, WV, SV, CHK, CKK, QL)                                                                          \
     do {                                                                                                               \
-        const size_t lds = sizeof(float) * QB * ((CHK) + 4) + sizeof(u64) * (QB * (CKK) + (WV) * (SV)) + sizeof(int) * QB + \
+        const size_t lds = sizeof(float) * QB * ((CHK) + 4) + sizeof(u64) * (QB * (CKK)) + sizeof(int) * QB +           \
                            ((QL) ? sizeof(float) * 4 * (KS) * QB : 0);                                                 \
         static bool granted = false;                                                                                   \
         if (!granted) {                                                                                                \
@@ -575,12 +578,15 @@ int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int
     // 512-candidate chunks fit two workgroups per CU in LDS but not in registers (241 VGPRs -> 2 waves/SIMD): measured
     // 148 us against 136 us for the 1024-candidate chunks at C=64, so they are opt-in (flag 2048, tests)
     const bool half = small_k && (flags & 2048);
-    if (c_knn <= 4) { if (small_k) FSG_KNN_RM(1, 16, 96, 1024, 64); else FSG_KNN_RM(1, 8, 128, 1024, 64); }
-    else if (c_knn <= 16) FSG_KNN_RM(4, 8, 128, 1024, 64);
+    // 16 waves per workgroup wherever the registers allow (both phases are latency-bound); flag 8192: the 8-wave variants
+    const bool w8 = (flags & 8192) != 0;
+    if (c_knn <= 4) { if (!w8) FSG_KNN_RM(1, 16, 128, 1024, 64); else FSG_KNN_RM(1, 8, 128, 1024, 64); }
+    else if (c_knn <= 16) { if (!w8) FSG_KNN_RM(4, 16, 128, 1024, 64); else FSG_KNN_RM(4, 8, 128, 1024, 64); }
     else if (c_knn <= 64) {
         if (half) FSG_KNN_RM(16, 8, 64, 512, 32);
-        else if (small_k && !(flags & 8192)) FSG_KNN_RMQ(16, 16, 96, 1024, 32, true);   // flag 8192: the 8-wave variant
-        else FSG_KNN_RM(16, 8, 128, 1024, 64);
+        else if (w8) FSG_KNN_RM(16, 8, 128, 1024, 64);
+        else if (small_k) FSG_KNN_RMQ(16, 16, 128, 1024, 32, true);
+        else FSG_KNN_RMQ(16, 16, 128, 1024, 64, true);   // 131.6 KB rows + 16 KB best lists + 8 KB query operand
     }
     else { if (half) FSG_KNN_RM(32, 8, 64, 512, 32); else FSG_KNN_RM(32, 8, 128, 1024, 64); }
 #undef FSG_KNN_RM
@@ -594,7 +600,7 @@ int fsg_knn_segment_rows_launch(const float *xyz, const float *new_xyz, const in
                                 int b, int n, int m, int nsample, int32_t *idx, float *dist2, hipStream_t st) {
     if (nsample > 32 || b > 4096) return FSG_ERR_UNSUPPORTED;
     constexpr int WV = 16, SV = 96, CHK = 1024, CKK = 64;
-    const size_t lds = sizeof(float) * QB * (CHK + 4) + sizeof(u64) * (QB * CKK + WV * SV) + sizeof(int) * QB;
+    const size_t lds = sizeof(float) * QB * (CHK + 4) + sizeof(u64) * (QB * CKK) + sizeof(int) * QB;
     static bool granted = false;
     if (!granted) {
         if (hipFuncSetAttribute((const void *)knn_rows_mfma_kernel<1, WV, SV, CHK, CKK, true>,

@@ -7,14 +7,14 @@ import fissure_segmentation_amd as fsg
 from golden_util import cloud
 F = fsg.functional
 dev = torch.device("cuda:0")
-VARIANTS = (("full", 0), ("noB", 256), ("neither", 768), ("plain-placement", 65536))
+VARIANTS = (("full", 0), ("noB", 256), ("neither", 768), ("half-chunks", 2048), ("8-wave", 8192))
 def med(fn, n=20):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ts = []
     for _ in range(n):
         s.record(); fn(); e.record(); torch.cuda.synchronize(); ts.append(1e3 * s.elapsed_time(e))
     return float(np.median(ts))
-for (B, C, N, k) in [(8, 64, 2048, 20), (8, 3, 2048, 20), (4, 64, 8192, 40)]:
+for (B, C, N, k) in [(8, 64, 2048, 20), (8, 3, 2048, 20), (4, 64, 8192, 40), (4, 3, 8192, 40), (8, 12, 2048, 20)]:
     x = torch.from_numpy(cloud(1, B, C, N)).to(dev)
     best = {n: 1e9 for n, _ in VARIANTS}
     for _ in range(200): F.knn_graph(x, k)          # clocks up
