@@ -4,7 +4,7 @@
 // flat buffer of optim.FlatAdam torch's fused kernel is a single launch, but a chunked one: 64 Ki elements per
 // workgroup = 28 workgroups for the 1.8 M parameters of DGCNN-seg on a 256-CU chip (43 us per step in
 // profiles/r1_bench_c2_kernel_stats.csv, against 50 MB of traffic = 6 us at HBM rate).  This kernel streams the four
-// arrays as float4 with one workgroup per 1024 elements.
+// arrays as float4, 1024 grid-stride workgroups.
 //
 // The step count lives on the device (the update is replayed inside a hipGraph, so nothing per-step may come from the
 // host): every workgroup reads it at entry, the LAST workgroup to finish (ticket counter) increments it -- by then all
@@ -87,9 +87,11 @@ extern "C" int fsg_adam_flat_f32(float *param, const float *grad, float *exp_avg
     FSG_REQUIRE(((uintptr_t)state & 7) == 0, "fsg_adam_flat_f32: state must be 8-byte aligned");
     FSG_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f,
                 "fsg_adam_flat_f32: bad hyper-parameters beta1=%g beta2=%g eps=%g", beta1, beta2, eps);
+    // four workgroups per CU, grid-stride: every workgroup pays two fp64 pow() in one thread before its first load, so
+    // few fat workgroups beat one per 1024 elements (7.8 M parameters: 96 us with 7.6 K workgroups)
     long blocks = ((n >> 2) + 255) / 256;
     if (blocks < 1) blocks = 1;
-    if (blocks > 8192) blocks = 8192;  // grid-stride above 8 M elements
+    if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                        exp_avg_sq, (AdamState *)state, (long)n, lr, lr_dev, beta1, beta2, eps, weight_decay);
     FSG_CHECK_LAUNCH("fsg_adam_flat_f32");
