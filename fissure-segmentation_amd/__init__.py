@@ -8,6 +8,7 @@ if their input is not on a GPU or the library is missing.
 """
 from . import _lib  # noqa: F401  (fails loudly when libfsg_hip.so is absent)
 from . import functional  # noqa: F401
+from . import augmentations  # noqa: F401
 
 __version__ = "0.1.0"
 

@@ -24,3 +24,32 @@ def pairwise_dist(x):
     ar = torch.arange(x.shape[1], device=x.device)
     d[:, ar, ar] = 0
     return d
+
+
+def farthest_point_sampling(kpts, num_points, start=None):
+    """Drop-in for the pure-torch loop of dseg_ae_regularization.py:30-43 (used at :85 to pick the auto-encoder's input
+    points of one object): `kpts (1,N,3)` -> `(kpts[:, ind, :], ind)` with `ind (num_points,) int64`.  The reference's
+    `torch.argmax(dist)` runs over the flattened (B,N) distances, so it is only meaningful -- and only ever called -- with
+    one cloud; B > 1 raises here.
+
+    One `fsg_fps_f32` launch instead of `num_points` arg-max round trips.  The reference starts at a random point
+    (`torch.randint(N, (1,))`); the kernel starts a segment at its first row, so the cloud is rotated to put the start
+    there (`start` fixes it for tests).  Distances are the direct form (x-y)^2 as in the reference; ties (measure zero on
+    real data) go to the first point after the start instead of the lowest index."""
+    B, N, _ = kpts.size()
+    if N <= num_points:
+        if N < num_points:
+            print(f'Tried to sample {num_points} from a point cloud with only {N}')
+        return kpts, torch.arange(N)
+    if B != 1:
+        raise ValueError("farthest_point_sampling: one cloud at a time (the reference shares one index list and is "
+                         "called with B = 1)")
+    if not kpts.is_cuda:
+        raise RuntimeError("farthest_point_sampling (HIP path) needs its input on the GPU")
+    if start is None:
+        start = int(torch.randint(N, (1,)))
+    pts = torch.roll(kpts[0].to(torch.float32), -start, 0).contiguous()
+    offset = torch.tensor([N], dtype=torch.int32, device=kpts.device)
+    new_offset = torch.tensor([num_points], dtype=torch.int32, device=kpts.device)
+    ind = (F_hip.fps(pts, offset, new_offset, num_points).long() + start) % N
+    return kpts[:, ind, :], ind

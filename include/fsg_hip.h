@@ -352,6 +352,16 @@ size_t fsg_ensemble_accumulate_workspace_bytes(int R, int64_t n_points);
 int fsg_ensemble_accumulate_f32(const float *logits, int R, int B, int cls, int S, const int64_t *pts, int64_t n_points,
                                 float *acc, void *workspace, fsg_stream_t stream);
 
+/*
+ * On-device sampling + augmentation, the step in front of the path: data.py:435-460 (random `sample_points` subset of an
+ * item) after augmentations.py:52-113 (random rotation / scale / translation of the coordinate rows), one pass:
+ *   x (B,C,N) fp32;  sample (B,S) int64 column indices in [0,N), or NULL (then S == N: identity subset);
+ *   affine (B,12) fp32 = row-major [A | t] (3 x 4, column-vector form  x' = A x + t) applied to rows 0..2, or NULL;
+ *   out (B,C,S):  out[b,0:3,i] = A_b x[b,0:3,sample[b,i]] + t_b,  out[b,3:,i] = x[b,3:,sample[b,i]].
+ */
+int fsg_sample_transform_f32(const float *x, int B, int C, int64_t N, const int64_t *sample, int S, const float *affine,
+                             float *out, fsg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -578,3 +578,47 @@ class NNULoss(nn.Module):
     def forward(self, prediction, target):
         total, ce, gdl = nnu_loss(prediction, target, self.class_weights)
         return total, {"CE": ce, "GDL": gdl}
+
+
+def farthest_point_sampling(kpts, num_points, start):
+    """dseg_ae_regularization.py:30-43 with the random start passed in (pure torch, CPU)"""
+    _, N, _ = kpts.size()
+    ind = torch.zeros(num_points).long()
+    ind[0] = start
+    dist = torch.sum((kpts - kpts[:, ind[0], :]) ** 2, dim=2)
+    for i in range(1, num_points):
+        ind[i] = torch.argmax(dist)
+        dist = torch.min(dist, torch.sum((kpts - kpts[:, ind[i], :]) ** 2, dim=2))
+    return kpts[:, ind, :], ind
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# augmentations.py:52-113 + data.py:435-460, restated without pytorch3d (parity unpinned: pytorch3d is not vendored).
+# so3_exp_map: Rodrigues' formula as published by pytorch3d (eps 1e-4 on the squared norm); Transform3d: row-vector
+# convention, rotate -> scale -> translate.  tests/ cross-check the rotation against scipy's Rotation.from_rotvec.
+def so3_exp_map(log_rot, eps=1e-4):
+    theta = torch.clamp((log_rot * log_rot).sum(1), eps).sqrt()
+    K = torch.zeros(log_rot.shape[0], 3, 3, dtype=log_rot.dtype)
+    K[:, 0, 1], K[:, 0, 2] = -log_rot[:, 2], log_rot[:, 1]
+    K[:, 1, 0], K[:, 1, 2] = log_rot[:, 2], -log_rot[:, 0]
+    K[:, 2, 0], K[:, 2, 1] = -log_rot[:, 1], log_rot[:, 0]
+    f1 = (theta.sin() / theta)[:, None, None]
+    f2 = ((1 - theta.cos()) / theta ** 2)[:, None, None]
+    return torch.eye(3)[None] + f1 * K + f2 * (K @ K)
+
+
+def augment_points(point_clouds, log_rot, translation, scaling):
+    """transform_points(point_clouds (B,3,N), compose_transform(log_rot, translation, scaling)): x -> (x R) * s + t on rows"""
+    R = so3_exp_map(log_rot)
+    p = point_clouds.transpose(1, 2)                      # (B,N,3) row vectors
+    return ((p @ R) * scaling.expand(-1, 3)[:, None, :] + translation[:, None, :]).transpose(1, 2)
+
+
+def dataset_item(x, labels, sample, log_rot=None, translation=None, scaling=None, binary=False):
+    """PointDataset.__getitem__ (data.py:435-460) for one item with the random draws passed in: x (C,N), labels (N)"""
+    if log_rot is not None:
+        x = torch.cat([augment_points(x[None, :3], log_rot, translation, scaling)[0], x[3:]], dim=0)
+    lbl = labels[sample]
+    if binary:
+        lbl = (lbl != 0).long()
+    return x[:, sample], lbl

@@ -704,6 +704,94 @@ def test_predict_full_pointcloud_regression_batched(fsg, device):
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("Np,m,start", [(2000, 256, 0), (2000, 256, 1234), (777, 100, 776), (50, 50, 0), (30, 40, 0)])
+def test_farthest_point_sampling_drop_in(fsg, device, Np, m, start):
+    """utils.general_utils.farthest_point_sampling (one fsg_fps_f32 launch) against the reference's pure-torch loop
+    (dseg_ae_regularization.py:30-43, restated in oracle/ref_cpu.py) from the same start point: identical index lists"""
+    from fissure_segmentation_amd.utils.general_utils import farthest_point_sampling
+    from oracle import ref_cpu
+    pts = torch.from_numpy(cloud(Np + m, 1, 3, Np)).transpose(1, 2).contiguous()      # (1, Np, 3)
+    got_p, got_i = farthest_point_sampling(pts.to(device), m, start=start)
+    if Np <= m:
+        assert got_p.shape == (1, Np, 3) and torch.equal(got_i, torch.arange(Np))
+        return
+    want_p, want_i = ref_cpu.farthest_point_sampling(pts, m, start)
+    assert torch.equal(got_i.cpu(), want_i)
+    assert torch.equal(got_p.cpu(), want_p)
+
+
+def test_point_augmentation_against_oracle_and_scipy(fsg, device):
+    """augmentations.point_augmentation / transform_points (fsg_sample_transform_f32) against the CPU restatement
+    (oracle/ref_cpu.py) with the same random draws, and the rotation matrices against scipy's exponential map.
+    Row-vector convention, rotate -> scale -> translate; 1e-6 absolute (coordinates are O(1))."""
+    from scipy.spatial.transform import Rotation
+    from fissure_segmentation_amd import augmentations as A
+    from oracle import ref_cpu
+    pc = torch.from_numpy(cloud(21, 5, 3, 1000))
+    torch.manual_seed(9)
+    out, tf = A.point_augmentation(pc.to(device))
+    torch.manual_seed(9)
+    log_rot, tr, sc = A.random_transform_parameters(5, device)
+    want = ref_cpu.augment_points(pc, log_rot.cpu(), tr.cpu(), sc.cpu())
+    torch.testing.assert_close(out.cpu(), want, rtol=0, atol=1e-6)
+    R = A.so3_exp_map(log_rot).cpu().numpy()
+    np.testing.assert_allclose(R, Rotation.from_rotvec(log_rot.cpu().numpy()).as_matrix(), atol=1e-6)
+    ang = log_rot.norm(dim=1).cpu()
+    torch.testing.assert_close(ang, torch.full((5,), 0.1 * np.pi), rtol=1e-5, atol=0)          # |angle| = 0.1 pi
+    assert (tr.abs() <= 0.1).all() and (sc <= 1).all() and (sc >= 0.9).all()
+    # the 4x4 matrices compose and invert like the reference's Transform3d (data.py:553-582 relies on this)
+    back = tf.inverse().transform_points(out.transpose(1, 2)).transpose(1, 2)
+    torch.testing.assert_close(back.cpu(), pc, rtol=0, atol=2e-6)
+    ident = tf.compose(tf.inverse()).get_matrix().cpu()
+    torch.testing.assert_close(ident, torch.eye(4).expand(5, 4, 4), rtol=0, atol=1e-6)
+    centred = A.transform_points_with_centering(pc.to(device), tf).cpu()
+    c = pc.mean(2, keepdim=True)
+    torch.testing.assert_close(centred, ref_cpu.augment_points(pc - c, log_rot.cpu(), tr.cpu(), sc.cpu()) + c, rtol=0, atol=1e-6)
+    with pytest.raises(RuntimeError, match="GPU"):
+        A.point_augmentation(pc)                          # no CPU fallback
+
+
+@pytest.mark.parametrize("C,binary", [(3, False), (7, True)])
+def test_sample_and_augment_is_the_dataset_item(fsg, device, C, binary):
+    """augmentations.sample_and_augment == PointDataset.__getitem__ (data.py:435-460, restated in oracle/ref_cpu.py) item by
+    item, with the same draws: augmented coordinates, untouched feature rows, the same column subset for the labels"""
+    from fissure_segmentation_amd import augmentations as A
+    from oracle import ref_cpu
+    B, Nf, S = 4, 3000, 1024
+    x = torch.from_numpy(cloud(31, B, C, Nf))
+    lbl = torch.from_numpy(np.random.default_rng(3).integers(0, 4, (B, Nf)))
+    torch.manual_seed(12)
+    xs, ls, tf = A.sample_and_augment(x.to(device), lbl.to(device), S, augment=True, binary=binary)
+    torch.manual_seed(12)
+    log_rot, tr, sc = A.random_transform_parameters(B, device)
+    sample = A.random_subsets(B, Nf, S, device).cpu()
+    assert all(len(set(r.tolist())) == S for r in sample) and int(sample.min()) >= 0 and int(sample.max()) < Nf
+    assert xs.shape == (B, C, S) and ls.shape == (B, S) and len(tf) == B
+    for b in range(B):
+        wx, wl = ref_cpu.dataset_item(x[b], lbl[b], sample[b], log_rot[b:b + 1].cpu(), tr[b:b + 1].cpu(), sc[b:b + 1].cpu(),
+                                      binary=binary)
+        torch.testing.assert_close(xs[b].cpu(), wx, rtol=0, atol=1e-6)
+        assert torch.equal(xs[b, 3:].cpu(), wx[3:])       # feature rows are copied bit for bit
+        assert torch.equal(ls[b].cpu(), wl)
+    # no augmentation, no sub-sampling: a column permutation of the input
+    xs2, ls2, tf2 = A.sample_and_augment(x.to(device), None, None, augment=False)
+    assert tf2 is None and ls2 is None and xs2.shape == x.shape
+    assert torch.equal(xs2.sort(dim=2).values.cpu(), x.sort(dim=2).values)
+
+
+def test_sample_transform_error_paths(fsg, device):
+    import ctypes
+    x = torch.zeros(2, 2, 10, device=device)
+    out = torch.zeros(2, 2, 10, device=device)
+    aff = torch.zeros(2, 12, device=device)
+    Pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    with pytest.raises(RuntimeError, match="three coordinate rows"):
+        fsg._lib.call("fsg_sample_transform_f32", Pp(x), 2, 2, 10, None, 10, Pp(aff), Pp(out), None)
+    with pytest.raises(RuntimeError, match="S must equal N"):
+        fsg._lib.call("fsg_sample_transform_f32", Pp(x), 2, 2, 10, None, 5, None, Pp(out), None)
+    fsg._lib.call("fsg_sample_transform_f32", Pp(x), 0, 2, 10, None, 10, None, Pp(out), None)     # empty batch: no-op
+
+
 def test_ensemble_accumulate_kernel(fsg, device):
     """fsg_ensemble_accumulate_f32 against the loop it replaces, in numpy: run order per point, duplicates inside a run
     (highest slot wins), indices outside the cloud ignored, B = 2 clouds sharing the subsets, 5 classes"""
