@@ -232,7 +232,11 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
             const uintptr_t xba = reinterpret_cast<uintptr_t>(xb);   // uniform by construction: tell the compiler so
             const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xba);
             const unsigned xhi = __builtin_amdgcn_readfirstlane((unsigned)(xba >> 32));
-            const int nrec = __builtin_amdgcn_readfirstlane((int)((long)c_knn * sc * 4));
+            // the resource ends with column N-1 of the LAST channel row: a read past it returns 0, every read before it
+            // stays inside this cloud's own extent (with a channel stride > N, or the last cloud of a tensor, "the whole
+            // row of every channel" would reach beyond the allocation); columns >= N of the earlier rows read whatever
+            // lies between the rows -- those columns are overwritten with +inf below
+            const int nrec = __builtin_amdgcn_readfirstlane((int)((((long)c_knn - 1) * sc + N) * 4));
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 reinterpret_cast<void *>(((uintptr_t)xhi << 32) | xlo), 0, nrec, 0x00020000);
             const unsigned col0 = (unsigned)(c0 + wave * 16 + l15);   // this lane's candidate in the wave's first tile

@@ -150,27 +150,109 @@ class _LinearPM(torch.autograd.Function):
         g2 = g.reshape(-1, g.shape[-1])
         x2 = x.reshape(-1, x.shape[-1])
         gx = gw = gb = None
-        N, K = w.shape
-        M = g2.shape[0]
         if not g2.is_contiguous():
             g2 = g2.contiguous()
         if ctx.needs_input_grad[0]:
-            gx = (gemm_small(g2, N, 1, w, K, 1, None, M, K, N) if _small(M, K, N, g2, w) else g2 @ w).view_as(x)
+            gx = _linear_dx(g2, w).view_as(x)
         if ctx.needs_input_grad[1]:
-            S = 16 if (M % 16 == 0 and M >= 4096) else 1
-            if _small(N, K, M, g2, x2):
-                gw = gemm_small(g2, 1, N, x2, K, 1, None, N, K, M)
-            elif S > 1 and x2.is_contiguous():
-                gw = torch.bmm(g2.view(S, M // S, -1).transpose(1, 2), x2.view(S, M // S, -1)).sum(0)
-            else:
-                gw = g2.t() @ x2
+            gw = _linear_dw(g2, x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g2.sum(0)   # (a one-row product with ones is 3-15x slower: tools/probe_bias_grad.py)
+            gb = _bias_grad(g2)
         return gx, gw, gb
+
+
+def _linear_dx(g2, w, out=None):
+    """dX = dY W for dY (M,N), W (N,K); `out`: accumulate into an existing (M,K) gradient instead (one GEMM with beta = 1)"""
+    N, K = w.shape
+    M = g2.shape[0]
+    if out is not None:
+        return out.addmm_(g2, w)
+    return gemm_small(g2, N, 1, w, K, 1, None, M, K, N) if _small(M, K, N, g2, w) else g2 @ w
+
+
+def _linear_dw(g2, x2):
+    """dW = dY^T X: a tiny output behind a long reduction (see _LinearPM)"""
+    M, N = g2.shape
+    K = x2.shape[1]
+    S = 16 if (M % 16 == 0 and M >= 4096) else 1
+    if _small(N, K, M, g2, x2):
+        return gemm_small(g2, 1, N, x2, K, 1, None, N, K, M)
+    if S > 1 and x2.is_contiguous():
+        return torch.bmm(g2.view(S, M // S, -1).transpose(1, 2), x2.view(S, M // S, -1)).sum(0)
+    return g2.t() @ x2
+
+
+def _bias_grad(g2):
+    """column sums of dY (M,N).  Narrow outputs (the class logits: N = 4) go to fsg_colsum_narrow_f32 -- ATen's dim-0
+    reduction of a (16384, 4) tensor takes 17 us; otherwise `sum(0)` (a one-row product with ones is 3-15x slower:
+    tools/probe_bias_grad.py)"""
+    M, N = g2.shape
+    if g2.is_cuda and g2.dtype == torch.float32 and N <= 32 and (N & (N - 1)) == 0 and M * N >= 4096:
+        out = torch.empty(N, dtype=torch.float32, device=g2.device)
+        with torch.cuda.device(g2.device):
+            _lib.call("fsg_colsum_narrow_f32", _p(g2), M, N, _p(out), _stream())
+        return out
+    return g2.sum(0)
 
 
 def linear_pm(x, w, b=None):
     return _LinearPM.apply(x, w, b)
+
+
+class _LinearPM2(torch.autograd.Function):
+    """Two bias-free point-wise layers on the SAME input rows (DGCNNSeg: the global-feature conv 192 -> 1024 and the
+    `levels` half of the first head conv 192 -> 256, models/dgcnn.py:134-160): forward as two products, backward with the
+    second input gradient accumulated into the first by its GEMM (beta = 1) -- autograd would otherwise add the two
+    (M,K) gradients in a kernel of its own."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2):
+        ctx.save_for_backward(x, w1, w2)
+        x2 = x.reshape(-1, x.shape[-1])
+        return torch.nn.functional.linear(x2, w1), torch.nn.functional.linear(x2, w2)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        x, w1, w2 = ctx.saved_tensors
+        x2 = x.reshape(-1, x.shape[-1])
+        gs = [g.contiguous() if g is not None else None for g in (g1, g2)]
+        gx = None
+        if ctx.needs_input_grad[0]:
+            for g, w in zip(gs, (w1, w2)):
+                if g is not None:
+                    gx = _linear_dx(g, w) if gx is None else _linear_dx(g, w, out=gx)
+            gx = gx.view_as(x) if gx is not None else None
+        gw1 = _linear_dw(gs[0], x2) if (gs[0] is not None and ctx.needs_input_grad[1]) else None
+        gw2 = _linear_dw(gs[1], x2) if (gs[1] is not None and ctx.needs_input_grad[2]) else None
+        return gx, gw1, gw2
+
+
+def linear_pm2(x, w1, w2):
+    """(x W1^T, x W2^T) for x (M,K) contiguous fp32 rows; see _LinearPM2"""
+    return _LinearPM2.apply(x, w1, w2)
+
+
+class _SplitCols(torch.autograd.Function):
+    """W (R, C) -> (W[:, :c0], W[:, c0:]) as two contiguous matrices; the gradient is ONE concatenation.  Slicing a weight
+    twice costs autograd a zero-filled (R, C) tensor + a strided copy per slice and an add to merge them."""
+
+    @staticmethod
+    def forward(ctx, w, c0):
+        ctx.c0 = c0
+        return w[:, :c0].contiguous(), w[:, c0:].contiguous()
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None or gb is None:
+            R = (ga if ga is not None else gb).shape[0]
+            dev = (ga if ga is not None else gb).device
+            ga = ga if ga is not None else torch.zeros(R, ctx.c0, dtype=torch.float32, device=dev)
+            gb = gb if gb is not None else torch.zeros(R, 0, dtype=torch.float32, device=dev)
+        return torch.cat([ga, gb], dim=1), None
+
+
+def split_cols(w, c0):
+    return _SplitCols.apply(w, c0)
 
 
 _ones_memo = {}

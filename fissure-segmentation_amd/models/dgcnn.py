@@ -224,20 +224,27 @@ class DGCNNSeg(DGCNNBase):
         _, p3 = self.ec3(x2, self.knn_graph, x_pm=p2, both=True)
         levels = torch.cat([p1, p2, p3], dim=2).view(B * N, 192)
         gf = self.global_feature[0].layers                                                   # conv, BN, LeakyReLU
-        yg = F_hip.linear_pm(levels, gf[0].weight.view(gf[0].out_channels, -1))
+        # the two layers that read `levels` (global-feature conv and the `levels` half of the first head conv) share one
+        # autograd node, so that their input gradients are accumulated by the second GEMM instead of an extra add
+        seg0 = self.segmentation[0]
+        w0 = seg0.layers[0].weight.view(seg0.layers[0].out_channels, -1)
+        w0_levels, w0_global = F_hip.split_cols(w0, 192)
+        yg, y0 = F_hip.linear_pm2(levels, gf[0].weight.view(gf[0].out_channels, -1), w0_levels)
         if yg.shape[1] % 64 == 0:  # BN + LeakyReLU + max over the points in one stage, activation never written
             g = F_hip.bn_act_max(yg.view(B, N, -1), gf[1], gf[2].negative_slope)              # (B,1024)
         else:
             g = _norm_act(yg, list(gf)[1:]).view(B, N, -1).max(dim=1)[0]
         # first head layer on cat([levels, g.repeat(N)]) (models/dgcnn.py:159-160 of the reference): the global part
         # is constant per cloud, so its product is computed once per cloud instead of once per point
-        seg0 = self.segmentation[0]
-        w0 = seg0.layers[0].weight.view(seg0.layers[0].out_channels, -1)
-        y = F_hip.add_per_cloud(F_hip.linear_pm(levels, w0[:, :192]).view(B, N, -1), nn.functional.linear(g, w0[:, 192:]))
+        y = F_hip.add_per_cloud(y0.view(B, N, -1), nn.functional.linear(g, w0_global))
         y = _norm_act(y.view(B * N, -1), list(seg0.layers)[1:])
         for block in list(self.segmentation)[1:]:
             y = pointwise_block(y, block)
-        return y.view(B, N, self.num_classes).transpose(1, 2).contiguous()
+        out = y.view(B, N, self.num_classes).transpose(1, 2)
+        # training: hand the loss the (B,cls,N) VIEW of the point-major logits (the fused loss and every ATen loss take
+        # strided input; its gradient then arrives point-major, no transposing copies either way); inference keeps the
+        # reference's contiguous layout
+        return out if self.training and torch.is_grad_enabled() else out.contiguous()
 
 
 class DGCNNReg(DGCNNBase):

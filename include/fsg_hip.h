@@ -362,6 +362,13 @@ int fsg_ensemble_accumulate_f32(const float *logits, int R, int B, int cls, int 
 int fsg_sample_transform_f32(const float *x, int B, int C, int64_t N, const int64_t *sample, int S, const float *affine,
                              float *out, fsg_stream_t stream);
 
+/*
+ * Column sums of a narrow row-major matrix: out[c] = sum_m x[m*C + c], C a power of two <= 32 -- the bias gradient of the
+ * last point-wise layer (models/dgcnn.py:146, Conv1d(128, num_classes) with bias) over B*N rows.  One workgroup, fixed
+ * summation order.
+ */
+int fsg_colsum_narrow_f32(const float *x, int64_t M, int C, float *out, fsg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -704,6 +704,21 @@ def test_predict_full_pointcloud_regression_batched(fsg, device):
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
 
 
+def test_knn_on_interleaved_cloud_views(fsg, device):
+    """Clouds handed over as strided views (predict_full_pointcloud builds its batch as a permuted view: cloud stride 256,
+    channel stride 512 for N = 256): the operand loads must stay inside each cloud's own extent -- the view of the last
+    cloud ends exactly at the end of the storage -- and the result must match the contiguous copy."""
+    R, C, S, k = 2, 3, 256, 8
+    store = torch.from_numpy(cloud(41, 1, C, R * S)).to(device)                 # (1, 3, 512)
+    view = store.view(1, C, R, S).permute(2, 0, 1, 3).reshape(R, C, S)          # strides (256, 512, 1): no copy
+    assert view.stride() == (S, R * S, 1) and view.data_ptr() == store.data_ptr()
+    got = fsg.functional.knn_graph(view, k, c_knn=3, fix_diag=True)
+    want = fsg.functional.knn_graph(view.contiguous(), k, c_knn=3, fix_diag=True)
+    assert torch.equal(got, want)
+    idx_o, _ = c_api.knn_dense(N(view.contiguous()), k, fix_diag=True)
+    assert np.array_equal(N(got), idx_o)
+
+
 @pytest.mark.parametrize("Np,m,start", [(2000, 256, 0), (2000, 256, 1234), (777, 100, 776), (50, 50, 0), (30, 40, 0)])
 def test_farthest_point_sampling_drop_in(fsg, device, Np, m, start):
     """utils.general_utils.farthest_point_sampling (one fsg_fps_f32 launch) against the reference's pure-torch loop
