@@ -29,12 +29,12 @@ SIGNATURES = {
     "fsg_edgeconv1_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),
     "fsg_edgeconv1_fwd_f32": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
                               _I),
-    "fsg_edgeconv1_bwd_f32": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P,
-                               _P], _I),
+    "fsg_edgeconv1_bwd_f32": ([_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P,
+                               _P, _P, _P, _P], _I),
     "fsg_edgeconv2_workspace_bytes": ([_I, _I, _I, _I], ctypes.c_size_t),
     "fsg_edgeconv2_bwd_workspace_bytes": ([_I, _I, _I, _I], ctypes.c_size_t),
     "fsg_edgeconv2_fwd_f32": ([_P] * 11 + [_I] * 5 + [_F] * 5 + [_P] * 12, _I),
-    "fsg_edgeconv2_bwd_f32": ([_P] * 18 + [_I] * 5 + [_F] + [_P] * 8, _I),
+    "fsg_edgeconv2_bwd_f32": ([_P, _P, _L, _P, _L] + [_P] * 16 + [_I] * 5 + [_F] + [_P] * 8, _I),
     "fsg_bn_act_workspace_bytes": ([ctypes.c_long, _I], ctypes.c_size_t),
     "fsg_bn_act_fwd_f32": ([_P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P], _I),
     "fsg_bn_act_bwd_f32": ([_P, _P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _F, _P, _P, _P, _P, _P], _I),

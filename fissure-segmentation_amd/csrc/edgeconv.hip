@@ -412,7 +412,10 @@ __global__ __launch_bounds__(256) void ec1_apply_kernel(const float *__restrict_
 
 // ------------------------------------------------------------------ backward
 // h = grad_out * f'(u) on the selected edge (point-major), per-workgroup partial sums of h and h*yhat
+// (the point-major gradient may arrive as up to two tensors with their own row strides -- e.g. one from the next layer and
+// one slice of the gradient of the concatenated features: they are summed here instead of by an ATen add + a copy)
 __global__ __launch_bounds__(256) void ec1_bwd_point_kernel(const float *__restrict__ gout, const float *__restrict__ gout_pm,
+                                                             long ld_pm, const float *__restrict__ gout_pm2, long ld_pm2,
                                                              const float *__restrict__ ysel,
                                                              const float *__restrict__ gamma,
                                                              const float *__restrict__ beta,
@@ -437,7 +440,10 @@ __global__ __launch_bounds__(256) void ec1_bwd_point_kernel(const float *__restr
         const long o = ((long)b * N + i) * Co + c;
         const float yhat = (ysel[o] - mu) * r;
         const float u = __builtin_fmaf(ga, yhat, be);
-        const float gv = tile[lane][p] + (gout_pm ? gout_pm[o] : 0.f);
+        const long row = (long)b * N + i;
+        float gv = tile[lane][p];
+        if (gout_pm) gv += gout_pm[row * ld_pm + c];
+        if (gout_pm2) gv += gout_pm2[row * ld_pm2 + c];
         const float hv = gv * (u > 0.f ? 1.f : slope);
         h[o] = hv;
         sb += hv;
@@ -554,11 +560,13 @@ int fsg_ec_apply_launch(const float *ysel, const float *gamma, const float *beta
     return FSG_OK;
 }
 
-int fsg_ec_bwd_point_launch(const float *gout, const float *gout_pm, const float *ysel, const float *gamma,
+int fsg_ec_bwd_point_launch(const float *gout, const float *gout_pm, long ld_pm, const float *gout_pm2, long ld_pm2,
+                            const float *ysel, const float *gamma,
                             const float *beta, const float *mean, const float *invstd, int B, int N, int Co, float slope,
                             float *h, float *partials, float *dbeta, float *dgamma, hipStream_t st) {
     const int tiles64 = fsg_cdiv(N, 64);
-    hipLaunchKernelGGL(ec1_bwd_point_kernel, dim3(B, tiles64, Co / 64), dim3(256), 0, st, gout, gout_pm, ysel, gamma,
+    hipLaunchKernelGGL(ec1_bwd_point_kernel, dim3(B, tiles64, Co / 64), dim3(256), 0, st, gout, gout_pm, ld_pm, gout_pm2,
+                       ld_pm2, ysel, gamma,
                        beta, mean, invstd, N, Co, slope, h, partials);
     FSG_CHECK_LAUNCH("edgeconv/bwd_point");
     hipLaunchKernelGGL(sum_partials_kernel, dim3(Co / 64, 2), dim3(256), 0, st, partials, B * tiles64, Co, 2, dbeta,
@@ -687,21 +695,24 @@ extern "C" int fsg_edgeconv1_fwd_f32(const float *pq, const int32_t *idx, const 
     return FSG_OK;
 }
 
-extern "C" int fsg_edgeconv1_bwd_f32(const float *grad_out, const float *grad_out_pm, const float *pq, const int32_t *rowptr, const int32_t *col,
+extern "C" int fsg_edgeconv1_bwd_f32(const float *grad_out, const float *grad_out_pm, int64_t ld_pm, const float *grad_out_pm2,
+                                     int64_t ld_pm2, const float *pq, const int32_t *rowptr, const int32_t *col,
                                      const float *gamma, const float *beta, const float *mean, const float *invstd,
                                      const float *ysel, const uint8_t *arg, const float *ssum, int B, int N, int k,
                                      int Co, int training, float slope, float *grad_pq, float *grad_gamma,
                                      float *grad_beta, float *h_scratch, float *workspace, fsg_stream_t stream) {
-    FSG_REQUIRE((grad_out || grad_out_pm) && pq && rowptr && col && gamma && beta && mean && invstd && ysel && arg && grad_pq &&
-                    grad_gamma && grad_beta && h_scratch && workspace,
+    FSG_REQUIRE((grad_out || grad_out_pm || grad_out_pm2) && pq && rowptr && col && gamma && beta && mean && invstd && ysel &&
+                    arg && grad_pq && grad_gamma && grad_beta && h_scratch && workspace,
                 "fsg_edgeconv1_bwd_f32: NULL pointer");
+    FSG_REQUIRE((!grad_out_pm || ld_pm >= Co) && (!grad_out_pm2 || ld_pm2 >= Co),
+                "fsg_edgeconv1_bwd_f32: row stride of a point-major gradient below Co=%d", Co);
     FSG_REQUIRE(!training || ssum, "fsg_edgeconv1_bwd_f32: training needs ssum");
     FSG_REQUIRE(B > 0 && N > 0 && k > 0 && k <= 64 && Co > 0 && Co % 64 == 0 && B <= 65535,
                 "fsg_edgeconv1_bwd_f32: bad shape B=%d N=%d k=%d Co=%d", B, N, k, Co);
     hipStream_t st = (hipStream_t)stream;
     const int tiles64 = fsg_cdiv(N, 64);
-    hipLaunchKernelGGL(ec1_bwd_point_kernel, dim3(B, tiles64, Co / 64), dim3(256), 0, st, grad_out, grad_out_pm, ysel, gamma, beta,
-                       mean, invstd, N, Co, slope, h_scratch, workspace);
+    hipLaunchKernelGGL(ec1_bwd_point_kernel, dim3(B, tiles64, Co / 64), dim3(256), 0, st, grad_out, grad_out_pm, (long)ld_pm,
+                       grad_out_pm2, (long)ld_pm2, ysel, gamma, beta, mean, invstd, N, Co, slope, h_scratch, workspace);
     FSG_CHECK_LAUNCH("fsg_edgeconv1_bwd_f32/point");
     hipLaunchKernelGGL(sum_partials_kernel, dim3(Co / 64, 2), dim3(256), 0, st, workspace, B * tiles64, Co, 2, grad_beta,
                        grad_gamma);

@@ -567,7 +567,8 @@ extern "C" int fsg_edgeconv2_fwd_f32(const float *pq, const int32_t *idx, const 
     return fsg_ec_apply_launch(ysel2, gamma2, beta2, mean2, invstd2, B, N, C2, slope, out, out_pm, st);
 }
 
-int fsg_ec_bwd_point_launch(const float *gout, const float *gout_pm, const float *ysel, const float *gamma,
+int fsg_ec_bwd_point_launch(const float *gout, const float *gout_pm, long ld_pm, const float *gout_pm2, long ld_pm2,
+                            const float *ysel, const float *gamma,
                             const float *beta, const float *mean, const float *invstd, int B, int N, int Co, float slope,
                             float *h, float *partials, float *dbeta, float *dgamma, hipStream_t st);
 int fsg_ec_sum_launch(const float *partials, int R, int L, int nvec, float *out0, float *out1, hipStream_t st);
@@ -599,14 +600,17 @@ extern "C" size_t fsg_edgeconv2_bwd_workspace_bytes(int B, int N, int k, int C2)
     return sizeof(float) * (point_rec + dw + p1 + du + (size_t)B * N * C2) + 256;
 }
 
-extern "C" int fsg_edgeconv2_bwd_f32(const float *grad_out, const float *grad_out_pm, const float *pq, const int32_t *idx,
+extern "C" int fsg_edgeconv2_bwd_f32(const float *grad_out, const float *grad_out_pm, int64_t ld_pm, const float *grad_out_pm2,
+                                     int64_t ld_pm2, const float *pq, const int32_t *idx,
                                      const int32_t *rowptr, const int32_t *col, const float *w2, const float *gamma1,
                                      const float *beta1, const float *mean1, const float *invstd1, const float *ssum1,
                                      const float *gamma2, const float *beta2, const float *mean2, const float *invstd2,
                                      const float *ysel2, const uint8_t *arg2, int B, int N, int k, int C2, int training,
                                      float slope, float *grad_pq, float *grad_w2, float *grad_gamma1, float *grad_beta1,
                                      float *grad_gamma2, float *grad_beta2, void *workspace, fsg_stream_t stream) {
-    FSG_REQUIRE((grad_out || grad_out_pm) && pq && idx && rowptr && col && w2 && gamma1 && beta1 && mean1 && invstd1 &&
+    FSG_REQUIRE((!grad_out_pm || ld_pm >= C2) && (!grad_out_pm2 || ld_pm2 >= C2),
+                "fsg_edgeconv2_bwd_f32: row stride of a point-major gradient below C2=%d", C2);
+    FSG_REQUIRE((grad_out || grad_out_pm || grad_out_pm2) && pq && idx && rowptr && col && w2 && gamma1 && beta1 && mean1 && invstd1 &&
                     gamma2 && beta2 && mean2 && invstd2 && ysel2 && arg2 && grad_pq && grad_w2 && grad_gamma1 &&
                     grad_beta1 && grad_gamma2 && grad_beta2 && workspace,
                 "fsg_edgeconv2_bwd_f32: NULL pointer");
@@ -623,7 +627,8 @@ extern "C" int fsg_edgeconv2_bwd_f32(const float *grad_out, const float *grad_ou
     float *h2 = du1 + (size_t)B * N * k * C1;
     int rc;
     // h2 = grad_out f'(u2) on the selected edge, dbeta2 / dgamma2
-    if ((rc = fsg_ec_bwd_point_launch(grad_out, grad_out_pm, ysel2, gamma2, beta2, mean2, invstd2, B, N, C2, slope, h2,
+    if ((rc = fsg_ec_bwd_point_launch(grad_out, grad_out_pm, (long)ld_pm, grad_out_pm2, (long)ld_pm2, ysel2, gamma2, beta2,
+                                      mean2, invstd2, B, N, C2, slope, h2,
                                       point_part, grad_beta2, grad_gamma2, st)) != FSG_OK)
         return rc;
     const float invM = 1.0f / ((float)B * (float)N * (float)k);

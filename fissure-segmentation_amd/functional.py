@@ -233,13 +233,14 @@ def linear_pm2(x, w1, w2):
 
 
 class _SplitCols(torch.autograd.Function):
-    """W (R, C) -> (W[:, :c0], W[:, c0:]) as two contiguous matrices; the gradient is ONE concatenation.  Slicing a weight
-    twice costs autograd a zero-filled (R, C) tensor + a strided copy per slice and an add to merge them."""
+    """W (R, C) -> the two column blocks (W[:, :c0], W[:, c0:]) as views (the GEMMs take the row stride); the gradient is
+    ONE concatenation.  Slicing a weight twice costs autograd a zero-filled (R, C) tensor + a strided copy per slice and
+    an add to merge them."""
 
     @staticmethod
     def forward(ctx, w, c0):
         ctx.c0 = c0
-        return w[:, :c0].contiguous(), w[:, c0:].contiguous()
+        return w[:, :c0], w[:, c0:]
 
     @staticmethod
     def backward(ctx, ga, gb):
@@ -416,6 +417,17 @@ def reverse_graph(idx):
     return cached
 
 
+def _pm_grad(g, B, N, C):
+    """point-major output gradient (B,N,C) -> (tensor, row stride) for the kernels: rows of C contiguous floats with ANY
+    row stride pass as they are (e.g. a slice of the gradient of concatenated features), everything else is copied"""
+    if g is None:
+        return None, 0
+    if g.dtype == torch.float32 and g.shape == (B, N, C) and g.stride(2) == 1 and g.stride(1) >= C and \
+            (B == 1 or g.stride(0) == N * g.stride(1)):
+        return g, g.stride(1)
+    return _f32c(g), C
+
+
 class _EdgeConv1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pq, idx, gamma, beta, running_mean, running_var, training, momentum, eps, slope):
@@ -444,15 +456,18 @@ class _EdgeConv1(torch.autograd.Function):
         ctx.save_for_backward(pq, idx, gamma, beta, mean, invstd, ysel, arg, ssum)
         ctx.meta = (B, N, k, Co, bool(training), slope)
         ctx.set_materialize_grads(False)   # the layout that only feeds the next graph build gets None, not a zero tensor
-        return out, out_pm
+        # the point-major output twice (second one an alias): two consumers -- the next layer and the concatenated
+        # features -- then deliver their gradients separately and the backward kernel sums them (no ATen add, no copy)
+        return out, out_pm, out_pm.view(B, N, Co)
 
     @staticmethod
-    def backward(ctx, g, g_pm):
+    def backward(ctx, g, g_pm, g_pm2):
         pq, idx, gamma, beta, mean, invstd, ysel, arg, ssum = ctx.saved_tensors
         B, N, k, Co, training, slope = ctx.meta
         dev = pq.device
         g = _f32c(g) if g is not None else None
-        g_pm = _f32c(g_pm) if g_pm is not None else None
+        g_pm, ld1 = _pm_grad(g_pm, B, N, Co)
+        g_pm2, ld2 = _pm_grad(g_pm2, B, N, Co)
         rowptr, col = reverse_graph(idx)
         gpq = torch.empty_like(pq)
         dgamma = torch.empty(Co, dtype=torch.float32, device=dev)
@@ -460,7 +475,8 @@ class _EdgeConv1(torch.autograd.Function):
         h = torch.empty(B, N, Co, dtype=torch.float32, device=dev)
         ws = torch.empty(B * ((N + 63) // 64) * 2 * Co, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.call("fsg_edgeconv1_bwd_f32", _p(g), _p(g_pm), _p(pq), _p(rowptr), _p(col), _p(gamma), _p(beta), _p(mean),
+            _lib.call("fsg_edgeconv1_bwd_f32", _p(g), _p(g_pm), ld1, _p(g_pm2), ld2, _p(pq), _p(rowptr), _p(col), _p(gamma),
+                      _p(beta), _p(mean),
                       _p(invstd), _p(ysel), _p(arg), _p(ssum), B, N, k, Co, int(training), slope, _p(gpq), _p(dgamma),
                       _p(dbeta), _p(h), _p(ws), _stream())
         return gpq, None, dgamma, dbeta, None, None, None, None, None, None
@@ -491,10 +507,12 @@ def edgeconv1(x, idx, conv_weight, bn, slope, x_pm=None, both=False):
     idx = idx.contiguous()
     if torch.is_grad_enabled() and pq.requires_grad and _ASYNC_CSR:
         prefetch_reverse_graph(idx)
-    out, out_pm = _EdgeConv1.apply(pq, idx, bn.weight, bn.bias,
-                                   bn.running_mean if (track or not training) else None,
-                                   bn.running_var if (track or not training) else None, training, float(momentum),
-                                   float(bn.eps), float(slope))
+    out, out_pm, out_pm2 = _EdgeConv1.apply(pq, idx, bn.weight, bn.bias,
+                                            bn.running_mean if (track or not training) else None,
+                                            bn.running_var if (track or not training) else None, training, float(momentum),
+                                            float(bn.eps), float(slope))
+    if both == "twice":      # (B,Co,N), (B,N,Co) and an alias of the latter for a second consumer (see _EdgeConv1)
+        return out, out_pm, out_pm2
     return (out, out_pm) if both else out
 
 
@@ -527,22 +545,24 @@ class _EdgeConv2(torch.autograd.Function):
         ctx.save_for_backward(pq, idx, w2, g1, b1, mean1, invstd1, ssum1, g2, b2, mean2, invstd2, ysel2, arg2)
         ctx.meta = (B, N, k, C2, t, slope)
         ctx.set_materialize_grads(False)
-        return out, out_pm
+        return out, out_pm, out_pm.view(B, N, C2)    # alias for a second consumer, see _EdgeConv1
 
     @staticmethod
-    def backward(ctx, g, g_pm):
+    def backward(ctx, g, g_pm, g_pm2):
         pq, idx, w2, g1, b1, mean1, invstd1, ssum1, g2, b2, mean2, invstd2, ysel2, arg2 = ctx.saved_tensors
         B, N, k, C2, training, slope = ctx.meta
         dev = pq.device
         g = _f32c(g) if g is not None else None
-        g_pm = _f32c(g_pm) if g_pm is not None else None
+        g_pm, ld1 = _pm_grad(g_pm, B, N, C2)
+        g_pm2, ld2 = _pm_grad(g_pm2, B, N, C2)
         rowptr, col = reverse_graph(idx)
         gpq, gw2 = torch.empty_like(pq), torch.empty_like(w2)
         dg1, db1 = torch.empty_like(g1), torch.empty_like(b1)
         dg2, db2 = torch.empty_like(g2), torch.empty_like(b2)
         ws = torch.empty(_lib.lib.fsg_edgeconv2_bwd_workspace_bytes(B, N, k, C2), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            _lib.call("fsg_edgeconv2_bwd_f32", _p(g), _p(g_pm), _p(pq), _p(idx), _p(rowptr), _p(col), _p(w2), _p(g1),
+            _lib.call("fsg_edgeconv2_bwd_f32", _p(g), _p(g_pm), ld1, _p(g_pm2), ld2, _p(pq), _p(idx), _p(rowptr), _p(col),
+                      _p(w2), _p(g1),
                       _p(b1), _p(mean1), _p(invstd1), _p(ssum1), _p(g2), _p(b2), _p(mean2), _p(invstd2), _p(ysel2),
                       _p(arg2), B, N, k, C2, int(training), slope, _p(gpq), _p(gw2), _p(dg1), _p(db1), _p(dg2), _p(db2),
                       _p(ws), _stream())
@@ -581,9 +601,11 @@ def edgeconv2(x, idx, conv1_weight, bn1, conv2_weight, bn2, slope, x_pm=None, bo
     idx = idx.contiguous()
     if torch.is_grad_enabled() and pq.requires_grad and _ASYNC_CSR:
         prefetch_reverse_graph(idx)
-    out, out_pm = _EdgeConv2.apply(pq, idx, w2, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
-                                   bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, t1, m1, m2, float(bn1.eps),
-                                   float(bn2.eps), float(slope))
+    out, out_pm, out_pm2 = _EdgeConv2.apply(pq, idx, w2, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
+                                            bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, t1, m1, m2,
+                                            float(bn1.eps), float(bn2.eps), float(slope))
+    if both == "twice":
+        return out, out_pm, out_pm2
     return (out, out_pm) if both else out
 
 

@@ -76,7 +76,8 @@ class EdgeConv(nn.Module):
 
     def forward(self, x, fixed_knn_graph=None, x_pm=None, both=False):
         """x (B,C,N) -> (B,Cout,N) like the reference; `both=True` additionally returns the point-major copy
-        (B,N,Cout) that the point-wise head consumes, `x_pm` is an optional point-major copy of the input."""
+        (B,N,Cout) that the point-wise head consumes (`both="twice"`: that copy twice, for two consumers), `x_pm` is an
+        optional point-major copy of the input."""
         if len(self.shared_mlp) == 1 and len(self.shared_mlp[0].layers) == 3 and \
                 F_hip.edgeconv1_supported(self.shared_mlp[0].layers[0].out_channels, self.k):
             # fused path: no (B,2C,N,k) / (B,Cout,N,k) tensor is ever written (csrc/edgeconv.hip)
@@ -98,7 +99,10 @@ class EdgeConv(nn.Module):
         for layer in self.shared_mlp:
             e = layer(e)
         out = e.max(dim=-1)[0]
-        return (out, out.transpose(1, 2).contiguous()) if both else out
+        if not both:
+            return out
+        pm = out.transpose(1, 2).contiguous()
+        return (out, pm, pm) if both == "twice" else (out, pm)
 
 
 def pointwise_block(x_pm, block):
@@ -219,10 +223,12 @@ class DGCNNSeg(DGCNNBase):
         B, _, N = x.shape
         # EdgeConvs hand over both layouts: channel-major (B,C,N) feeds the next graph build, point-major (B,N,C)
         # feeds the GEMMs; the head runs point-major, so every 1x1 conv is ONE GEMM over the B*N points
-        x1, p1 = self.ec1(x, self.knn_graph, both=True)
-        x2, p2 = self.ec2(x1, self.knn_graph, x_pm=p1, both=True)
+        # p1 / p2 have two consumers (the next EdgeConv and the concatenation): "twice" hands out an alias for the second,
+        # so that their gradients reach the EdgeConv backward kernel separately (summed there, slices taken by stride)
+        x1, p1, p1c = self.ec1(x, self.knn_graph, both="twice")
+        x2, p2, p2c = self.ec2(x1, self.knn_graph, x_pm=p1, both="twice")
         _, p3 = self.ec3(x2, self.knn_graph, x_pm=p2, both=True)
-        levels = torch.cat([p1, p2, p3], dim=2).view(B * N, 192)
+        levels = torch.cat([p1c, p2c, p3], dim=2).view(B * N, 192)
         gf = self.global_feature[0].layers                                                   # conv, BN, LeakyReLU
         # the two layers that read `levels` (global-feature conv and the `levels` half of the first head conv) share one
         # autograd node, so that their input gradients are accumulated by the second GEMM instead of an extra add

@@ -97,7 +97,8 @@ int fsg_edge_weights_bwd_f32(const float *grad_Wt, int Co, int C, float *grad_W,
  *   selected slot, ssum (B,N,Co) = sum_s y (training only), mean/invstd (Co) (outputs when training, inputs
  *   -- running statistics -- otherwise).  running_mean/var (nullable) are updated in place when training.
  *   workspace: fsg_edgeconv1_workspace_bytes() floats-as-bytes (training only).
- * Backward: grad_out (B,Co,N) and/or grad_out_pm (B,N,Co) (either may be NULL; both are summed) -> grad_pq (B,N,2*Co), grad_gamma, grad_beta (Co); h_scratch (B,N,Co) and
+ * Backward: grad_out (B,Co,N) and/or up to two point-major gradients grad_out_pm / grad_out_pm2 (B,N,Co) with row strides
+ *   ld_pm / ld_pm2 >= Co in elements (any of the three may be NULL; they are summed) -> grad_pq (B,N,2*Co), grad_gamma, grad_beta (Co); h_scratch (B,N,Co) and
  *   workspace (2*Co*B*ceil(N/64) floats) are caller-provided scratch.
  */
 size_t fsg_edgeconv1_workspace_bytes(int B, int N, int Co);
@@ -106,7 +107,8 @@ int fsg_edgeconv1_fwd_f32(const float *pq, const int32_t *idx, const float *gamm
                           float momentum, float eps, float slope, float *out, float *out_pm, float *ysel,
                           uint8_t *arg, float *ssum, float *mean, float *invstd, float *workspace,
                           fsg_stream_t stream);
-int fsg_edgeconv1_bwd_f32(const float *grad_out, const float *grad_out_pm, const float *pq, const int32_t *rowptr, const int32_t *col,
+int fsg_edgeconv1_bwd_f32(const float *grad_out, const float *grad_out_pm, int64_t ld_pm, const float *grad_out_pm2,
+                          int64_t ld_pm2, const float *pq, const int32_t *rowptr, const int32_t *col,
                           const float *gamma, const float *beta, const float *mean, const float *invstd,
                           const float *ysel, const uint8_t *arg, const float *ssum, int B, int N, int k, int Co,
                           int training, float slope, float *grad_pq, float *grad_gamma, float *grad_beta,
@@ -117,7 +119,8 @@ int fsg_edgeconv1_bwd_f32(const float *grad_out, const float *grad_out_pm, const
  * len(shared_mlp) == 2 (ec1 of DGCNNSeg, the EdgeConv of the SpatialTransformer).  Layer 1 arrives decomposed as
  * pq (B,N,128) = [P | Q] like fsg_edgeconv1; w2 (C2,64) is the second 1x1 conv; *1 / *2 are the two BatchNorms.
  * Forward saves ssum1 (B,N,64), mean1/invstd1, ysel2/arg2/ssum2 (B,N,C2), mean2/invstd2 for the backward
- * (mean/invstd are INPUTS -- running statistics -- when training == 0).  Backward returns grad_pq (B,N,128),
+ * (mean/invstd are INPUTS -- running statistics -- when training == 0).  Backward (output gradients as for
+ * fsg_edgeconv1_bwd_f32) returns grad_pq (B,N,128),
  * grad_w2 (C2,64) and the four BatchNorm parameter gradients.  Workspaces: fsg_edgeconv2_workspace_bytes /
  * fsg_edgeconv2_bwd_workspace_bytes (the backward one holds the only per-edge tensor, du1 (B*N*k, 64)).
  */
@@ -130,7 +133,8 @@ int fsg_edgeconv2_fwd_f32(const float *pq, const int32_t *idx, const float *w2, 
                           float *out, float *out_pm, float *ssum1, float *mean1, float *invstd1, float *ysel2,
                           uint8_t *arg2, float *ssum2, float *mean2, float *invstd2, void *workspace,
                           fsg_stream_t stream);
-int fsg_edgeconv2_bwd_f32(const float *grad_out, const float *grad_out_pm, const float *pq, const int32_t *idx,
+int fsg_edgeconv2_bwd_f32(const float *grad_out, const float *grad_out_pm, int64_t ld_pm, const float *grad_out_pm2,
+                          int64_t ld_pm2, const float *pq, const int32_t *idx,
                           const int32_t *rowptr, const int32_t *col, const float *w2, const float *gamma1,
                           const float *beta1, const float *mean1, const float *invstd1, const float *ssum1,
                           const float *gamma2, const float *beta2, const float *mean2, const float *invstd2,
