@@ -26,6 +26,7 @@ SIGNATURES = {
     "fsg_graph_reverse_csr": ([_P, _I, _I, _I, _P, _P, _P, _P], _I),
     "fsg_edge_weights_fwd_f32": ([_P, _I, _I, _P, _P], _I),
     "fsg_edge_weights_bwd_f32": ([_P, _I, _I, _P, _P], _I),
+    "fsg_edge_weights_many_f32": ([_P, _I, _P], _I),
     "fsg_edgeconv1_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),
     "fsg_edgeconv1_fwd_f32": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
                               _I),
@@ -95,6 +96,11 @@ class PTLayerParams(ctypes.Structure):
     _fields_ = [(n, _P) for n in ("lp1_w", "lp1_b", "bnp_g", "bnp_b", "bnp_rm", "bnp_rv", "lp2_w", "lp2_b", "bn1_g", "bn1_b",
                                   "bn1_rm", "bn1_rv", "lw1_w", "lw1_b", "bn2_g", "bn2_b", "bn2_rm", "bn2_rv", "lw2_w",
                                   "lw2_b")] + [(n, _F) for n in ("eps_p", "eps_1", "eps_2", "mom_p", "mom_1", "mom_2")]
+
+
+class EdgeWeightJobs(ctypes.Structure):
+    """include/fsg_hip.h: fsg_edge_weight_jobs"""
+    _fields_ = [("src", _P * 8), ("dst", _P * 8), ("Co", _I * 8), ("C", _I * 8), ("n", _I)]
 
 
 class PTLayerGrads(ctypes.Structure):

@@ -651,6 +651,39 @@ __global__ __launch_bounds__(256) void edge_weights_bwd_kernel(const float *__re
     gW[t] = c2 < C ? g[(long)r * C + c2] - g[(long)(Co + r) * C + c2] : g[(long)(Co + r) * C + (c2 - C)];
 }
 
+// all EdgeConv layers of a model at once (blockIdx.y = layer): the transforms depend on the weights only, so one launch at
+// the head of the forward (and one at the tail of the backward) replaces one per layer
+__global__ __launch_bounds__(256) void edge_weights_many_kernel(fsg_edge_weight_jobs jobs, int backward) {
+    const int j = blockIdx.y;
+    const int Co = jobs.Co[j], C = jobs.C[j];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= 2 * Co * C) return;
+    const float *src = jobs.src[j];
+    float *dst = jobs.dst[j];
+    if (!backward) {
+        const int r = t / C, c = t - r * C;
+        dst[t] = r < Co ? src[(long)r * 2 * C + c] : src[(long)(r - Co) * 2 * C + C + c] - src[(long)(r - Co) * 2 * C + c];
+    } else {
+        const int r = t / (2 * C), c2 = t - r * 2 * C;
+        dst[t] = c2 < C ? src[(long)r * C + c2] - src[(long)(Co + r) * C + c2] : src[(long)(Co + r) * C + (c2 - C)];
+    }
+}
+
+extern "C" int fsg_edge_weights_many_f32(const fsg_edge_weight_jobs *jobs, int backward, fsg_stream_t stream) {
+    FSG_REQUIRE(jobs && jobs->n >= 1 && jobs->n <= FSG_EDGE_WEIGHT_MAX_JOBS, "fsg_edge_weights_many_f32: 1..%d jobs",
+                FSG_EDGE_WEIGHT_MAX_JOBS);
+    long most = 0;
+    for (int j = 0; j < jobs->n; ++j) {
+        FSG_REQUIRE(jobs->src[j] && jobs->dst[j] && jobs->Co[j] > 0 && jobs->C[j] > 0, "fsg_edge_weights_many_f32: bad job %d", j);
+        const long e = 2L * jobs->Co[j] * jobs->C[j];
+        most = e > most ? e : most;
+    }
+    hipLaunchKernelGGL(edge_weights_many_kernel, dim3(fsg_cdiv(most, 256), jobs->n), dim3(256), 0, (hipStream_t)stream, *jobs,
+                       backward);
+    FSG_CHECK_LAUNCH("fsg_edge_weights_many_f32");
+    return FSG_OK;
+}
+
 extern "C" int fsg_edge_weights_fwd_f32(const float *W, int Co, int C, float *Wt, fsg_stream_t stream) {
     FSG_REQUIRE(W && Wt && Co > 0 && C > 0, "fsg_edge_weights_fwd_f32: bad arguments");
     hipLaunchKernelGGL(edge_weights_fwd_kernel, dim3(fsg_cdiv(2L * Co * C, 256)), dim3(256), 0, (hipStream_t)stream, W, Co, C, Wt);

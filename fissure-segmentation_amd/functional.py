@@ -313,6 +313,48 @@ class _EdgeWeights(torch.autograd.Function):
         return out
 
 
+class _EdgeWeightsMany(torch.autograd.Function):
+    """`_EdgeWeights` for all EdgeConv layers of a model in one launch each way: the transforms depend on the weights
+    only, so they can run together at the head of the forward -- and, because autograd runs a node once all its output
+    gradients are in, together at the tail of the backward."""
+
+    @staticmethod
+    def _run(srcs, shapes, backward):
+        dev = srcs[0].device
+        jobs = _lib.EdgeWeightJobs()
+        jobs.n = len(srcs)
+        outs = []
+        for j, (t, (Co, C)) in enumerate(zip(srcs, shapes)):
+            out = torch.empty((Co, 2 * C) if backward else (2 * Co, C), dtype=torch.float32, device=dev)
+            jobs.src[j], jobs.dst[j], jobs.Co[j], jobs.C[j] = t.data_ptr(), out.data_ptr(), Co, C
+            outs.append(out)
+        with torch.cuda.device(dev):
+            _lib.call("fsg_edge_weights_many_f32", ctypes.byref(jobs), int(backward), _stream())
+        return outs
+
+    @staticmethod
+    def forward(ctx, *Ws):
+        Wc = [W if (W.dtype == torch.float32 and W.is_contiguous()) else W.float().contiguous() for W in Ws]
+        ctx.shapes = [(W.shape[0], W.shape[1] // 2) for W in Wc]
+        return tuple(_EdgeWeightsMany._run(Wc, ctx.shapes, False))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        dev = next(g for g in gs if g is not None).device
+        gc = [torch.zeros(2 * Co, C, dtype=torch.float32, device=dev) if g is None else
+              (g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous())
+              for g, (Co, C) in zip(gs, ctx.shapes)]
+        return tuple(_EdgeWeightsMany._run(gc, ctx.shapes, True))
+
+
+def edge_weights_many(conv_weights):
+    """[(Co,2C,1,1) or (Co,2C) first-layer EdgeConv weights] -> [(2Co,C) P/Q weights], one launch (up to 8 layers)"""
+    Ws = [w.reshape(w.shape[0], w.shape[1]) for w in conv_weights]
+    if not 1 <= len(Ws) <= 8:
+        raise ValueError("edge_weights_many: 1..8 layers")
+    return list(_EdgeWeightsMany.apply(*Ws))
+
+
 # ------------------------------------------------------------------ BatchNorm call counters
 _deferred_counters = None
 
@@ -486,14 +528,15 @@ def edgeconv1_supported(out_channels, k):
     return out_channels % 64 == 0 and k <= 64
 
 
-def edgeconv1(x, idx, conv_weight, bn, slope, x_pm=None, both=False):
+def edgeconv1(x, idx, conv_weight, bn, slope, x_pm=None, both=False, w_cat=None):
     """Fused single-layer EdgeConv: x (B,C,N), idx (B,N,k) int32, conv_weight (Co,2C,1,1), bn a BatchNorm2d module
     (its running statistics are updated in place like nn.BatchNorm2d does) -> (B,Co,N); with both=True also the
     point-major copy (B,N,Co).  x_pm: optional point-major (B,N,C) copy of x (saves the transpose for the GEMM)."""
     _need_gpu(x, idx, conv_weight)
     Co, C2 = conv_weight.shape[0], conv_weight.shape[1]
     C = C2 // 2
-    w_cat = _EdgeWeights.apply(conv_weight.reshape(Co, C2).to(torch.float32))   # (2Co, C): [W_rel ; W_ctr - W_rel]
+    if w_cat is None:        # (2Co, C): [W_rel ; W_ctr - W_rel]; models hand in the batch of edge_weights_many instead
+        w_cat = _EdgeWeights.apply(conv_weight.reshape(Co, C2).to(torch.float32))
     if x_pm is None:
         x_pm = x.transpose(1, 2)
     pq = linear_pm(x_pm.to(torch.float32).contiguous(), w_cat)                   # (B,N,2Co): one plain GEMM
@@ -582,12 +625,13 @@ def _bn_step(bn):
     return training, float(momentum)
 
 
-def edgeconv2(x, idx, conv1_weight, bn1, conv2_weight, bn2, slope, x_pm=None, both=False):
+def edgeconv2(x, idx, conv1_weight, bn1, conv2_weight, bn2, slope, x_pm=None, both=False, w_cat=None):
     """Fused two-layer EdgeConv (2C -> 64 -> 64|128): see csrc/edgeconv2.hip."""
     _need_gpu(x, idx, conv1_weight, conv2_weight)
     C1, CC = conv1_weight.shape[0], conv1_weight.shape[1]
     C = CC // 2
-    w_cat = _EdgeWeights.apply(conv1_weight.reshape(C1, CC).to(torch.float32))
+    if w_cat is None:
+        w_cat = _EdgeWeights.apply(conv1_weight.reshape(C1, CC).to(torch.float32))
     if x_pm is None:
         x_pm = x.transpose(1, 2)
     pq = linear_pm(x_pm.to(torch.float32).contiguous(), w_cat)                   # (B,N,128)

@@ -74,7 +74,24 @@ class EdgeConv(nn.Module):
         widths = [2 * in_features, *out_features_list]
         self.shared_mlp = nn.ModuleList(SharedFullyConnected(a, b) for a, b in zip(widths[:-1], widths[1:]))
 
-    def forward(self, x, fixed_knn_graph=None, x_pm=None, both=False):
+    @property
+    def fused(self):
+        """True when this block runs on one of the fused HIP EdgeConv paths (its first conv then takes the P/Q weight)"""
+        mlp = self.shared_mlp
+        if len(mlp) == 1 and len(mlp[0].layers) == 3:
+            return F_hip.edgeconv1_supported(mlp[0].layers[0].out_channels, self.k)
+        return len(mlp) == 2 and all(len(m.layers) == 3 for m in mlp) and \
+            F_hip.edgeconv2_supported(mlp[0].layers[0].out_channels, mlp[1].layers[0].out_channels, self.k)
+
+    @staticmethod
+    def pq_weights(blocks):
+        """P/Q weights of the first conv of several fused EdgeConv blocks in ONE launch (None for unfused blocks)"""
+        fused = [b for b in blocks if b.fused]
+        ws = F_hip.edge_weights_many([b.shared_mlp[0].layers[0].weight for b in fused]) if fused else []
+        it = iter(ws)
+        return [next(it) if b.fused else None for b in blocks]
+
+    def forward(self, x, fixed_knn_graph=None, x_pm=None, both=False, w_cat=None):
         """x (B,C,N) -> (B,Cout,N) like the reference; `both=True` additionally returns the point-major copy
         (B,N,Cout) that the point-wise head consumes (`both="twice"`: that copy twice, for two consumers), `x_pm` is an
         optional point-major copy of the input."""
@@ -85,7 +102,7 @@ class EdgeConv(nn.Module):
             if graph is None:
                 graph = F_hip.knn_graph(x, self.k, c_knn=3 if self.first_layer else None, fix_diag=True)
             conv, bn, act = self.shared_mlp[0].layers
-            return F_hip.edgeconv1(x, graph, conv.weight, bn, act.negative_slope, x_pm=x_pm, both=both)
+            return F_hip.edgeconv1(x, graph, conv.weight, bn, act.negative_slope, x_pm=x_pm, both=both, w_cat=w_cat)
         if len(self.shared_mlp) == 2 and all(len(m.layers) == 3 for m in self.shared_mlp) and \
                 F_hip.edgeconv2_supported(self.shared_mlp[0].layers[0].out_channels,
                                           self.shared_mlp[1].layers[0].out_channels, self.k):
@@ -94,7 +111,7 @@ class EdgeConv(nn.Module):
                 graph = F_hip.knn_graph(x, self.k, c_knn=3 if self.first_layer else None, fix_diag=True)
             (conv1, bn1, act), (conv2, bn2, _) = self.shared_mlp[0].layers, self.shared_mlp[1].layers
             return F_hip.edgeconv2(x, graph, conv1.weight, bn1, conv2.weight, bn2, act.negative_slope, x_pm=x_pm,
-                                   both=both)
+                                   both=both, w_cat=w_cat)
         e = create_neighbor_features(x, self.k, fixed_knn_graph, knn_only_over_coords=self.first_layer)
         for layer in self.shared_mlp:
             e = layer(e)
@@ -225,9 +242,10 @@ class DGCNNSeg(DGCNNBase):
         # feeds the GEMMs; the head runs point-major, so every 1x1 conv is ONE GEMM over the B*N points
         # p1 / p2 have two consumers (the next EdgeConv and the concatenation): "twice" hands out an alias for the second,
         # so that their gradients reach the EdgeConv backward kernel separately (summed there, slices taken by stride)
-        x1, p1, p1c = self.ec1(x, self.knn_graph, both="twice")
-        x2, p2, p2c = self.ec2(x1, self.knn_graph, x_pm=p1, both="twice")
-        _, p3 = self.ec3(x2, self.knn_graph, x_pm=p2, both=True)
+        w1, w2, w3 = EdgeConv.pq_weights([self.ec1, self.ec2, self.ec3])     # one launch for the three weight transforms
+        x1, p1, p1c = self.ec1(x, self.knn_graph, both="twice", w_cat=w1)
+        x2, p2, p2c = self.ec2(x1, self.knn_graph, x_pm=p1, both="twice", w_cat=w2)
+        _, p3 = self.ec3(x2, self.knn_graph, x_pm=p2, both=True, w_cat=w3)
         levels = torch.cat([p1c, p2c, p3], dim=2).view(B * N, 192)
         gf = self.global_feature[0].layers                                                   # conv, BN, LeakyReLU
         # the two layers that read `levels` (global-feature conv and the `levels` half of the first head conv) share one

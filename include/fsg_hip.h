@@ -86,6 +86,17 @@ int fsg_graph_reverse_csr(const int32_t *idx, int B, int N, int k, int32_t *rowp
  */
 int fsg_edge_weights_fwd_f32(const float *W, int Co, int C, float *Wt, fsg_stream_t stream);
 int fsg_edge_weights_bwd_f32(const float *grad_Wt, int Co, int C, float *grad_W, fsg_stream_t stream);
+/* the same for up to 8 layers in ONE launch (the transforms depend on the weights only): src/dst per layer are W -> Wt
+ * (backward == 0) or grad_Wt -> grad_W (backward != 0); `jobs` is read on the host during the call */
+#define FSG_EDGE_WEIGHT_MAX_JOBS 8
+typedef struct fsg_edge_weight_jobs {
+    const float *src[FSG_EDGE_WEIGHT_MAX_JOBS];
+    float *dst[FSG_EDGE_WEIGHT_MAX_JOBS];
+    int Co[FSG_EDGE_WEIGHT_MAX_JOBS];
+    int C[FSG_EDGE_WEIGHT_MAX_JOBS];
+    int n;
+} fsg_edge_weight_jobs;
+int fsg_edge_weights_many_f32(const fsg_edge_weight_jobs *jobs, int backward, fsg_stream_t stream);
 
 /*
  * Fused EdgeConv with ONE shared-MLP layer: replaces models/dgcnn.py:234-241 (gather, 1x1 Conv2d, BatchNorm2d,
