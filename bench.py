@@ -12,8 +12,12 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails with the legacy mode); the GPU boxes
+# export this already -- set it before the HIP runtime starts in case a launcher drops it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
