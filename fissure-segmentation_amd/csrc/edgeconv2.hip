@@ -30,6 +30,28 @@ constexpr int MAXPAIR = 3;      // output tiles per wave
 
 __device__ __forceinline__ float lrelu(float u, float slope) { return u > 0.f ? u : u * slope; }
 
+// Row gathers with lanes = channels: the row index is wave-uniform (v_readlane of the neighbour list), so the row offset
+// belongs in the SCALAR offset of a buffer load and the lane's channel in its vector offset -- no per-load 64-bit address
+// arithmetic on the VALU (the plain-pointer form cost ~5 VALU issues per load, 160 of the ~330 of the gather phase), and a
+// row outside the tile is simply an offset outside the resource (reads 0).
+struct RowGather {
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned oob;   // a byte offset outside the resource
+    __device__ __forceinline__ RowGather(const float *base, long bytes) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(base);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        const int n = __builtin_amdgcn_readfirstlane((int)bytes);
+        rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), 0, n, 0x00020000);
+        oob = (unsigned)n;
+    }
+    // element `col` (per lane) of row `row` (uniform) of a matrix with `ld` floats per row; !ok -> 0
+    __device__ __forceinline__ float load(bool ok, int row, int ld, int col) const {
+        const unsigned so = ok ? (unsigned)row * (unsigned)(ld * 4) : oob;
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)col * 4u,
+                                                                             __builtin_amdgcn_readfirstlane(so), 0));
+    }
+};
+
 struct Tile {
     int TP, R, Rpad;
 };
@@ -53,10 +75,9 @@ __global__ __launch_bounds__(256) void ec2_fwd_kernel(const float *__restrict__ 
     float *red = Y + Rpad * (LD2 > LD1 ? LD2 : LD1);  // [3][4][C2]
 
     const int b = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: keep it scalar
     const int ld = 2 * C1;
-    const float *P = pq + (long)b * N * ld;
-    const float *Q = P + C1;
+    const RowGather rows_pq(pq + (long)b * N * ld, (long)N * ld * 4);   // [P | Q] rows of this cloud
     const int R = TP * k;
     const int ntiles = (N + TP - 1) / TP;
 
@@ -93,8 +114,8 @@ __global__ __launch_bounds__(256) void ec2_fwd_kernel(const float *__restrict__ 
                 for (int u = 0; u < 16; ++u) {
                     const bool ok = r0 + u < R && i0 + p < N;
                     const int j = __builtin_amdgcn_readlane(myj, u);
-                    y[u] = ok ? P[(long)j * ld + lane] : 0.f;
-                    qv[u] = ok ? Q[(long)(i0 + p) * ld + lane] : 0.f;
+                    y[u] = rows_pq.load(ok, j, ld, lane);
+                    qv[u] = rows_pq.load(ok, i0 + p, ld, C1 + lane);
                     if (++sl == k) { sl = 0; ++p; }
                 }
                 p = p_first;
@@ -228,11 +249,10 @@ __global__ __launch_bounds__(256) void ec2_bwd_kernel(
     uint8_t *rowp = As + TP * C2;                                // [Rpad] point of a row, [Rpad] slot of a row
 
     const int b = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: keep it scalar
     const int ql = lane & 31, half = lane >> 5;
     const int ld = 2 * C1;
-    const float *P = pq + (long)b * N * ld;
-    const float *Q = P + C1;
+    const RowGather rows_pq(pq + (long)b * N * ld, (long)N * ld * 4);   // [P | Q] rows of this cloud
     const int R = TP * k;
     const int ntiles = (N + TP - 1) / TP;
 
@@ -277,8 +297,8 @@ __global__ __launch_bounds__(256) void ec2_bwd_kernel(
                 for (int u = 0; u < 16; ++u) {
                     const bool ok = r0 + u < R && i0 + p < N;
                     const int j = __builtin_amdgcn_readlane(myj, u);
-                    y[u] = ok ? P[(long)j * ld + lane] : 0.f;
-                    qv[u] = ok ? Q[(long)(i0 + p) * ld + lane] : 0.f;
+                    y[u] = rows_pq.load(ok, j, ld, lane);
+                    qv[u] = rows_pq.load(ok, i0 + p, ld, C1 + lane);
                     if (++sl == k) { sl = 0; ++p; }
                 }
 #pragma unroll
@@ -421,7 +441,7 @@ __global__ __launch_bounds__(256) void ec2_bwd_gather_kernel(
     const float *__restrict__ mean1, const float *__restrict__ invstd1, const float *__restrict__ dbeta1,
     const float *__restrict__ dgamma1, int N, int k, int training, float invM, float *__restrict__ grad_pq) {
     const int b = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: keep it scalar
     const int j = blockIdx.y * 4 + wave;
     if (j >= N) return;
     const int c = lane;
