@@ -20,7 +20,7 @@ __device__ __forceinline__ float lrelu(float u, float slope) { return u > 0.f ? 
 __global__ __launch_bounds__(256) void bnact_stats_kernel(const float *__restrict__ y, long M, int C,
                                                            float *__restrict__ partials) {
     __shared__ float red[3][4][64];
-    const int cg = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cg = blockIdx.x, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = cg * 64 + lane;
     const long r0 = (long)blockIdx.y * ROWS;
     const long r1 = r0 + ROWS < M ? r0 + ROWS : M;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void bnact_bwd_reduce_kernel(const float *__re
                                                                 const float *__restrict__ invstd, long M, int C,
                                                                 float slope, float *__restrict__ partials) {
     __shared__ float red[2][4][64];
-    const int cg = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cg = blockIdx.x, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = cg * 64 + lane;
     const long r0 = (long)blockIdx.y * ROWS;
     const long r1 = r0 + ROWS < M ? r0 + ROWS : M;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void bnmax_stats_kernel(const float *__restric
     __shared__ float red[3][4][64];
     __shared__ float bestv[4][64];
     __shared__ int besta[4][64];
-    const int cg = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cg = blockIdx.x, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = cg * 64 + lane;
     const int tiles = (N + ROWS - 1) / ROWS;
     const int b = blockIdx.y / tiles, tile = blockIdx.y - b * tiles;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void bnmax_bwd_kernel(const float *__restrict_
                                                          int B, int N, int C, int training, float slope,
                                                          float *__restrict__ gy, float *__restrict__ dgamma,
                                                          float *__restrict__ dbeta) {
-    const int cg = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cg = blockIdx.x, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = cg * 64 + lane;
     const int tiles = (N + ROWS - 1) / ROWS;
     const int b = blockIdx.y / tiles, tile = blockIdx.y - b * tiles;

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(WAVES * 64) void chamfer_nn_kernel(const float *__r
     __shared__ float4 ty[TILE];
     __shared__ float pd[WAVES][QW];
     __shared__ int pj[WAVES][QW];
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i0 = blockIdx.x * QW + lane, i1 = i0 + 64;
     const float *yb = y + (long)b * M * 3;
     float ax = 0.f, ay = 0.f, az = 0.f, bx = 0.f, by = 0.f, bz = 0.f;

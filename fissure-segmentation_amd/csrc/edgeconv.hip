@@ -169,7 +169,7 @@ __global__ __launch_bounds__(1024) void csr_scan_fill_kernel(const int32_t *__re
     extern __shared__ int sh[];   // [N] totals -> cursors, [N] counts of the lower slices
     __shared__ int wsum[16];
     int *lower = sh + N;
-    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const long NK = (long)NS * k;
     const int32_t *cb = cnt + (long)b * G * N;
     for (int j = tid; j < N; j += 1024) {
@@ -224,7 +224,7 @@ constexpr int CSR_SORT_CAP = 1024;
 __global__ __launch_bounds__(256) void csr_sort_rows_kernel(const int32_t *__restrict__ rowptr, int32_t *__restrict__ col, int N,
                                                             int NK) {
     __shared__ int32_t buf[4][CSR_SORT_CAP];
-    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.y, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + wave;
     if (j >= N) return;
     const int32_t *rp = rowptr + (long)b * (N + 1);
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(512) void ec1_stats_select_kernel(const float *__re
                                                                 float *__restrict__ partials) {
     __shared__ float red[3][4 * TPW][64];
     const int b = blockIdx.x, tile = blockIdx.y, cg = blockIdx.z;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // 4 * TPW waves, 4 points each
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 4 * TPW waves, 4 points each
     const int c = cg * 64 + lane;
     const int ld = 2 * Co;
     const float *P = pq + (long)b * N * ld;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
                                                             float *__restrict__ running_mean,
                                                             float *__restrict__ running_var) {
     __shared__ double red[3][FIN_S][64];
-    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = blockIdx.x * 64 + lane;
     double a = 0.0, bm = 0.0, cm = 0.0;
 #pragma unroll 4
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void ec1_apply_kernel(const float *__restrict_
                                                          float *__restrict__ out, float *__restrict__ out_pm) {
     __shared__ float tile[64][65];
     const int b = blockIdx.x, i0 = blockIdx.y * 64, cg = blockIdx.z;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = cg * 64 + lane;
     const float g = gamma[c] * invstd[c], sh = beta[c] - mean[c] * g;
     for (int p = wave; p < 64; p += 4) {
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void ec1_bwd_point_kernel(const float *__restr
     __shared__ float tile[64][65];
     __shared__ float red[2][4][64];
     const int b = blockIdx.x, i0 = blockIdx.y * 64, cg = blockIdx.z;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int cc = wave; cc < 64; cc += 4) {
         const int i = i0 + lane;
         tile[cc][lane] = (gout && i < N) ? gout[((long)b * Co + cg * 64 + cc) * N + i] : 0.f;
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void ec1_bwd_point_kernel(const float *__restr
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float *__restrict__ partials, int R, int Co, int nvec,
                                                             float *__restrict__ out0, float *__restrict__ out1) {
     __shared__ double red[4][64];
-    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = blockIdx.x * 64 + lane, v = blockIdx.y;
     double acc = 0.0;
 #pragma unroll 8
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void ec1_bwd_gather_kernel(
     const float *__restrict__ dbeta, const float *__restrict__ dgamma, int N, int k, int Co, int training, float invM,
     float *__restrict__ grad_pq) {
     const int b = blockIdx.x, cg = blockIdx.z;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = blockIdx.y * 4 + wave;
     if (j >= N) return;
     const int c = cg * 64 + lane;

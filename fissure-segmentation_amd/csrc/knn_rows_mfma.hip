@@ -120,7 +120,7 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
     // query l15 of a half -> word 16 (4s + l4) + l15: the 64 lanes of a wave hit the 64 LDS banks exactly once.
     float *qal = reinterpret_cast<float *>(ccount + QB);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: scalar
     const int l15 = lane & 15, l4 = lane >> 4;
     int b = blockIdx.y, q0 = blockIdx.x * QB;
     if (!SEG && !(flags & 65536)) {   // flag 65536: plain placement (A/B timing)

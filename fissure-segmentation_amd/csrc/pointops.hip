@@ -133,7 +133,7 @@ constexpr int FW = 8;
 template <int PPL>
 __device__ __forceinline__ void fps_multi_wave(const float *__restrict__ xyz, int st, int len, int qs, int qe,
                                                int32_t *__restrict__ idx, float *lds, unsigned long long *wkey) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float px[PPL], py[PPL], pz[PPL], md[PPL];
 #pragma unroll
     for (int r = 0; r < PPL; ++r) {
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
     __shared__ float wv[BLOCK / 64];
     __shared__ int wj[BLOCK / 64];
     __shared__ float pts[2048 * 3];
-    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int st = s ? offset[s - 1] : 0, en = offset[s];
     const int qs = s ? new_offset[s - 1] : 0, qe = new_offset[s];
     if (qe <= qs || en <= st) return;

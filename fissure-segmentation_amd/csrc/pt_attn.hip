@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void pt_stats_p_kernel(const float *__restrict
             ss[m] += (double)a * a;
         }
     }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         const double a = wave_sum_d(s[m]), b = wave_sum_d(ss[m]);
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(Geo<C>::NT) void pt_u1_kernel(const float *__restri
     float *H = T + G::EMAX * 4;                                 // [EP][HS]; afterwards the per-wave partials [WAVES][CSP][EP]
     const Stats S = split_stats(stats, C);
     const int tid = threadIdx.x, ps = tid / C, ch = tid % C;
-    const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     const float w20 = P.lp2_w[3 * ch], w21 = P.lp2_w[3 * ch + 1], w22 = P.lp2_w[3 * ch + 2], b2 = P.lp2_b[ch];
     const float m1 = S.m1[ch], r1 = S.r1[ch], g1 = P.bn1_g[ch], be1 = P.bn1_b[ch];
     // A operand: rows o of Wa, this wave's channel slice
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(Geo<C>::NT) void pt_b3_kernel(const float *__restri
         my[vv < 3 ? 3 * c2 + vv : 3 * C + c2] = a;
     }
     // (dgp, dbp): block sum of the first EMAX threads' accumulators
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         const float a = wave_sum_f(dgp[m]), b = wave_sum_f(dbp[m]);
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256) void pt_b4_kernel(const float *__restrict__ p,
             }
         }
     }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
         const float a = wave_sum_f(acc[i]);

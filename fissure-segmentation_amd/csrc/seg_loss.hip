@@ -84,7 +84,7 @@ __global__ __launch_bounds__(BLOCK) void nnu_partial_kernel(const float *__restr
             if (c == s.y) { tp[c] += s.p[c]; cnt[c] += 1.f; }
         }
     }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         const double a = wave_sum((double)tp[c]), s2 = wave_sum((double)sp[c]), n2 = wave_sum((double)cnt[c]);

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const float *__restrict
                                                          const float *__restrict__ bias, float *__restrict__ C, long ldc,
                                                          int I, int J, int K, int kchunk, float *__restrict__ part) {
     __shared__ float As[TK * LDT], Bs[TK * LDT];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, ql = lane & 31, half = lane >> 5;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, ql = lane & 31, half = lane >> 5;
     const int i0 = blockIdx.x * TI, j0 = blockIdx.y * TJ;
     const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
     const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;  // this wave's 32 x 32 quadrant
