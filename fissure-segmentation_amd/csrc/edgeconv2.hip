@@ -536,8 +536,8 @@ extern "C" int fsg_edgeconv2_fwd_f32(const float *pq, const int32_t *idx, const 
     FSG_REQUIRE(pq && idx && w2 && gamma1 && beta1 && gamma2 && beta2 && out && mean1 && invstd1 && ysel2 && arg2 &&
                     mean2 && invstd2 && workspace,
                 "fsg_edgeconv2_fwd_f32: NULL pointer");
-    FSG_REQUIRE(B > 0 && N > 0 && k > 0 && k <= 64 && (C2 == 64 || C2 == 128) && B <= 65535,
-                "fsg_edgeconv2_fwd_f32: bad shape B=%d N=%d k=%d C2=%d (layer widths 64 -> 64|128 only)", B, N, k, C2);
+    FSG_REQUIRE(B > 0 && N > 0 && N <= (1 << 21) && k > 0 && k <= 64 && (C2 == 64 || C2 == 128) && B <= 65535,
+                "fsg_edgeconv2_fwd_f32: bad shape B=%d N=%d k=%d C2=%d (layer widths 64 -> 64|128 only, N <= 2^21)", B, N, k, C2);
     FSG_REQUIRE(!training || (ssum1 && ssum2), "fsg_edgeconv2_fwd_f32: training needs ssum1/ssum2");
     hipStream_t st = (hipStream_t)stream;
     int TP, Rpad, G;
@@ -635,8 +635,8 @@ extern "C" int fsg_edgeconv2_bwd_f32(const float *grad_out, const float *grad_ou
                     grad_beta1 && grad_gamma2 && grad_beta2 && workspace,
                 "fsg_edgeconv2_bwd_f32: NULL pointer");
     FSG_REQUIRE(!training || ssum1, "fsg_edgeconv2_bwd_f32: training needs ssum1");
-    FSG_REQUIRE(B > 0 && N > 0 && k > 0 && k <= 64 && (C2 == 64 || C2 == 128) && B <= 65535,
-                "fsg_edgeconv2_bwd_f32: bad shape B=%d N=%d k=%d C2=%d", B, N, k, C2);
+    FSG_REQUIRE(B > 0 && N > 0 && N <= (1 << 21) && k > 0 && k <= 64 && (C2 == 64 || C2 == 128) && B <= 65535,
+                "fsg_edgeconv2_bwd_f32: bad shape B=%d N=%d k=%d C2=%d (N <= 2^21)", B, N, k, C2);
     hipStream_t st = (hipStream_t)stream;
     int TP, Rpad, G;
     ec2_bwd_tiling(k, C2, TP, Rpad, G, B, N);
