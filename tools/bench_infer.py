@@ -23,15 +23,23 @@ from fissure_segmentation_amd.models.pointtransformer.seg_model import PointTran
 
 
 def timed(fn, reps):
-    fn()
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(reps):
+    """median of `reps` calls, each bracketed by HIP events (the eager path is host-launched: single calls stall for tens
+    of milliseconds now and then on a shared host, a mean would report those)"""
+    import time
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.5:      # warm up: clocks, allocator, kernel attributes
         out = fn()
-    e.record()
-    torch.cuda.synchronize()
-    return s.elapsed_time(e) / reps, out
+        torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = fn()
+        e.record()
+        torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e))
+    ts.sort()
+    return ts[len(ts) // 2], out
 
 
 def main():
@@ -39,7 +47,7 @@ def main():
     ap.add_argument("--points", type=int, default=32768)
     ap.add_argument("--sample", type=int, default=2048)
     ap.add_argument("--runs", type=int, default=50)
-    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=9)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(1234)

@@ -5,7 +5,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "refresh")
 prof = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
-stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
+def newest(pattern):     # gpurun merges new files into gpurun_out/: older runs may still be lying around
+    return max(glob.glob(os.path.join(src, pattern), recursive=True), key=os.path.getmtime)
+
+
+stats = newest(os.path.join("stats", "**", "*kernel_stats.csv"))
 line = [l for l in open(os.path.join(src, "stats.log")) if '"ms_per_step"' in l][-1]
 prof_ms = json.loads(line)["ms_per_step"]
 bench = json.loads([l for l in open(os.path.join(src, "bench_c2.json")) if l.startswith("{")][-1])
@@ -17,8 +21,8 @@ with open(os.path.join(prof, f"{tag}_bench_c2_kernel_stats.csv"), "w") as f:
     f.write(open(stats).read())
 json.dump(bench, open(os.path.join(prof, f"{tag}_bench_c2.json"), "w"), indent=1)
 shutil.copy(os.path.join(src, "bench_other.jsonl"), os.path.join(prof, f"{tag}_bench_other_configs.jsonl"))
-fetch = glob.glob(os.path.join(src, "pmc_fetch", "**", "*counter_collection.csv"), recursive=True)[0]
-write = glob.glob(os.path.join(src, "pmc_write", "**", "*counter_collection.csv"), recursive=True)[0]
+fetch = newest(os.path.join("pmc_fetch", "**", "*counter_collection.csv"))
+write = newest(os.path.join("pmc_write", "**", "*counter_collection.csv"))
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarise_pmc.py"), fetch, write, tag])
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "mfma_utilisation.py")])
 print("bench:", bench["ms_per_step"], "ms/step", bench["value"], bench["unit"], "roofline", bench["roofline"]["frac"],
