@@ -246,7 +246,6 @@ __global__ __launch_bounds__(256) void ec2_bwd_kernel(
     float *A1s = Hs + TP * C2;             // [C1] a1, [C1] b1
     float *red1 = A1s + 2 * C1;            // [2][C1]  sums of du1 and du1*yhat1
     uint8_t *As = reinterpret_cast<uint8_t *>(red1 + 2 * C1);   // [TP][C2] arg2
-    uint8_t *rowp = As + TP * C2;                                // [Rpad] point of a row, [Rpad] slot of a row
 
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: keep it scalar
@@ -261,11 +260,6 @@ __global__ __launch_bounds__(256) void ec2_bwd_kernel(
         const float a = gamma1[threadIdx.x] * invstd1[threadIdx.x];
         A1s[threadIdx.x] = a;
         A1s[C1 + threadIdx.x] = beta1[threadIdx.x] - mean1[threadIdx.x] * a;
-    }
-    for (int r = threadIdx.x; r < Rpad; r += 256) {
-        const int p = r / k;
-        rowp[r] = (uint8_t)p;
-        rowp[Rpad + r] = (uint8_t)(r - p * k);
     }
     f32x16 accw[WPW];
 #pragma unroll
@@ -331,21 +325,28 @@ __global__ __launch_bounds__(256) void ec2_bwd_kernel(
                 z = rowok ? z : 0.f;
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z, wrow[2 * s], acc, 0, 0, 0);
             }
+            // dy2 = a2 (h2 [s = arg] - db2 - yhat2 dg2) splits into a part that is affine in y2 -- every edge, ONE fma per
+            // accumulator element: A + Bc y2 with A = a2 (mu2 r2 dg2 - db2), Bc = -a2 r2 dg2 -- and the selected-edge term
+            // a2 h2, which exists for one row per (point, column) and is added by the small pass after the barrier.  (Per
+            // element the unsplit form cost ~17 VALU issues: two row-table reads, the slot compare, the select.)
             const int col = ct * 32 + ql;
             const float r2 = invstd2[col], a2 = gamma2[col] * r2, mu2 = mean2[col];
             const float db2 = training ? dbeta2[col] * invM : 0.f, dg2 = training ? dgamma2[col] * invM : 0.f;
+            const float Bc = -(a2 * r2) * dg2, A = a2 * (mu2 * r2 * dg2 - db2);
+            const bool whole = rt * 32 + 32 <= rvalid;   // wave-uniform: every row of this row tile is a real edge
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                float dy = 0.f;
-                if (row < rvalid) {
-                    const int p = rowp[row], sl = rowp[Rpad + row];
-                    const float hsel = (As[p * C2 + col] == sl) ? Hs[p * C2 + col] : 0.f;
-                    const float yhat = (acc[e] - mu2) * r2;
-                    dy = a2 * (hsel - db2 - yhat * dg2);
-                }
+                float dy = __builtin_fmaf(Bc, acc[e], A);
+                if (!whole && row >= rvalid) dy = 0.f;
                 D[row * LD2 + col] = dy;
             }
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < pvalid * C2; t += 256) {   // + a2 h2 on the selected edge of every (point, column)
+            const int p = t / C2, col = t - p * C2;
+            const int sl = As[t];
+            if (sl < k) D[(p * k + sl) * LD2 + col] += gamma2[col] * invstd2[col] * Hs[t];
         }
         __syncthreads();
 
