@@ -495,23 +495,25 @@ __global__ __launch_bounds__(256) void ec1_bwd_gather_kernel(
     for (int t0 = beg; t0 < end; t0 += 64) {  // in-edges in chunks of 64: one coalesced load, then lane broadcasts
         const int mye = (t0 + lane < end) ? cb[t0 + lane] : 0;
         const int cnt = min(64, end - t0);
-        for (int t = 0; t < cnt; t += 2) {
-            const int e0 = __builtin_amdgcn_readlane(mye, t);
-            const int e1 = __builtin_amdgcn_readlane(mye, min(t + 1, cnt - 1));
-            const long o0 = ((long)b * N + (e0 >> 6)) * Co + c, o1 = ((long)b * N + (e1 >> 6)) * Co + c;
-            const float h0 = h[o0], h1 = h[o1];
-            const int a0 = arg[o0], a1 = arg[o1];
-            float q0 = 0.f, q1 = 0.f;
-            if (training) {
-                q0 = Q[(long)(e0 >> 6) * ld + c];
-                q1 = Q[(long)(e1 >> 6) * ld + c];
+        // eight in-edges per round (independent gathers in flight); the sums keep the edge order (same bits)
+        for (int t = 0; t < cnt; t += 8) {
+            float hv[8], qv[8];
+            int av[8], sl[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = __builtin_amdgcn_readlane(mye, min(t + u, cnt - 1));
+                const long o = ((long)b * N + (e >> 6)) * Co + c;
+                hv[u] = h[o];
+                av[u] = arg[o];
+                sl[u] = e & 63;
+                qv[u] = training ? Q[(long)(e >> 6) * ld + c] : 0.f;
             }
-            ah += (a0 == (e0 & 63)) ? h0 : 0.f;
-            aq += q0;
-            if (t + 1 < cnt) {
-                ah += (a1 == (e1 & 63)) ? h1 : 0.f;
-                aq += q1;
-            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (t + u < cnt) {
+                    ah += (av[u] == sl[u]) ? hv[u] : 0.f;
+                    aq += qv[u];
+                }
         }
     }
     const float r = invstd[c], coef = r * gamma[c], mu = mean[c];

@@ -455,22 +455,23 @@ __global__ __launch_bounds__(256) void ec2_bwd_gather_kernel(
     for (int t0 = beg; t0 < end; t0 += 64) {
         const int mye = (t0 + lane < end) ? cb[t0 + lane] : 0;
         const int cnt = min(64, end - t0);
-        for (int t = 0; t < cnt; t += 2) {
-            const int e0 = __builtin_amdgcn_readlane(mye, t);
-            const int e1 = __builtin_amdgcn_readlane(mye, min(t + 1, cnt - 1));
-            const long r0 = ((long)b * N + (e0 >> 6)) * k + (e0 & 63), r1 = ((long)b * N + (e1 >> 6)) * k + (e1 & 63);
-            const float d0 = du1[r0 * C1 + c], d1 = du1[r1 * C1 + c];
-            float q0 = 0.f, q1 = 0.f;
-            if (training) {
-                q0 = Q[(long)(e0 >> 6) * ld + c];
-                q1 = Q[(long)(e1 >> 6) * ld + c];
+        // eight in-edges per round: the du1 rows come from HBM (84 MB, written by the kernel before), so the number of
+        // independent loads in flight is what this loop costs; the sums keep the edge order (reproducible, same bits)
+        for (int t = 0; t < cnt; t += 8) {
+            float d[8], q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = __builtin_amdgcn_readlane(mye, min(t + u, cnt - 1));
+                const long r = ((long)b * N + (e >> 6)) * k + (e & 63);
+                d[u] = du1[r * C1 + c];
+                q[u] = training ? Q[(long)(e >> 6) * ld + c] : 0.f;
             }
-            ad += d0;
-            aq += q0;
-            if (t + 1 < cnt) {
-                ad += d1;
-                aq += q1;
-            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (t + u < cnt) {
+                    ad += d[u];
+                    aq += q[u];
+                }
         }
     }
     float own = 0.f;
