@@ -114,10 +114,24 @@ __global__ __launch_bounds__(BLOCK) void nnu_grad_kernel(const float *__restrict
     __shared__ float coefA[MAXC], coefE[MAXC];
     __shared__ float ce_scale;
     const int R = 3 * C + 3;
-    if ((int)threadIdx.x < R) {
+    {
+        // fold the per-block records: the workgroup as (group, component) with Rp = 2^m >= R components per group; every
+        // group walks its share of the records (one thread per component walking ALL of them was a chain of nrec dependent
+        // L2 round trips: 13 of the kernel's 19 us at 64 records), then the groups are merged in a fixed tree
+        __shared__ double part[BLOCK];
+        int Rp = 16;
+        while (Rp < R) Rp <<= 1;                      // R <= 99 -> Rp <= 128 <= BLOCK
+        const int comp = threadIdx.x & (Rp - 1), grp = threadIdx.x / Rp, ngrp = BLOCK / Rp;
         double v = 0.0;
-        for (int r = 0; r < nrec; ++r) v += rec[(long)r * R + threadIdx.x];
-        tot[threadIdx.x] = v;
+        if (comp < R)
+            for (int r = grp; r < nrec; r += ngrp) v += rec[(long)r * R + comp];
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int sft = ngrp >> 1; sft >= 1; sft >>= 1) {
+            if (grp < sft) part[threadIdx.x] += part[threadIdx.x + sft * Rp];
+            __syncthreads();
+        }
+        if ((int)threadIdx.x < R) tot[threadIdx.x] = part[threadIdx.x];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
