@@ -460,18 +460,27 @@ __global__ __launch_bounds__(256) void ec1_bwd_point_kernel(const float *__restr
     }
 }
 
-// sums R records of `nvec` vectors of Co floats in fp64: out[v][c]
-__global__ __launch_bounds__(256) void sum_partials_kernel(const float *__restrict__ partials, int R, int Co, int nvec,
-                                                            float *__restrict__ out0, float *__restrict__ out1) {
-    __shared__ double red[4][64];
+// sums R records of `nvec` vectors of Co floats in fp64: out[v][c].  Sixteen 64-lane slices per 64 channels stride over the
+// records (with four slices a thread walked R/4 records one dependent L2 round trip after the other: 11 us at R = 1024),
+// merged in slice order -- fixed order, reproducible
+constexpr int SUMP_SLICES = 16;
+__global__ __launch_bounds__(64 * SUMP_SLICES) void sum_partials_kernel(const float *__restrict__ partials, int R, int Co,
+                                                                        int nvec, float *__restrict__ out0,
+                                                                        float *__restrict__ out1) {
+    __shared__ double red[SUMP_SLICES][64];
     const int lane = threadIdx.x & 63, slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = blockIdx.x * 64 + lane, v = blockIdx.y;
     double acc = 0.0;
-#pragma unroll 8
-    for (int r = slice; r < R; r += 4) acc += partials[((long)r * nvec + v) * Co + c];
+#pragma unroll 4
+    for (int r = slice; r < R; r += SUMP_SLICES) acc += partials[((long)r * nvec + v) * Co + c];
     red[slice][lane] = acc;
     __syncthreads();
-    if (slice == 0) (v == 0 ? out0 : out1)[c] = (float)(red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+    if (slice == 0) {
+        double t = red[0][lane];
+#pragma unroll
+        for (int w = 1; w < SUMP_SLICES; ++w) t += red[w][lane];
+        (v == 0 ? out0 : out1)[c] = (float)t;
+    }
 }
 
 // one wave per destination point j: dP_j (reverse-graph gather) and dQ_j
@@ -571,14 +580,14 @@ int fsg_ec_bwd_point_launch(const float *gout, const float *gout_pm, long ld_pm,
                        ld_pm2, ysel, gamma,
                        beta, mean, invstd, N, Co, slope, h, partials);
     FSG_CHECK_LAUNCH("edgeconv/bwd_point");
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(Co / 64, 2), dim3(256), 0, st, partials, B * tiles64, Co, 2, dbeta,
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(Co / 64, 2), dim3(64 * SUMP_SLICES), 0, st, partials, B * tiles64, Co, 2, dbeta,
                        dgamma);
     FSG_CHECK_LAUNCH("edgeconv/bwd_sum");
     return FSG_OK;
 }
 
 int fsg_ec_sum_launch(const float *partials, int R, int L, int nvec, float *out0, float *out1, hipStream_t st) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(L / 64, nvec), dim3(256), 0, st, partials, R, L, nvec, out0, out1);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(L / 64, nvec), dim3(64 * SUMP_SLICES), 0, st, partials, R, L, nvec, out0, out1);
     FSG_CHECK_LAUNCH("edgeconv/sum");
     return FSG_OK;
 }
@@ -749,7 +758,7 @@ extern "C" int fsg_edgeconv1_bwd_f32(const float *grad_out, const float *grad_ou
     hipLaunchKernelGGL(ec1_bwd_point_kernel, dim3(B, tiles64, Co / 64), dim3(256), 0, st, grad_out, grad_out_pm, (long)ld_pm,
                        grad_out_pm2, (long)ld_pm2, ysel, gamma, beta, mean, invstd, N, Co, slope, h_scratch, workspace);
     FSG_CHECK_LAUNCH("fsg_edgeconv1_bwd_f32/point");
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(Co / 64, 2), dim3(256), 0, st, workspace, B * tiles64, Co, 2, grad_beta,
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(Co / 64, 2), dim3(64 * SUMP_SLICES), 0, st, workspace, B * tiles64, Co, 2, grad_beta,
                        grad_gamma);
     FSG_CHECK_LAUNCH("fsg_edgeconv1_bwd_f32/sum");
     const float invM = 1.0f / ((float)B * (float)N * (float)k);
