@@ -769,18 +769,22 @@ struct Segs {
     float *dst[4];
     int count;
 };
-__global__ __launch_bounds__(256) void pt_reduce_kernel(const float *__restrict__ rec, int R, int L, Segs sg) {
-    __shared__ double red[8][32];
+// (32 slices of 32 outputs: with 8 slices a thread walked R/8 records as one chain of dependent L2 round trips)
+constexpr int RED_SL = 32;
+__global__ __launch_bounds__(32 * RED_SL) void pt_reduce_kernel(const float *__restrict__ rec, int R, int L, Segs sg) {
+    __shared__ double red[RED_SL][32];
     const int ll = threadIdx.x & 31, sl = threadIdx.x >> 5, l = blockIdx.x * 32 + ll;
     double a = 0;
-    if (l < L)
-        for (int r = sl; r < R; r += 8) a += rec[(long)r * L + l];
+    if (l < L) {
+#pragma unroll 4
+        for (int r = sl; r < R; r += RED_SL) a += rec[(long)r * L + l];
+    }
     red[sl][ll] = a;
     __syncthreads();
     if (sl == 0 && l < L) {
         double t = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) t += red[i][ll];
+        for (int i = 0; i < RED_SL; ++i) t += red[i][ll];
         for (int i = 0; i < sg.count; ++i)
             if (l >= sg.off[i] && l < sg.off[i + 1]) sg.dst[i][l - sg.off[i]] = (float)t;
     }
@@ -871,7 +875,7 @@ int backward(const float *p, const int32_t *idx, const float *q, const float *k,
     {
         const int L = CS * CS + 3 * CS;
         Segs sg = {{0, CS * CS, CS * CS + CS, CS * CS + 2 * CS, L}, {G_.lw2_w, G_.lw2_b, G_.bn2_g, G_.bn2_b}, 4};
-        hipLaunchKernelGGL(pt_reduce_kernel, dim3(fsg_cdiv(L, 32)), dim3(256), 0, st, rec, gr, L, sg);
+        hipLaunchKernelGGL(pt_reduce_kernel, dim3(fsg_cdiv(L, 32)), dim3(32 * RED_SL), 0, st, rec, gr, L, sg);
     }
     // B2
     hipLaunchKernelGGL(pt_b2_kernel<C>, dim3(gr), dim3(G::NT), 0, st, p, idx, q, k, ld, P, stats, n, ns, u1, w.dz2, G_.bn2_g,
@@ -879,7 +883,7 @@ int backward(const float *p, const int32_t *idx, const float *q, const float *k,
     {
         const int L = CS * C + 2 * C + CS;
         Segs sg = {{0, CS * C, CS * C + C, CS * C + 2 * C, L}, {G_.lw1_w, G_.bn1_g, G_.bn1_b, G_.lw1_b}, 4};
-        hipLaunchKernelGGL(pt_reduce_kernel, dim3(fsg_cdiv(L, 32)), dim3(256), 0, st, rec, gr, L, sg);
+        hipLaunchKernelGGL(pt_reduce_kernel, dim3(fsg_cdiv(L, 32)), dim3(32 * RED_SL), 0, st, rec, gr, L, sg);
     }
     // B3
     hipLaunchKernelGGL(pt_b3_kernel<C>, dim3(gr), dim3(G::NT), 0, st, p, idx, q, k, ld, P, stats, n, ns, g, u1, sm, w.dz2,
@@ -887,14 +891,14 @@ int backward(const float *p, const int32_t *idx, const float *q, const float *k,
     {
         const int L = 4 * C + 6;
         Segs sg = {{0, 3 * C, 4 * C, 4 * C + 3, L}, {G_.lp2_w, G_.lp2_b, G_.bnp_g, G_.bnp_b}, 4};
-        hipLaunchKernelGGL(pt_reduce_kernel, dim3(fsg_cdiv(L, 32)), dim3(256), 0, st, rec, gr, L, sg);
+        hipLaunchKernelGGL(pt_reduce_kernel, dim3(fsg_cdiv(L, 32)), dim3(32 * RED_SL), 0, st, rec, gr, L, sg);
     }
     // B4
     const int ge = edge_grid((long)n * ns);
     hipLaunchKernelGGL(pt_b4_kernel, dim3(ge), dim3(256), 0, st, p, idx, P, stats, n, ns, w.dzp, G_.bnp_g, G_.bnp_b, invM, dp, rec);
     {
         Segs sg = {{0, 9, 12, 12, 12}, {G_.lp1_w, G_.lp1_b, nullptr, nullptr}, 2};
-        hipLaunchKernelGGL(pt_reduce_kernel, dim3(1), dim3(256), 0, st, rec, ge, 12, sg);
+        hipLaunchKernelGGL(pt_reduce_kernel, dim3(1), dim3(32 * RED_SL), 0, st, rec, ge, 12, sg);
     }
     return 0;
 }
