@@ -173,11 +173,14 @@ __global__ __launch_bounds__(1024) void csr_scan_fill_kernel(const int32_t *__re
     const long NK = (long)NS * k;
     const int32_t *cb = cnt + (long)b * G * N;
     for (int j = tid; j < N; j += 1024) {
+        int cv[FSG_CSR_SPLIT];   // G == FSG_CSR_SPLIT (launcher): all slice counts of a destination in flight at once -- with
+#pragma unroll                   // a run-time bound the loop is one dependent L2 round trip per slice
+        for (int gg = 0; gg < FSG_CSR_SPLIT; ++gg) cv[gg] = cb[(long)gg * N + j];
         int tot = 0, low = 0;
-        for (int gg = 0; gg < G; ++gg) {
-            const int c = cb[(long)gg * N + j];
-            tot += c;
-            low += gg < g ? c : 0;
+#pragma unroll
+        for (int gg = 0; gg < FSG_CSR_SPLIT; ++gg) {
+            tot += cv[gg];
+            low += gg < g ? cv[gg] : 0;
         }
         sh[j] = tot;
         lower[j] = low;
