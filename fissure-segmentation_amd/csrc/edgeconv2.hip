@@ -476,7 +476,14 @@ __global__ __launch_bounds__(256) void ec2_bwd_gather_kernel(
     }
     float own = 0.f;
     const float *dj = du1 + (((long)b * N + j) * k) * C1 + c;
-    for (int s = 0; s < k; ++s) own += dj[(long)s * C1];
+    for (int s0 = 0; s0 < k; s0 += 8) {   // eight rows in flight, summed in slot order
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = dj[(long)min(s0 + u, k - 1) * C1];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (s0 + u < k) own += t[u];
+    }
     const float r = invstd1[c], coef = r * gamma1[c], mu = mean1[c];
     float dp = ad, dq = own;
     if (training) {
