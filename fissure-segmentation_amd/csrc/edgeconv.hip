@@ -437,20 +437,35 @@ __global__ __launch_bounds__(256) void ec1_bwd_point_kernel(const float *__restr
     const int c = cg * 64 + lane;
     const float r = invstd[c], ga = gamma[c], be = beta[c], mu = mean[c];
     float sb = 0.f, sg = 0.f;
-    for (int p = wave; p < 64; p += 4) {
-        const int i = i0 + p;
-        if (i >= N) break;
-        const long o = ((long)b * N + i) * Co + c;
-        const float yhat = (ysel[o] - mu) * r;
-        const float u = __builtin_fmaf(ga, yhat, be);
-        const long row = (long)b * N + i;
-        float gv = tile[lane][p];
-        if (gout_pm) gv += gout_pm[row * ld_pm + c];
-        if (gout_pm2) gv += gout_pm2[row * ld_pm2 + c];
-        const float hv = gv * (u > 0.f ? 1.f : slope);
-        h[o] = hv;
-        sb += hv;
-        sg = __builtin_fmaf(hv, yhat, sg);
+    // four rows per round with all their loads issued first (a loop that breaks at the cloud's end is one dependent round
+    // trip per row: 16 in a row were the whole 12 us of this kernel); the sums keep the row order
+    for (int p0 = wave; p0 < 64; p0 += 16) {
+        float ys[4], g1[4], g2[4];
+#pragma unroll
+        for (int u4 = 0; u4 < 4; ++u4) {
+            const int i = i0 + p0 + 4 * u4;
+            const bool ok = i < N;
+            const long row = (long)b * N + (ok ? i : i0);
+            ys[u4] = ysel[row * Co + c];
+            g1[u4] = gout_pm ? gout_pm[row * ld_pm + c] : 0.f;
+            g2[u4] = gout_pm2 ? gout_pm2[row * ld_pm2 + c] : 0.f;
+        }
+#pragma unroll
+        for (int u4 = 0; u4 < 4; ++u4) {
+            const int p = p0 + 4 * u4, i = i0 + p;
+            if (i < N) {
+                const long o = ((long)b * N + i) * Co + c;
+                const float yhat = (ys[u4] - mu) * r;
+                const float u = __builtin_fmaf(ga, yhat, be);
+                float gv = tile[lane][p];
+                if (gout_pm) gv += g1[u4];
+                if (gout_pm2) gv += g2[u4];
+                const float hv = gv * (u > 0.f ? 1.f : slope);
+                h[o] = hv;
+                sb += hv;
+                sg = __builtin_fmaf(hv, yhat, sg);
+            }
+        }
     }
     red[0][wave][lane] = sb;
     red[1][wave][lane] = sg;
