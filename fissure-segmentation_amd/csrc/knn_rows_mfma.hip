@@ -197,8 +197,6 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
     if (QAL) __syncthreads();   // A operand copy complete
 
     for (int c0 = 0; c0 < N; c0 += CH) {
-        const int len = min(CH, N - c0);
-        const int ntile = (len + 15) >> 4;
         // ---------------------------------------------------------------- phase A: distance block into LDS
         if (SEG) {
             __syncthreads();  // qsh written (first chunk) / previous chunk's rows consumed
@@ -218,10 +216,10 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
         // (no copies), unconditional loads off one per-lane offset, and the diagonal / out-of-range fix-ups only in the
         // tiles that can need them (wave-uniform tests).  The first version of this loop spent ~230 VALU issues per
         // tile on per-load predicates, 64-bit address pairs and operand copies against 32 MFMAs (rocprofv3:
-        // SQ_INSTS_VALU 17.1 M vs SQ_INSTS_MFMA 2.1 M per launch at C=64); it survives below for 128 channels only.
+        // SQ_INSTS_VALU 17.1 M vs SQ_INSTS_MFMA 2.1 M per launch at C=64).
         // (Requesting the next chunk's first tile before the end-of-chunk barrier was tried: the 17 registers held
         // across the barrier cost more in spills at 64 channels than the hidden latency returns.)
-        constexpr bool full_chunk = !SEG && KS <= 16;   // (the launcher checks that c_knn * stride_c fits the resource)
+        constexpr bool full_chunk = !SEG;   // (SEG fills the rows above; the launcher checks that c_knn * stride_c fits the resource)
         if (full_chunk) {
             constexpr int TPW = CH / 16 / WAVES;
             static_assert(TPW % 2 == 0, "tiles per wave must be even (two operand register sets)");
@@ -310,69 +308,6 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
                 tile(b0, x0, wave + i * WAVES);
                 if (i + 2 < TPW) ld(b0, x0, col0 + (unsigned)((i + 2) * WAVES * 16));
                 tile(b1, x1, wave + (i + 1) * WAVES);
-            }
-        }
-        float bn[KS], xn = 0.f;   // operand of the NEXT tile of this wave: its loads fly while the current MFMAs run
-        // 32-bit element offsets from the (uniform) cloud base: one VGPR per address instead of a 64-bit pair
-        const unsigned sc32 = (unsigned)sc;
-        auto load_tile = [&](int t) {
-            const int jc = c0 + t * 16 + l15;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const int ch = 4 * s + l4;
-                bn[s] = (ch < c_knn && jc < N) ? xb[(unsigned)ch * sc32 + (unsigned)jc] : 0.f;
-            }
-            xn = jc < N ? xxb[(unsigned)jc] : 0.f;
-        };
-        constexpr bool PREFETCH = KS <= 16;  // no registers to spare at 128 channels
-        if (!SEG && !full_chunk && PREFETCH && wave < ntile && !(flags & 512)) load_tile(wave);
-        for (int t = wave; t < ((SEG || full_chunk) ? 0 : CH / 16); t += WAVES) {   // 128 channels only
-            if (t >= ntile || (flags & 512)) {  // beyond the cloud (flag 512: timing ablation of phase A)
-#pragma unroll
-                for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) rows[(blk * 16 + l4 * 4 + e) * STRIDE + t * 16 + l15] = INFINITY;
-                continue;
-            }
-            const int jc = c0 + t * 16 + l15;  // candidate column of this lane
-            if (!PREFETCH) load_tile(t);
-            float bv[KS];
-#pragma unroll
-            for (int s = 0; s < KS; ++s) bv[s] = bn[s];
-            const float xc = xn;
-            if (PREFETCH && t + WAVES < ntile) load_tile(t + WAVES);
-            // two independent accumulator chains (the two 16-query blocks) interleaved: a dependent 16x16x4 MFMA issues
-            // every 40 cycles, two alternating chains keep the pipe at its 32-cycle rate
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            if (QAL) {
-                float qh[KS];
-#pragma unroll
-                for (int s = 0; s < KS; ++s) qh[s] = qal[(4 * s + l4) * 16 + l15];
-#pragma unroll
-                for (int s = 0; s < KS; ++s) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qh[s], bv[s], acc0, 0, 0, 0);
-#pragma unroll
-                for (int s = 0; s < KS; ++s) qh[s] = qal[64 * KS + (4 * s + l4) * 16 + l15];
-#pragma unroll
-                for (int s = 0; s < KS; ++s) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qh[s], bv[s], acc1, 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[0][QAL ? 0 : s], bv[s], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[QAL ? 0 : 1][QAL ? 0 : s], bv[s], acc1, 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                const f32x4 acc = blk ? acc1 : acc0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int qr = blk * 16 + l4 * 4 + e;
-                    const float tt = xxq[blk][e] - 2.0f * acc[e];
-                    float d = tt + xc;
-                    if (fix_diag && jc == q0 + qr) d = 0.f;
-                    if (jc >= N) d = INFINITY;
-                    rows[qr * STRIDE + t * 16 + l15] = d;
-                }
             }
         }
         __syncthreads();
@@ -555,7 +490,7 @@ int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int
                              int32_t *idx_out, float *dist_out, float *xx_scratch, hipStream_t st) {
     const int drop = (flags & FSG_KNN_DROP_FIRST) ? 1 : 0;
     if (c_knn > 128 || k + drop > 64 || N > 65535 * 16 || xx_scratch == nullptr) return FSG_ERR_UNSUPPORTED;
-    if (c_knn <= 64 && (long)c_knn * stride_c >= (1L << 29)) return FSG_ERR_UNSUPPORTED;   // buffer resource: 2 GB
+    if ((long)c_knn * stride_c >= (1L << 29)) return FSG_ERR_UNSUPPORTED;   // buffer resource: 2 GB
     hipLaunchKernelGGL(knn_sqnorm2_kernel, dim3(fsg_cdiv(N, 256), B), dim3(256), 0, st, x, N, (long)stride_b,
                        (long)stride_c, c_knn, xx_scratch);
     FSG_CHECK_LAUNCH("fsg_knn_dense_f32/sqnorm");
@@ -592,7 +527,11 @@ int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int
         else if (small_k) FSG_KNN_RMQ(16, 16, 128, 1024, 32, true);
         else FSG_KNN_RMQ(16, 16, 128, 1024, 64, true);   // 131.6 KB rows + 16 KB best lists + 8 KB query operand
     }
-    else { if (half) FSG_KNN_RM(32, 8, 64, 512, 32); else FSG_KNN_RM(32, 8, 128, 1024, 64); }
+    else {
+        if (half) FSG_KNN_RM(32, 8, 64, 512, 32);
+        else if (!w8 && small_k) FSG_KNN_RMQ(32, 16, 128, 1024, 32, true);   // 131.6 KB rows + 8 KB lists + 16 KB query operand
+        else FSG_KNN_RM(32, 8, 128, 1024, 64);
+    }
 #undef FSG_KNN_RM
 #undef FSG_KNN_RMQ
     FSG_CHECK_LAUNCH("fsg_knn_dense_f32/rows_mfma");
