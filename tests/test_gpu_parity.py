@@ -1303,3 +1303,21 @@ def test_flat_adam_error_paths():
                   0.999, 1e-8, 0.0, None)
     with pytest.raises(RuntimeError, match="hyper"):
         _lib.call("fsg_adam_flat_f32", P(t), P(t), P(t), P(t), P(st), 64, 1e-3, None, 1.0, 0.999, 1e-8, 0.0, None)
+
+
+@pytest.mark.gpu
+def test_chamfer_backward_collapsed_targets(fsg, device):
+    """Chamfer backward when thousands of points share a handful of nearest neighbours (a collapsed reconstruction): the
+    default path sums the lanes of a wave that hit the same target before its atomics -- same gradient as fp64 autograd.
+    4096 points against 12 targets (and the 12 against the 4096), rtol 1e-4."""
+    from fissure_segmentation_amd.losses.chamfer_loss import ChamferLoss
+    rng = np.random.default_rng(21)
+    a = rng.uniform(-1, 1, (2, 4096, 3)).astype(np.float32)
+    b = rng.uniform(-1, 1, (2, 12, 3)).astype(np.float32)
+    at, bt = G(a, device).requires_grad_(True), G(b, device).requires_grad_(True)
+    ChamferLoss()(at, bt).backward()
+    ar, br = torch.from_numpy(a).double().requires_grad_(True), torch.from_numpy(b).double().requires_grad_(True)
+    d = ((ar[:, :, None, :] - br[:, None, :, :]) ** 2).sum(-1)
+    (d.min(2).values.mean(1).mean() + d.min(1).values.mean(1).mean()).backward()
+    np.testing.assert_allclose(N(at.grad), ar.grad.numpy(), rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(N(bt.grad), br.grad.numpy(), rtol=1e-4, atol=1e-7)
