@@ -42,11 +42,13 @@ class DGCNN_Cls_Encoder(LoadableModel):
             conv, bn, act = block
             if F_hip.edgeconv1_supported(conv.out_channels, self.k):  # fused gather+conv+BN+LeakyReLU+max
                 idx = graph if graph is not None else F_hip.knn_graph(x, self.k, fix_diag=False)
-                x, x_pm = F_hip.edgeconv1(x, idx, conv.weight, bn, act.negative_slope, x_pm=x_pm, both=True)
+                # the point-major output has two consumers (next block, concatenation): hand the concatenation an alias so
+                # that the two gradients reach the backward kernel separately (summed there, the slice taken by stride)
+                x, x_pm, x_cat = F_hip.edgeconv1(x, idx, conv.weight, bn, act.negative_slope, x_pm=x_pm, both="twice")
             else:
                 x = block(get_graph_feature(x, k=self.k, idx=graph)).max(dim=-1)[0]
-                x_pm = x.transpose(1, 2).contiguous()
-            feats.append(x_pm)
+                x_pm = x_cat = x.transpose(1, 2).contiguous()
+            feats.append(x_cat)
         conv5, bn5, act5 = self.conv5
         y = F_hip.linear_pm(torch.cat(feats, dim=2).view(B * N, -1), conv5.weight.view(conv5.out_channels, -1))
         if conv5.out_channels % 64 == 0:   # BN + LeakyReLU + max over the points, activation never materialised
