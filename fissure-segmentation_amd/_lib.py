@@ -49,6 +49,7 @@ SIGNATURES = {
     "fsg_ensemble_accumulate_f32": ([_P, _I, _I, _I, _I, _P, _L, _P, _P, _P], _I),
     "fsg_sample_transform_f32": ([_P, _I, _I, _L, _P, _I, _P, _P, _P], _I),
     "fsg_colsum_narrow_f32": ([_P, _L, _I, _P, _P], _I),
+    "fsg_fold_layer1_f32": ([_P, _I, _P, _L, _P, _I, _I, _I, _I, _P, _P], _I),
     "fsg_adam_flat_f32": ([_P, _P, _P, _P, _P, _L, _F, _P, _F, _F, _F, _F, _P], _I),
     "fsg_nnu_loss_workspace_bytes": ([_I], ctypes.c_size_t),
     "fsg_nnu_loss_f32": ([_P, _L, _L, _L, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _L, _L, _L, _P, _P], _I),

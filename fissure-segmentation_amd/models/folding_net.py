@@ -69,6 +69,19 @@ def _first_layer_split(conv, code, pts_pm):
     return F_hip.add_per_cloud(per_point.view(B, m, -1), per_cloud).view(B * m, -1)
 
 
+def _first_layer_relu(conv, code, pts_pm):
+    """relu of `_first_layer_split` without materialising the pre-activation: the per-cloud part is one small GEMM, the rest
+    one fused pass (fsg_fold_layer1_f32) when the width allows -- (B,E), (B,m,c) -> (B*m, Cout)"""
+    E = code.shape[1]
+    w = conv.weight.view(conv.out_channels, -1)
+    if conv.out_channels % 4 or pts_pm.shape[-1] > 3 or conv.bias is None:
+        return torch.relu(_first_layer_split(conv, code, pts_pm))
+    w_code, w_pts = F_hip.split_cols(w, E)
+    per_cloud = nn.functional.linear(code, w_code, conv.bias)                           # (B, Cout)
+    B, m = pts_pm.shape[0], pts_pm.shape[1]
+    return F_hip.fold_layer1(pts_pm, w_pts, per_cloud, relu=True).view(B * m, -1)
+
+
 def _lin(conv, x_pm):
     return F_hip.linear_pm(x_pm, conv.weight.view(conv.out_channels, -1), conv.bias)
 
@@ -125,8 +138,9 @@ class FoldingDecoder(Decoder):
         code = x.reshape(B, -1)                                                  # (B, E)
         pts = self.get_folding_points(B).to(x.device)                            # (B, m, 2|3) point-major
         for fold in (self.folding1, self.folding2):                              # Conv1d-ReLU-Conv1d-ReLU-Conv1d as GEMMs
-            y = torch.relu(_first_layer_split(fold[0], code, pts))
-            y = torch.relu(_lin(fold[2], y))
+            y = _first_layer_relu(fold[0], code, pts)                            # one pass: code part + grid part + ReLU
+            conv2 = fold[2]                                                      # bias + ReLU in the GEMM epilogue
+            y = F_hip.linear_pm_relu(y, conv2.weight.view(conv2.out_channels, -1), conv2.bias)
             pts = _lin(fold[4], y).view(B, self.m, 3)
         return pts.transpose(1, 2).contiguous()                                  # (B, 3, m)
 

@@ -384,6 +384,15 @@ int fsg_sample_transform_f32(const float *x, int B, int C, int64_t N, const int6
  */
 int fsg_colsum_narrow_f32(const float *x, int64_t M, int C, float *out, fsg_stream_t stream);
 
+/*
+ * First layer of a folding MLP (models/folding_net.py:205-221): Conv1d(E + cp, Cout, 1) over cat([code repeated over the m
+ * points, pts]) (+ ReLU) with the code part already reduced to per_cloud (B,Cout) = code W[:, :E]^T + bias by the caller:
+ *   out[b,i,:] = [relu]( per_cloud[b,:] + sum_{j<cp} pts[b,i,j] * w[:,j] ),   pts (B,m,cp), cp in 1..3, w (Cout,cp) with row
+ *   stride ldw (the W[:, E:] slice of the conv weight), out (B,m,Cout) written once.  Cout % 4 == 0, 16-byte aligned rows.
+ */
+int fsg_fold_layer1_f32(const float *pts, int cp, const float *w, int64_t ldw, const float *per_cloud, int B, int m, int Cout,
+                        int relu, float *out, fsg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1321,3 +1321,52 @@ def test_chamfer_backward_collapsed_targets(fsg, device):
     (d.min(2).values.mean(1).mean() + d.min(1).values.mean(1).mean()).backward()
     np.testing.assert_allclose(N(at.grad), ar.grad.numpy(), rtol=1e-4, atol=1e-8)
     np.testing.assert_allclose(N(bt.grad), br.grad.numpy(), rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cp,relu", [(2, True), (3, True), (3, False)])
+def test_fold_layer1_matches_the_unfused_composition(fsg, device, cp, relu):
+    """functional.fold_layer1 (fsg_fold_layer1_f32: first layer of a folding MLP, folding_net.py:205-221) against
+    [relu](Conv1d over cat([code repeated, pts])) written with torch ops, values and all three gradients; the weight
+    operand is a column slice of the conv weight (row stride E + cp).  fp32, rtol 1e-4."""
+    torch.manual_seed(cp)
+    B, m, E, Co = 3, 301, 40, 64
+    conv = torch.nn.Conv1d(E + cp, Co, 1).to(device)
+    code = torch.randn(B, E, device=device, requires_grad=True)
+    pts = torch.randn(B, m, cp, device=device, requires_grad=True)
+    g = torch.randn(B, m, Co, device=device)
+    w = conv.weight.view(Co, E + cp)
+    ref = conv(torch.cat([code[:, :, None].expand(B, E, m), pts.transpose(1, 2)], dim=1)).transpose(1, 2)
+    ref = torch.relu(ref) if relu else ref
+    ref.backward(g)
+    want = [t.grad.clone() for t in (code, pts, conv.weight, conv.bias)]
+    for t in (code, pts, conv.weight, conv.bias):
+        t.grad = None
+    w_code, w_pts = fsg.functional.split_cols(w, E)
+    per_cloud = torch.nn.functional.linear(code, w_code, conv.bias)
+    out = fsg.functional.fold_layer1(pts, w_pts, per_cloud, relu=relu)
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-5)
+    out.backward(g)
+    for got, exp in zip((code.grad, pts.grad, conv.weight.grad, conv.bias.grad), want):
+        torch.testing.assert_close(got, exp, rtol=1e-4, atol=1e-4)
+    with pytest.raises(RuntimeError, match="cp"):
+        fsg.functional.fold_layer1(torch.randn(B, m, 4, device=device), torch.randn(Co, 4, device=device), per_cloud.detach())
+
+
+@pytest.mark.gpu
+def test_linear_pm_relu_matches_linear_then_relu(fsg, device):
+    """functional.linear_pm_relu (bias + ReLU in the GEMM epilogue) == relu(linear): values bit for bit, gradients 1e-5"""
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(96, 160).to(device)
+    x = torch.randn(4, 500, 96, device=device, requires_grad=True)
+    g = torch.randn(4, 500, 160, device=device)
+    ref = torch.relu(lin(x))
+    ref.backward(g)
+    want = [t.grad.clone() for t in (x, lin.weight, lin.bias)]
+    for t in (x, lin.weight, lin.bias):
+        t.grad = None
+    out = fsg.functional.linear_pm_relu(x, lin.weight, lin.bias)
+    assert torch.equal(out, ref)
+    out.backward(g)
+    for got, exp in zip((x.grad, lin.weight.grad, lin.bias.grad), want):
+        torch.testing.assert_close(got, exp, rtol=1e-5, atol=1e-4)
