@@ -233,11 +233,12 @@ def main():
         if not dgcnn:
             raise LookupError("no EdgeConv group in this workload")
 
-        def group():
+        def group():     # the three EdgeConv layers exactly as DGCNNSeg.forward runs them (layouts handed over, no transposes)
             with torch.no_grad():
-                x1 = net.ec1(x)
-                x2 = net.ec2(x1)
-                net.ec3(x2)
+                w1, w2, w3 = type(net.ec1).pq_weights([net.ec1, net.ec2, net.ec3])
+                x1, p1, _ = net.ec1(x, both="twice", w_cat=w1)
+                x2, p2, _ = net.ec2(x1, x_pm=p1, both="twice", w_cat=w2)
+                net.ec3(x2, x_pm=p2, both=True, w_cat=w3)
         group()
         torch.cuda.synchronize()
         gg = torch.cuda.CUDAGraph()
