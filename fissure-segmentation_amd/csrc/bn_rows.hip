@@ -22,6 +22,7 @@ __global__ void bnr_stats_kernel(const float *__restrict__ x, long M, int C, dou
     extern __shared__ double red[];   // [2][blockDim]
     const int NT = blockDim.x, PT = NT / C, tid = threadIdx.x, ps = tid / C, ch = tid % C;
     double s = 0, ss = 0;
+#pragma unroll 4   // several rows in flight per thread (the loop is one dependent round trip per row otherwise)
     for (long r = (long)blockIdx.x * PT + ps; r < M; r += (long)gridDim.x * PT) {
         const float v = x[r * C + ch];
         s += v;
@@ -89,6 +90,7 @@ __global__ void bnr_bwd_reduce_kernel(const float *__restrict__ g, const float *
     const int NT = blockDim.x, PT = NT / C, tid = threadIdx.x, ps = tid / C, ch = tid % C;
     const float m = mean[ch], rs = rstd[ch];
     double db = 0, dg = 0;
+#pragma unroll 4   // several rows in flight per thread (the loop is one dependent round trip per row otherwise)
     for (long r = (long)blockIdx.x * PT + ps; r < M; r += (long)gridDim.x * PT) {
         float gv = g[r * C + ch];
         if (relu && !(out[r * C + ch] > 0.f)) gv = 0.f;
