@@ -400,10 +400,10 @@ class PTLayer(nn.Module):
         gv = queryandgroup(self.nsample, p, p, v, idx, o, o, use_xyz=False)
         pr, gk = gk[:, :, :3], gk[:, :, 3:]
         for i, layer in enumerate(self.linear_p):
-            pr = layer(pr.transpose(1, 2)).transpose(1, 2) if i == 1 else layer(pr)
+            pr = layer(pr.transpose(1, 2).contiguous()).transpose(1, 2).contiguous() if i == 1 else layer(pr)
         w = gk - q.unsqueeze(1) + pr
         for i, layer in enumerate(self.linear_w):
-            w = layer(w.transpose(1, 2)).transpose(1, 2) if i % 3 == 0 else layer(w)
+            w = layer(w.transpose(1, 2).contiguous()).transpose(1, 2).contiguous() if i % 3 == 0 else layer(w)
         w = torch.softmax(w, 1)
         n, ns, c = gv.shape
         s = self.share_planes
@@ -431,7 +431,7 @@ class TransitionDown(nn.Module):
         idx = furthestsampling(p, o, n_o)
         n_p = p[idx.long()]
         g = queryandgroup(self.nsample, p, n_p, x, None, o, n_o, use_xyz=True)
-        x = self.relu(self.bn(self.linear(g).transpose(1, 2)))
+        x = self.relu(self.bn(self.linear(g).transpose(1, 2).contiguous()))
         return [n_p, self.pool(x).squeeze(-1), n_o]
 
 
@@ -580,9 +580,38 @@ class NNULoss(nn.Module):
         return total, {"CE": ce, "GDL": gdl}
 
 
+def predict_full_pointcloud(net, pc, sample_points=1024, n_runs_min=50):
+    """models/point_seg_net.py:21-48 for any net with `num_classes`: 4/5 of the runs on random subsets, the rest mix
+    still-unseen points with seen ones; same torch.randperm calls in the same order as the reference's loop."""
+    import warnings
+    n_fill = n_runs_min // 5
+    n_first = n_runs_min - n_fill
+    n_pts = pc.shape[-1]
+    n_cls = net.num_classes if hasattr(net, "num_classes") else net(pc[..., :sample_points]).shape[1]
+    acc = torch.zeros(pc.shape[0], n_cls, *pc.shape[2:])
+    for _ in range(n_first):
+        pts = torch.randperm(n_pts)[:sample_points]
+        acc[..., pts] += torch.softmax(net(pc[..., pts]), 1)
+    unseen = torch.nonzero(acc.sum(1) == 0)[..., 1]
+    if unseen.shape[0] > 0:
+        seen = torch.nonzero(acc.sum(1))[..., 1]
+        n_mix = sample_points // 2
+        pick = torch.randperm(n_fill * n_mix) % len(unseen)
+        for r in range(n_fill):
+            lo = unseen[pick[r * n_mix:(r + 1) * n_mix]]
+            rest = torch.randperm(len(seen))[:sample_points - n_mix]
+            pts = torch.cat((lo, rest), 0)
+            acc[..., pts] += torch.softmax(net(pc[..., pts]), 1)
+        if (acc.sum(1) == 0).any():
+            warnings.warn("NOT ALL POINTS HAVE BEEN SEEN")
+    return torch.softmax(acc, 1)
+
+
 def farthest_point_sampling(kpts, num_points, start):
     """dseg_ae_regularization.py:30-43 with the random start passed in (pure torch, CPU)"""
     _, N, _ = kpts.size()
+    if N <= num_points:  # :32-35 -- nothing to sample, the cloud comes back whole and in order
+        return kpts, torch.arange(N)
     ind = torch.zeros(num_points).long()
     ind[0] = start
     dist = torch.sum((kpts - kpts[:, ind[0], :]) ** 2, dim=2)

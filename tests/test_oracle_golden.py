@@ -156,3 +156,183 @@ def test_nnu_loss_restatement():
         assert abs(parts["GDL"].item() - float(g[f"s{seed}_gdl"])) < 2e-6
         gr = g[f"s{seed}_grad"]
         assert np.abs(x.grad.numpy() - gr).max() <= 1e-5 * np.abs(gr).max()
+
+
+# --------------------------------------------------------------------------------------------------------------
+# PointTransformer path: fixtures produced by the reference's own seg_model.py / pointops.py with the two native
+# pointops_cuda calls served by oracle/fsg_oracle.c (oracle/make_golden_pt.py).  These pin every pure-torch
+# line of the path (BatchNorm views, softmax axis, share_planes grouping, TransitionUp head, interpolation weights).
+
+def packed(seed, sizes, c):
+    rng = np.random.default_rng(seed)
+    n = int(sum(sizes))
+    xyz = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    feat = rng.standard_normal((n, c)).astype(np.float32)
+    return xyz, feat, np.cumsum(np.asarray(sizes)).astype(np.int32)
+
+
+def check_grads_packed(mod, g, rtol=1e-3):
+    scale = max(float(g["gnorm_" + n]) for n, _ in mod.named_parameters())
+    for n, p in mod.named_parameters():
+        got = p.grad.reshape(-1).numpy()
+        ref_norm = float(g["gnorm_" + n])
+        if "grad_" + n in g:
+            ref = g["grad_" + n].reshape(-1)
+            assert np.linalg.norm(got - ref) <= rtol * ref_norm + 1e-5 * scale, n
+        else:
+            assert abs(np.linalg.norm(got.astype(np.float64)) - ref_norm) <= rtol * ref_norm + 1e-5 * scale, n
+            np.testing.assert_allclose(got[:16], g["ghead_" + n], rtol=2e-3, atol=1e-3 * ref_norm / np.sqrt(got.size) + 1e-5 * scale, err_msg=n)
+    for n, b in mod.named_buffers():
+        if "running" in n:
+            if "buf_" + n in g:
+                np.testing.assert_allclose(b.numpy(), g["buf_" + n], rtol=1e-4, atol=1e-5, err_msg=n)
+            else:
+                assert abs(float(b.double().norm()) - float(g["bnorm_" + n])) <= 1e-4 * float(g["bnorm_" + n]) + 1e-6, n
+
+
+PT_LAYER_FIXTURES = ["pt_layer_c32", "pt_layer_c64", "pt_layer_c128", "pt_layer_c256", "pt_layer_c512", "pt_layer_c64_eval"]
+
+
+@pytest.mark.parametrize("name", PT_LAYER_FIXTURES)
+def test_pt_layer_restatement_vs_reference(name):
+    g = load(name)
+    c, ns, sizes, train = int(g["c"]), int(g["ns"]), tuple(int(s) for s in g["sizes"]), bool(g["train"])
+    lay = fill_state_dict(ref_cpu.PTLayer(c, c, 8, ns), 811 + c).train(train)
+    xyz, feat, off = packed(900 + c + ns, sizes, c)
+    p, x = T(xyz).requires_grad_(True), T(feat).requires_grad_(True)
+    y = lay([p, x, T(off)])
+    gr = np.random.default_rng(5).standard_normal(tuple(y.shape)).astype(np.float32)
+    y.backward(T(gr))
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(x.grad.numpy(), g["grad_x"], rtol=1e-3, atol=1e-5 * np.abs(g["grad_x"]).max() + 1e-7)
+    assert np.linalg.norm(p.grad.numpy() - g["grad_p"]) <= 1e-4 * np.linalg.norm(g["grad_p"])
+    check_grads_packed(lay, g)
+
+
+def test_pt_block_restatement_vs_reference():
+    g = load("pt_block_c64")
+    blk = fill_state_dict(ref_cpu.PTBlock(64, 64, 8, 16), 821).train()
+    xyz, feat, off = packed(1821, (90, 11, 60), 64)
+    x = T(feat).requires_grad_(True)
+    _, y, _ = blk([T(xyz), x, T(off)])
+    gr = np.random.default_rng(6).standard_normal(tuple(y.shape)).astype(np.float32)
+    y.backward(T(gr))
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=1e-4, atol=1e-5)
+    assert np.linalg.norm(x.grad.numpy() - g["grad_x"]) <= 1e-4 * np.linalg.norm(g["grad_x"])
+    check_grads_packed(blk, g)
+
+
+@pytest.mark.parametrize("name", ["pt_td_s1", "pt_td_s4"])
+def test_transition_down_restatement_vs_reference(name):
+    g = load(name)
+    seed, sizes = int(g["seed"]), tuple(int(s) for s in g["sizes"])
+    td = fill_state_dict(ref_cpu.TransitionDown(int(g["cin"]), int(g["cout"]), int(g["stride"]), int(g["ns"])), seed).train()
+    xyz, feat, off = packed(seed + 1000, sizes, int(g["cin"]))
+    x = T(feat).requires_grad_(True)
+    n_p, y, n_o = td([T(xyz), x, T(off)])
+    gr = np.random.default_rng(seed + 2000).standard_normal(tuple(y.shape)).astype(np.float32)
+    y.backward(T(gr))
+    assert np.array_equal(n_o.numpy(), g["new_o"]) and n_o.dtype == torch.int32
+    assert np.array_equal(n_p.detach().numpy(), g["new_p"])
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=1e-4, atol=1e-5)
+    assert np.linalg.norm(x.grad.numpy() - g["grad_x"]) <= 1e-4 * np.linalg.norm(g["grad_x"])
+    check_grads_packed(td, g)
+
+
+def test_transition_up_restatement_vs_reference():
+    g = load("pt_tu_head")
+    tu = fill_state_dict(ref_cpu.TransitionUp(64, None), 841).train()
+    xyz, feat, off = packed(1841, (8, 8, 5), 64)
+    x = T(feat).requires_grad_(True)
+    y = tu([T(xyz), x, T(off)])
+    gr = np.random.default_rng(2841).standard_normal(tuple(y.shape)).astype(np.float32)
+    y.backward(T(gr))
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=1e-4, atol=1e-5)
+    assert np.linalg.norm(x.grad.numpy() - g["grad_x"]) <= 1e-4 * np.linalg.norm(g["grad_x"])
+    check_grads_packed(tu, g)
+
+    g = load("pt_tu")
+    tu = fill_state_dict(ref_cpu.TransitionUp(64, 32), 842).train()
+    xyz1, feat1, off1 = packed(1842, (120, 33, 64), 32)
+    xyz2, feat2, off2 = packed(1843, (30, 2, 16), 64)
+    x1, x2 = T(feat1).requires_grad_(True), T(feat2).requires_grad_(True)
+    y = tu([T(xyz1), x1, T(off1)], [T(xyz2), x2, T(off2)])
+    gr = np.random.default_rng(2842).standard_normal(tuple(y.shape)).astype(np.float32)
+    y.backward(T(gr))
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=1e-4, atol=1e-5)
+    assert np.linalg.norm(x1.grad.numpy() - g["grad_x1"]) <= 1e-4 * np.linalg.norm(g["grad_x1"])
+    assert np.linalg.norm(x2.grad.numpy() - g["grad_x2"]) <= 1e-4 * np.linalg.norm(g["grad_x2"])
+    check_grads_packed(tu, g)
+
+    g = load("pt_interp")
+    f2 = T(feat2).requires_grad_(True)
+    y = ref_cpu.interpolation(T(xyz2), T(xyz1), f2, T(off2), T(off1))
+    gr = np.random.default_rng(2850).standard_normal(tuple(y.shape)).astype(np.float32)
+    y.backward(T(gr))
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(f2.grad.numpy(), g["grad_feat"], rtol=1e-4, atol=1e-5)
+
+    g = load("pt_group")
+    q1 = ref_cpu.queryandgroup(8, T(xyz1), T(xyz1), T(feat1), None, T(off1), T(off1), use_xyz=True)
+    q2 = ref_cpu.queryandgroup(4, T(xyz1), T(xyz2), T(feat1), None, T(off1), T(off2), use_xyz=False)
+    assert np.array_equal(q1.numpy(), g["self_xyz"]) and np.array_equal(q2.numpy(), g["cross"])
+
+
+def test_pointtransformer_model_restatement_vs_reference():
+    """PointTransformerCompatibility(6, 4) at the BASELINE config 3 cloud size (2 x 2048; level 5 has 8 points per
+    cloud < nsample 16), train mode: logits, input gradient, every parameter gradient (norm + head) and running
+    statistic; and the coords-only (c == 3) eval path."""
+    g = load("pt_compat_c6")
+    net = fill_state_dict(ref_cpu.PointTransformerCompatibility(6, 4), 801).train()
+    assert [str(s) for s in g["keys"]] == list(net.state_dict().keys())
+    xt = T(cloud(1801, 2, 6, 2048)).requires_grad_(True)
+    y = net(xt)
+    gr = np.random.default_rng(2801).standard_normal(tuple(y.shape)).astype(np.float32)
+    y.backward(T(gr))
+    np.testing.assert_allclose(y.detach().numpy(), g["logits"], **TOL)
+    assert np.linalg.norm(xt.grad.numpy() - g["grad_x"]) <= 1e-3 * np.linalg.norm(g["grad_x"])
+    check_grads_packed(net, g, rtol=2e-3)
+
+    g = load("pt_compat_c3_eval")
+    net = fill_state_dict(ref_cpu.PointTransformerCompatibility(3, 4), 802).eval()
+    with torch.no_grad():
+        y = net(T(cloud(1802, 2, 3, 1024)))
+    np.testing.assert_allclose(y.numpy(), g["logits"], **TOL)
+
+
+class _ReplayRandperm:
+    """torch.randperm stand-in that returns the rows the reference run drew (predict_full_s851.npz)."""
+
+    def __init__(self, g, device="cpu"):
+        self.rows = [g[f"perm{i}"] for i in range(int(g["n_perm"]))]
+        self.i, self.device = 0, device
+
+    def __call__(self, n, *a, **kw):
+        r = self.rows[self.i]
+        assert len(r) == n, "predict_full_pointcloud drew a different sequence of permutations than the reference"
+        self.i += 1
+        return torch.from_numpy(r.astype(np.int64)).to(self.device)
+
+
+def test_predict_full_pointcloud_restatement_vs_reference(monkeypatch):
+    """models/point_seg_net.py:21-48 on the reference's DGCNNSeg (eval mode), replaying the recorded randperm rows."""
+    g = load("predict_full_s851")
+    net = fill_state_dict(ref_cpu.DGCNNSeg(k=8, in_features=3, num_classes=4), 851).eval()
+    replay = _ReplayRandperm(g)
+    monkeypatch.setattr(torch, "randperm", replay)
+    with torch.no_grad(), pytest.warns(UserWarning):
+        out = ref_cpu.predict_full_pointcloud(net, T(cloud(1851, 1, 3, 1500)), sample_points=256, n_runs_min=10)
+    assert replay.i == len(replay.rows)
+    np.testing.assert_allclose(out.numpy(), g["probs"], rtol=1e-4, atol=1e-5)
+
+
+def test_farthest_point_sampling_restatement_vs_reference():
+    """dseg_ae_regularization.py:30-43: index list of the reference's loop (random start recorded as ind[0])."""
+    g = load("fps_torch")
+    for i in range(int(g["n_cases"])):
+        seed, n, m = (int(v) for v in g[f"case{i}"])
+        pts = np.random.default_rng(seed).uniform(-1, 1, (1, n, 3)).astype(np.float32)
+        ref_ind = g[f"ind{i}"]
+        sub, ind = ref_cpu.farthest_point_sampling(T(pts), m, int(ref_ind[0]))
+        assert np.array_equal(ind.numpy(), ref_ind), i
+        assert np.array_equal(sub.numpy(), g[f"pts{i}"]), i
