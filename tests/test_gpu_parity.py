@@ -1548,3 +1548,168 @@ def test_farthest_point_sampling_vs_reference_golden(fsg, device):
         sub, ind = farthest_point_sampling(G(pts, device), m, start=int(g[f"ind{i}"][0]))
         assert np.array_equal(N(ind), g[f"ind{i}"]), i
         assert np.array_equal(N(sub), g[f"pts{i}"]), i
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Model-level parity at the BASELINE shapes against the CPU oracle (oracle/ref_cpu.py, pinned to the reference by
+# tests/test_oracle_golden.py).  The oracle materialises (B,N,N) and (B,2C,N,k) like the reference does.
+
+class GraphTape:
+    """A dynamic-graph net is a discontinuous function of its input: a k-th neighbour whose distance ties with the
+    (k+1)-th within fp32 rounding of the FEATURES flips between two correct implementations, and the flipped point's
+    max-pooled features then differ by O(0.1).  Model-level parity is therefore stated in two halves:
+      (1) every graph the HIP net builds equals, bit for bit, the C oracle's kNN of the very tensor the kernel was given;
+      (2) with those graphs handed to the oracle model (instead of the ones it would build from its own, 1e-6-different
+          features) logits / gradients / running statistics agree to the floating-point bar.
+    The fraction of rows where the oracle's own graph differs from the replayed one is measured and bounded."""
+
+    def __init__(self, fsg, monkeypatch):
+        self.calls, self.fsg, self.mp = [], fsg, monkeypatch
+        real = fsg.functional.knn_graph
+
+        def recording(x, k, c_knn=None, fix_diag=True, drop_first=False, return_dist=False, **kw):
+            out = real(x, k, c_knn=c_knn, fix_diag=fix_diag, drop_first=drop_first, return_dist=return_dist, **kw)
+            idx = out[0] if return_dist else out
+            self.calls.append(dict(x=N(x), k=k, c_knn=c_knn, fix_diag=fix_diag, drop_first=drop_first, idx=N(idx)))
+            return out
+        monkeypatch.setattr(fsg.functional, "knn_graph", recording)
+
+    def check_exact_and_replay(self, max_flipped_rows=2e-3):
+        """half (1), then patch the oracle's graph builders to replay the tape in call order"""
+        for c in self.calls:
+            want, _ = c_api.knn_dense(c["x"], c["k"], c_knn=c["c_knn"], fix_diag=c["fix_diag"], drop_first=c["drop_first"])
+            assert np.array_equal(c["idx"], want), "graph build differs from the C oracle on the kernel's own input"
+        self.flipped, self.pos = [], 0
+
+        def replay(own_idx):
+            c = self.calls[self.pos % len(self.calls)]
+            self.pos += 1
+            assert c["idx"].shape == tuple(own_idx.shape)
+            rows = (np.sort(c["idx"], -1) != np.sort(own_idx.numpy(), -1)).any(-1).mean()
+            self.flipped.append(float(rows))
+            assert rows <= max_flipped_rows, f"{rows:.2%} of the rows have another neighbour set than the oracle's own graph"
+            return torch.from_numpy(c["idx"].astype(np.int64))
+
+        self.mp.setattr(ref_cpu, "knn", lambda x, k, self_loop=False, return_dist=False:
+                        replay(ref_cpu._knn_c(x, k, drop_first=not self_loop)))
+        self.mp.setattr(ref_cpu, "knn_opensrc", lambda x, k: replay(ref_cpu._knn_c(x, k, fix_diag=False)))
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64).reshape(-1), np.asarray(b, np.float64).reshape(-1)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def _model_vs_oracle(net, ref, x, gseed, device, out_tol, g_floor, tape=None, loss_fn=None, ref_loss_fn=None):
+    """Outputs: HIP vs the fp32 oracle at `out_tol` (the north_star bar).
+    Gradients: max-pools (over k neighbours, over N points), ReLU kinks and train-mode BatchNorm over few rows make the
+    backward pass discontinuous in the forward values, so two fp32 evaluations of the SAME algorithm differ by more
+    than rounding.  The bar is therefore calibrated, not asserted: the oracle is run in fp32 and in fp64 (same graphs),
+    and the HIP gradient must be as close to the fp64 one as the oracle's own fp32 run is, within a factor K = 10
+    (`g_floor` where both are tiny): e_hip <= max(g_floor, K e_cpu32).  Why a factor and a floor: ONE activation whose
+    pre-activation is within rounding of the LeakyReLU/ReLU kink takes the other slope in one of the runs; measured on the
+    static-graph DGCNN case below (tools/diag_calibrated.py): 127 of the 128 entries of segmentation.2's BatchNorm-bias
+    gradient agree to 3e-6, entry 24 differs by 0.123 = 0.8 |g| of one row -- 1.2e-3 of the tensor's norm while the CPU
+    fp32 run, which happened not to flip there, sits at 2.5e-7.  Such flips are rank-one perturbations of every gradient
+    upstream; a wrong tile or index at these sizes shows up as >= 1e-2."""
+    import copy
+    xt = G(x, device).requires_grad_(True)
+    y = net(xt)
+    gr = np.random.default_rng(gseed).standard_normal(tuple(y.shape)).astype(np.float32)
+    if loss_fn is None:
+        y.backward(G(gr, device))
+    else:
+        loss = loss_fn(y, xt)
+        loss.backward()
+    if tape is not None:
+        tape.check_exact_and_replay()
+    runs = {}
+    for name, mod in (("f32", ref), ("f64", copy.deepcopy(ref).double())):
+        xr = torch.from_numpy(x).to(next(mod.parameters()).dtype).requires_grad_(True)
+        yr = mod(xr)
+        if loss_fn is None:
+            yr.backward(torch.from_numpy(gr).to(yr.dtype))
+            lr = None
+        else:
+            lr = ref_loss_fn(yr, xr)
+            lr.backward()
+        runs[name] = (yr.detach().numpy(), xr.grad.numpy(), {n: p.grad.numpy() for n, p in mod.named_parameters()}, lr)
+    y32, gx32, gp32, l32 = runs["f32"]
+    y64, gx64, gp64, l64 = runs["f64"]
+    np.testing.assert_allclose(N(y), y32, rtol=out_tol, atol=out_tol)
+    if loss_fn is not None:
+        assert abs(float(loss.detach()) - float(l32)) <= 1e-4 * abs(float(l32))
+    report = {"out_max_abs": float(np.abs(N(y) - y32).max())}
+    if xt.grad is not None:
+        e_hip, e_cpu = _rel(N(xt.grad), gx64), _rel(gx32, gx64)
+        report["grad_x"] = (e_hip, e_cpu)
+        assert e_hip <= max(g_floor, 10 * e_cpu), ("grad_x", e_hip, e_cpu)
+    scale = max(float(np.linalg.norm(v)) for v in gp64.values())
+    worst, bad = ("", 0.0, 0.0), []
+    for n, p in net.named_parameters():
+        got = N(p.grad).astype(np.float64)
+        den = max(float(np.linalg.norm(gp64[n])), 1e-3 * scale)   # mathematically-zero gradients: noise on all sides
+        e_hip = float(np.linalg.norm(got.reshape(-1) - gp64[n].reshape(-1))) / den
+        e_cpu = float(np.linalg.norm(gp32[n].astype(np.float64).reshape(-1) - gp64[n].reshape(-1))) / den
+        if e_hip > worst[1]:
+            worst = (n, e_hip, e_cpu)
+        if e_hip > max(g_floor, 10 * e_cpu):
+            bad.append((n, e_hip, e_cpu))
+    assert not bad, bad
+    report["worst_param"] = worst
+    for n, b in net.named_buffers():
+        if "running" in n:
+            np.testing.assert_allclose(N(b), dict(ref.named_buffers())[n].numpy(), rtol=1e-4, atol=1e-5, err_msg=n)
+    if tape is not None:
+        report["rows_with_other_neighbours_in_own_graph"] = tape.flipped
+    print("\nPARITY", type(net).__name__, tuple(x.shape), report)
+    return report
+
+
+@pytest.mark.parametrize("B,Np,k,dynamic", [(8, 2048, 20, True), (1, 8192, 40, True), (2, 2048, 40, False)])
+def test_dgcnnseg_full_size_vs_oracle(fsg, device, monkeypatch, B, Np, k, dynamic):
+    """DGCNNSeg at BASELINE config 2 (8 x 2048, k=20), at the config-4 cloud size (8192 points, k=40; one cloud keeps
+    the oracle's 8192^2 matrices small) and with the static k=40 graph of the reference's experiment scripts
+    (bash_scripts/run_dgcnn_seg_experiments.sh:17): logits 1e-4, gradients in norm, running statistics."""
+    from fissure_segmentation_amd.models.dgcnn import DGCNNSeg
+    ref = fill_state_dict(ref_cpu.DGCNNSeg(k=k, in_features=3, num_classes=4, dynamic=dynamic), 7).train()
+    net = DGCNNSeg(k=k, in_features=3, num_classes=4, dynamic=dynamic)
+    net.load_state_dict(ref.state_dict())
+    _model_vs_oracle(net.to(device).train(), ref, cloud(4000 + Np + k, B, 3, Np), 4001, device, 1e-4, 2e-3,
+                     tape=GraphTape(fsg, monkeypatch))
+
+
+def test_knn_dense_8192_64ch_k40_vs_c_oracle(fsg, device):
+    """the config-4 feature-space graph build (64 channels, 8192 points, k=40): indices AND distance bits"""
+    x = cloud(4100, 1, 64, 8192)
+    idx, dist = fsg.functional.knn_graph(G(x, device), 40, return_dist=True)
+    idx_o, dist_o = c_api.knn_dense(x, 40, fix_diag=True)
+    assert np.array_equal(N(idx), idx_o)
+    assert np.array_equal(N(dist).view(np.int32), dist_o.view(np.int32))
+
+
+def test_folding_ae_chamfer_config5_shape_vs_oracle(fsg, device, monkeypatch):
+    """BASELINE config 5 geometry: DGCNNFoldingNet(n_input_points=4096, decode_mesh=True) -- the sqrt(n) x sqrt(n) grid
+    of shapes/shape_constructor.py:8-23 -- + ChamferLoss(recon, input), forward and backward, 2 clouds of 4096 points
+    (the oracle's per-layer edge tensors are 160 MB per cloud)."""
+    from fissure_segmentation_amd.losses.chamfer_loss import ChamferLoss
+    from fissure_segmentation_amd.models.folding_net import DGCNNFoldingNet
+    ref = fill_state_dict(ref_cpu.DGCNNFoldingNet(k=20, n_embedding=512, n_input_points=4096, decode_mesh=True), 9).train()
+    net = DGCNNFoldingNet(k=20, n_embedding=512, shape_type="plane", n_input_points=4096, decode_mesh=True)
+    net.load_state_dict(ref.state_dict())
+    net = net.to(device).train()
+    rep = _model_vs_oracle(net, ref, cloud(4200, 2, 3, 4096), 0, device, 1e-4, 2e-3, tape=GraphTape(fsg, monkeypatch),
+                           loss_fn=lambda y, x: ChamferLoss()(y, x.detach()),
+                           ref_loss_fn=lambda y, x: ref_cpu.ChamferLoss()(y, x.detach()))
+    assert rep["out_max_abs"] <= 1e-4
+
+
+def test_pointtransformer_config3_shape_vs_oracle(fsg, device):
+    """BASELINE config 3: PointTransformerCompatibility on 8 clouds of 2048 points, forward + backward, against the
+    oracle (bit-identical to the reference on the committed whole-model fixture).  Whole-model tolerance as in
+    test_pointtransformer_model_vs_reference_golden."""
+    from fissure_segmentation_amd.models.pointtransformer.seg_model import PointTransformerCompatibility
+    ref = fill_state_dict(ref_cpu.PointTransformerCompatibility(6, 4), 803).train()
+    net = PointTransformerCompatibility(6, 4)
+    net.load_state_dict(ref.state_dict())
+    _model_vs_oracle(net.to(device).train(), ref, cloud(4300, 8, 6, 2048), 4301, device, 5e-4, 2e-3)
