@@ -28,6 +28,26 @@ def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
 
+# ------------------------------------------------------------------ mixed precision (model_trainer.py:75-76,157,189-193)
+# The reference runs every segmentation step under `autocast` (fp16) + GradScaler.  The HIP kernels take fp32 rows and
+# the graph is always built in fp32 (indices equal the fp32 CPU path), so every autograd.Function leaves the autocast
+# region: floating-point inputs are cast to fp32 on entry, forward and backward run with autocast off, outputs and
+# gradients are fp32.  Reduced precision is an explicit choice here (`set_mfma_operands("bf16")`), not an ambient one.
+def _amp_fwd(fn):
+    return torch.amp.custom_fwd(fn, device_type="cuda", cast_inputs=torch.float32)
+
+
+def _amp_bwd(fn):
+    return torch.amp.custom_bwd(fn, device_type="cuda")
+
+
+def no_autocast():
+    """context: autocast off (entered only when it is on, so CPU-only hosts see no device warning)"""
+    if torch.is_autocast_enabled("cuda"):
+        return torch.autocast("cuda", enabled=False)
+    return _contextlib.nullcontext()
+
+
 _deterministic = bool(_os.environ.get("FSG_DETERMINISTIC"))
 
 
@@ -72,6 +92,7 @@ def knn_graph(x, k, c_knn=None, fix_diag=True, drop_first=False, return_dist=Fal
 # ------------------------------------------------------------------ edge features (models/dgcnn.py:31-36)
 class _EdgeGather(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, idx):
         B, C, N = x.shape
         k = idx.shape[2]
@@ -84,6 +105,7 @@ class _EdgeGather(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         (idx,) = ctx.saved_tensors
         B, C, N, k = ctx.shape
@@ -133,6 +155,7 @@ class _LinearPM(torch.autograd.Function):
     them as a single workgroup."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
@@ -145,6 +168,7 @@ class _LinearPM(torch.autograd.Function):
         return torch.nn.functional.linear(x, w, b)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         g2 = g.reshape(-1, g.shape[-1])
@@ -207,12 +231,14 @@ class _LinearPM2(torch.autograd.Function):
     (M,K) gradients in a kernel of its own."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, w1, w2):
         ctx.save_for_backward(x, w1, w2)
         x2 = x.reshape(-1, x.shape[-1])
         return torch.nn.functional.linear(x2, w1), torch.nn.functional.linear(x2, w2)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g1, g2):
         x, w1, w2 = ctx.saved_tensors
         x2 = x.reshape(-1, x.shape[-1])
@@ -239,11 +265,13 @@ class _SplitCols(torch.autograd.Function):
     an add to merge them."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, w, c0):
         ctx.c0 = c0
         return w[:, :c0], w[:, c0:]
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, ga, gb):
         if ga is None or gb is None:
             R = (ga if ga is not None else gb).shape[0]
@@ -277,10 +305,12 @@ class _AddPerCloud(torch.autograd.Function):
     reduction over the middle dimension takes 29 us for (8, 2048, 256), the same sum as a batched one-row product 6 us."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, y, c):
         return y + c.unsqueeze(1)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         B, N, C = g.shape
         gc = g if g.is_contiguous() else g.contiguous()
@@ -297,6 +327,7 @@ class _LinearReLU(torch.autograd.Function):
     output); backward masks the gradient once and reuses the routing of `_LinearPM`."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, w, b):
         x2 = x.reshape(-1, x.shape[-1])
         out = torch._addmm_activation(b, x2, w.t(), use_gelu=False)
@@ -304,6 +335,7 @@ class _LinearReLU(torch.autograd.Function):
         return out.view(*x.shape[:-1], w.shape[0])
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         x, w, out = ctx.saved_tensors
         g2 = torch.ops.aten.threshold_backward(g.reshape(-1, g.shape[-1]).contiguous(), out, 0)
@@ -326,6 +358,7 @@ class _FoldLayer1(torch.autograd.Function):
     (fsg_fold_layer1_f32; as thin GEMM + broadcast add + ReLU the tensor is written three times and read twice)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, pts, w_p, per_cloud, relu):
         pts, per_cloud = _f32c(pts), _f32c(per_cloud)
         B, m, cp = pts.shape
@@ -341,6 +374,7 @@ class _FoldLayer1(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         pts, w_p, out = ctx.saved_tensors
         B, m, cp = pts.shape
@@ -366,6 +400,7 @@ class _EdgeWeights(torch.autograd.Function):
     launch forward and one backward (fsg_edge_weights_*; ATen's slice / subtract / cat chain is 2 + 4)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, W):
         Co, C2 = W.shape
         Wc = W if (W.dtype == torch.float32 and W.is_contiguous()) else W.float().contiguous()
@@ -375,6 +410,7 @@ class _EdgeWeights(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         Co, C = g.shape[0] // 2, g.shape[1]
         gc = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
@@ -404,12 +440,14 @@ class _EdgeWeightsMany(torch.autograd.Function):
         return outs
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, *Ws):
         Wc = [W if (W.dtype == torch.float32 and W.is_contiguous()) else W.float().contiguous() for W in Ws]
         ctx.shapes = [(W.shape[0], W.shape[1] // 2) for W in Wc]
         return tuple(_EdgeWeightsMany._run(Wc, ctx.shapes, False))
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, *gs):
         dev = next(g for g in gs if g is not None).device
         gc = [torch.zeros(2 * Co, C, dtype=torch.float32, device=dev) if g is None else
@@ -460,13 +498,17 @@ def deferred_bn_counters():
 
 
 def with_deferred_bn_counters(forward):
-    """decorator for a top-level model forward"""
+    """decorator for a top-level model forward: one multi-tensor add for the BatchNorm call counters, and the whole
+    forward outside any ambient autocast region (the plain torch glue between the HIP stages -- concatenations, the small
+    per-cloud products -- would otherwise round to fp16 between fp32 kernels); a half-precision input is widened."""
     import functools
 
     @functools.wraps(forward)
-    def wrapped(*args, **kwargs):
-        with deferred_bn_counters():
-            return forward(*args, **kwargs)
+    def wrapped(self, x, *args, **kwargs):
+        with deferred_bn_counters(), no_autocast():
+            if torch.is_tensor(x) and x.is_floating_point() and x.dtype != torch.float32:
+                x = x.float()
+            return forward(self, x, *args, **kwargs)
     return wrapped
 
 
@@ -543,6 +585,7 @@ def _pm_grad(g, B, N, C):
 
 class _EdgeConv1(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, pq, idx, gamma, beta, running_mean, running_var, training, momentum, eps, slope):
         pq = _f32c(pq)
         B, N, two_co = pq.shape
@@ -574,6 +617,7 @@ class _EdgeConv1(torch.autograd.Function):
         return out, out_pm, out_pm.view(B, N, Co)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g, g_pm, g_pm2):
         pq, idx, gamma, beta, mean, invstd, ysel, arg, ssum = ctx.saved_tensors
         B, N, k, Co, training, slope = ctx.meta
@@ -632,6 +676,7 @@ def edgeconv1(x, idx, conv_weight, bn, slope, x_pm=None, both=False, w_cat=None)
 
 class _EdgeConv2(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, pq, idx, w2, g1, b1, rm1, rv1, g2, b2, rm2, rv2, training, mom1, mom2, eps1, eps2, slope):
         pq, w2 = _f32c(pq), _f32c(w2)
         g1, b1, g2, b2 = _f32c(g1), _f32c(b1), _f32c(g2), _f32c(b2)
@@ -662,6 +707,7 @@ class _EdgeConv2(torch.autograd.Function):
         return out, out_pm, out_pm.view(B, N, C2)    # alias for a second consumer, see _EdgeConv1
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g, g_pm, g_pm2):
         pq, idx, w2, g1, b1, mean1, invstd1, ssum1, g2, b2, mean2, invstd2, ysel2, arg2 = ctx.saved_tensors
         B, N, k, C2, training, slope = ctx.meta
@@ -727,6 +773,7 @@ def edgeconv2(x, idx, conv1_weight, bn1, conv2_weight, bn2, slope, x_pm=None, bo
 # ------------------------------------------------------------------ BatchNorm + LeakyReLU on (M, C) rows
 class _BNAct(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, y, gamma, beta, rm, rv, training, momentum, eps, slope):
         y, gamma, beta = _f32c(y), _f32c(gamma), _f32c(beta)
         M, C = y.shape
@@ -747,6 +794,7 @@ class _BNAct(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         y, gamma, beta, mean, invstd = ctx.saved_tensors
         M, C, training, slope = ctx.meta
@@ -762,6 +810,7 @@ class _BNAct(torch.autograd.Function):
 
 class _BNActMax(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, y, gamma, beta, rm, rv, training, momentum, eps, slope):
         y, gamma, beta = _f32c(y), _f32c(gamma), _f32c(beta)
         B, N, C = y.shape
@@ -784,6 +833,7 @@ class _BNActMax(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         y, gamma, beta, mean, invstd, ysel, arg = ctx.saved_tensors
         B, N, C, training, slope = ctx.meta
@@ -826,6 +876,7 @@ BN_ROWS_WIDTHS = (32, 64, 128, 256, 512)
 
 class _BNRows(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, res, gamma, beta, rm, rv, training, momentum, eps, relu):
         M, C = x.shape
         dev = x.device
@@ -845,6 +896,7 @@ class _BNRows(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         x, out, gamma, mean, rstd = ctx.saved_tensors
         M, C, training, relu, has_res = ctx.meta
@@ -880,6 +932,7 @@ def bn_rows(x, bn, relu=True, residual=None):
 # ------------------------------------------------------------------ Chamfer (losses/chamfer_loss.py:19)
 class _ChamferNN(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, y):
         xc, yc = _f32c(x), _f32c(y)
         B, N, _ = xc.shape
@@ -893,6 +946,7 @@ class _ChamferNN(torch.autograd.Function):
         return d, a
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, gd, _ga):
         xc, yc, a = ctx.saved_tensors
         B, N, _ = xc.shape
@@ -918,6 +972,7 @@ def chamfer_nn(x, y):
 # ------------------------------------------------------------------ segmentation loss (losses/nnu_loss.py:6-19)
 class _NNULoss(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, logits, target, class_weights, w_ce, w_dice, smooth):
         B, C, N = logits.shape
         dev = logits.device
@@ -940,6 +995,7 @@ class _NNULoss(torch.autograd.Function):
         return total, ce, gdl
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g, _gce, _ggdl):
         grad, ctx.grad = ctx.grad, None
         if g is None:
@@ -997,6 +1053,7 @@ def fps(xyz, offset, new_offset, m):
 
 class _GroupGather(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, feat, idx):
         f = _f32c(feat)
         n, c = f.shape
@@ -1009,6 +1066,7 @@ class _GroupGather(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         (idx,) = ctx.saved_tensors
         n, c = ctx.nc
@@ -1028,6 +1086,7 @@ def group_gather(feat, idx):
 
 class _VecAttn(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, v, pos, w, idx):
         v, pos, w = _f32c(v), _f32c(pos), _f32c(w)
         n, c = v.shape
@@ -1039,6 +1098,7 @@ class _VecAttn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         v, pos, w, idx = ctx.saved_tensors
         n, c = v.shape
@@ -1071,6 +1131,7 @@ class _PTAttn(torch.autograd.Function):
     tensors u1 and softmax weights are kept for the backward; gradients: qkv and the 14 parameters."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, p, idx, qkv, bns, *params):
         n, c3 = qkv.shape
         c, ns = c3 // 3, idx.shape[1]
@@ -1109,6 +1170,7 @@ class _PTAttn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         p, idx, qkv, stats, u1, sm, *params = ctx.saved_tensors
         n, ns, c, training, eps = ctx.meta

@@ -8,6 +8,15 @@ one flat fp32 buffer (the modules, their `state_dict` and autograd are unaffecte
 one workgroup per 1024 elements, step count on the device -- torch's fused kernel, also one launch here, runs 64 Ki
 elements per workgroup = 28 workgroups for DGCNN-seg).  Same update rule as torch/optim/adam.py; always capturable into
 a hipGraph.  On a CPU model (host-logic tests) the flat buffer is handed to torch.optim.Adam instead.
+
+Drop-in contract with `torch.optim.Adam(model.parameters())` as `model_trainer.py:57,189-195` uses it:
+* `param_groups[0]["params"]` are the model's own parameters, so `GradScaler.step(opt)` unscales and inf-checks the real
+  `p.grad` tensors and skips the step on overflow like it does for torch's Adam (the flat gradient is gathered afterwards,
+  inside `step()`);
+* a parameter whose `grad` is None at `step()` is left untouched (value and moments), as torch does; the step counter is
+  global, so its bias correction follows the optimizer's step count rather than a per-parameter one;
+* `state_dict()` / `load_state_dict()` speak torch.optim.Adam's per-parameter layout (state[i] = step, exp_avg,
+  exp_avg_sq shaped like parameter i), so checkpoints move between the two optimizers in both directions.
 """
 import ctypes
 
@@ -32,15 +41,16 @@ class FlatAdam:
                 off += n
         self.flat = torch.nn.Parameter(flat)
         self.flat.grad = torch.zeros_like(flat)
-        self._views = []
+        self._views, self._spans = [], []
         off = 0
         for n in sizes:
             self._views.append(self.flat.grad[off:off + n])
+            self._spans.append((off, off + n))
             off += n
         self.inner = None
         if dev.type == "cuda":
             # lr may be a float or a 1-element device tensor (then it is read on the device at every replay)
-            self._groups = [dict(params=[self.flat], lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)]
+            self._groups = [dict(params=self.params, lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)]
             self.exp_avg, self.exp_avg_sq = torch.zeros_like(flat), torch.zeros_like(flat)
             self._state = torch.zeros(2, dtype=torch.float32, device=dev)   # { step, ticket } of fsg_adam_flat_f32
         else:
@@ -83,32 +93,62 @@ class FlatAdam:
                   float(g["eps"]), float(g["weight_decay"]), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
 
     def step(self):
+        missing = [i for i, p in enumerate(self.params) if p.grad is None]
         self.gather_grads()
+        if not missing or self.inner is not None:
+            self.step_flat()
+            return
+        # parameters without a gradient keep their value and their moments (torch.optim.Adam skips them)
+        keep = [(a, b, self.flat.data[a:b].clone(), self.exp_avg[a:b].clone(), self.exp_avg_sq[a:b].clone())
+                for a, b in (self._spans[i] for i in missing)]
         self.step_flat()
+        with torch.no_grad():
+            for a, b, w, m, v in keep:
+                self.flat.data[a:b].copy_(w)
+                self.exp_avg[a:b].copy_(m)
+                self.exp_avg_sq[a:b].copy_(v)
 
     def state_dict(self):
-        """same layout as torch.optim.Adam over the single flat parameter"""
+        """torch.optim.Adam's layout over the model's parameters (loadable by `torch.optim.Adam(model.parameters())`)"""
         if self.inner is not None:
             return self.inner.state_dict()
         group = {k: v for k, v in self._groups[0].items() if k != "params"}
-        group["params"] = [0]
-        return {"state": {0: {"step": self._state[0].clone(), "exp_avg": self.exp_avg.clone(),
-                              "exp_avg_sq": self.exp_avg_sq.clone()}},
-                "param_groups": [group]}
+        group.update(amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                     decoupled_weight_decay=False)
+        if isinstance(group["lr"], torch.Tensor):
+            group["lr"] = float(group["lr"])
+        group["params"] = list(range(len(self.params)))
+        step = self._state[0].detach().cpu().clone()
+        state = {}
+        if float(step) > 0:
+            for i, (p, (a, b)) in enumerate(zip(self.params, self._spans)):
+                state[i] = {"step": step.clone(), "exp_avg": self.exp_avg[a:b].view(p.shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[a:b].view(p.shape).clone()}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
+        """accepts torch.optim.Adam's per-parameter layout (and this class's earlier single-flat-parameter layout)"""
         if self.inner is not None:
             self.inner.load_state_dict(sd)
             return
-        st = sd["state"].get(0)
+        st = sd["state"]
         with torch.no_grad():
-            if st is None:
-                self._state.zero_(), self.exp_avg.zero_(), self.exp_avg_sq.zero_()
-            else:
-                self._state[0] = float(st["step"])
-                self._state[1] = 0.0
-                self.exp_avg.copy_(st["exp_avg"])
-                self.exp_avg_sq.copy_(st["exp_avg_sq"])
+            self._state.zero_(), self.exp_avg.zero_(), self.exp_avg_sq.zero_()
+            if len(st) == 1 and 0 in st and st[0]["exp_avg"].numel() == self.flat.numel() and len(self.params) > 1:
+                self._state[0] = float(st[0]["step"])
+                self.exp_avg.copy_(st[0]["exp_avg"].reshape(-1))
+                self.exp_avg_sq.copy_(st[0]["exp_avg_sq"].reshape(-1))
+            elif st:
+                steps = {float(v["step"]) for v in st.values()}
+                if len(steps) != 1:
+                    raise ValueError("FlatAdam keeps one step counter; the checkpoint has per-parameter steps " + str(steps))
+                self._state[0] = steps.pop()
+                for i, v in st.items():
+                    a, b = self._spans[int(i)]
+                    if v["exp_avg"].numel() != b - a:
+                        raise ValueError(f"optimizer state {i} does not match parameter {i}")
+                    self.exp_avg[a:b].copy_(v["exp_avg"].reshape(-1))
+                    self.exp_avg_sq[a:b].copy_(v["exp_avg_sq"].reshape(-1))
         for k, v in sd["param_groups"][0].items():
             if k != "params" and k in self._groups[0]:
-                self._groups[0][k] = v
+                self._groups[0][k] = tuple(v) if k == "betas" else v

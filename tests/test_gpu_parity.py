@@ -1713,3 +1713,137 @@ def test_pointtransformer_config3_shape_vs_oracle(fsg, device):
     net = PointTransformerCompatibility(6, 4)
     net.load_state_dict(ref.state_dict())
     _model_vs_oracle(net.to(device).train(), ref, cloud(4300, 8, 6, 2048), 4301, device, 5e-4, 2e-3)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's mixed-precision step (model_trainer.py:75-76,154-195): autocast -> model -> loss -> scaled backward ->
+# scaler.step(optimizer) -> scaler.update -> zero_grad.
+
+def _forward_step(model, crit, opt, scaler, x, y, amp):
+    """the literal sequence of ModelTrainer.forward_step(train=True)"""
+    with torch.autocast("cuda", enabled=amp):
+        output = model(x)
+        loss = crit(output, y)
+    if isinstance(loss, tuple):
+        loss, components = loss
+    scaler.scale(loss).backward()
+    scaler.step(opt)
+    scaler.update()
+    opt.zero_grad()
+    return loss.detach(), output.detach()
+
+
+@pytest.mark.parametrize("model,optimizer", [("dgcnn", "adam"), ("dgcnn", "flat"), ("pointtransformer", "adam"),
+                                             ("dgcnn_stn_static", "adam"), ("pointnet", "adam")])
+def test_reference_amp_forward_step(fsg, device, model, optimizer):
+    """The HIP models inside the reference's autocast + GradScaler step: no dtype error anywhere, outputs fp32, and --
+    because every HIP stage leaves the autocast region and the loss scale is a power of two -- the same losses and
+    parameters as the plain fp32 step (three steps, 1e-5)."""
+    from fissure_segmentation_amd.losses.access_losses import get_loss_fn
+    from fissure_segmentation_amd.models.access_models import get_point_seg_model_class
+    from fissure_segmentation_amd.optim import FlatAdam
+    results = []
+    for amp in (True, False):
+        torch.manual_seed(5)
+        if model == "dgcnn":
+            net = get_point_seg_model_class("DGCNN")(in_features=3, num_classes=4, k=8)
+        elif model == "dgcnn_stn_static":
+            net = get_point_seg_model_class("DGCNN")(in_features=3, num_classes=4, k=8, spatial_transformer=True, dynamic=False)
+        elif model == "pointnet":
+            net = get_point_seg_model_class("PointNet")(in_features=3, num_classes=4, k=8)
+        else:
+            net = get_point_seg_model_class("PointTransformer")(in_features=3, num_classes=4)
+        net = fill_state_dict(net, 31).to(device).train()
+        crit = get_loss_fn("nnunet", torch.tensor([1.0, 2.0, 0.5, 1.5], device=device))
+        opt = (FlatAdam(net.parameters(), lr=1e-3) if optimizer == "flat" else torch.optim.Adam(net.parameters(), lr=1e-3))
+        scaler = torch.amp.GradScaler("cuda", enabled=amp)
+        losses = []
+        for step in range(3):
+            x = G(cloud(700 + step, 2, 3, 512), device)
+            y = G(np.random.default_rng(800 + step).integers(0, 4, (2, 512)), device)
+            loss, out = _forward_step(net, crit, opt, scaler, x, y, amp)
+            assert out.dtype == torch.float32 and loss.dtype == torch.float32
+            losses.append(float(loss))
+        results.append((losses, [p.detach().clone() for p in net.parameters()], float(scaler.get_scale()) if amp else None))
+    (l_amp, p_amp, scale), (l_ref, p_ref, _) = results
+    assert scale == 65536.0                      # no step was skipped for an overflow
+    np.testing.assert_allclose(l_amp, l_ref, rtol=1e-5)
+    for a, b in zip(p_amp, p_ref):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=2e-6)
+
+
+def test_pc_ae_step_and_half_inputs_under_autocast(fsg, device):
+    """ModelTrainer disables autocast for ChamferLoss (model_trainer.py:75), but a caller may not: encoder, decoder and
+    Chamfer under autocast, and a half-precision input cloud, still run in fp32 and match the plain run."""
+    from fissure_segmentation_amd.losses.chamfer_loss import ChamferLoss
+    from fissure_segmentation_amd.models.folding_net import DGCNNFoldingNet
+    net = fill_state_dict(DGCNNFoldingNet(k=8, n_embedding=64, shape_type="plane", n_input_points=1024, decode_mesh=True), 3)
+    net = net.to(device).train()
+    x = G(cloud(41, 2, 3, 1024), device).half().float()       # values exactly representable in fp16
+    ref = ChamferLoss()(net(x), x)
+    ref.backward()
+    g_ref = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad()
+    with torch.autocast("cuda"):
+        out = net(x.half())
+        loss = ChamferLoss()(out, x.half())
+    assert out.dtype == torch.float32 and loss.dtype == torch.float32
+    loss.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    for p, g in zip(net.parameters(), g_ref):
+        assert float((p.grad - g).norm()) <= 1e-4 * float(g.norm()) + 1e-7
+
+
+def test_flat_adam_is_a_drop_in_for_the_trainer(fsg, device):
+    """(1) GradScaler.step(FlatAdam) must unscale / inf-check the real gradients and skip the step on
+    overflow; (2) parameters without a gradient stay untouched; (3) state_dict moves to torch.optim.Adam and back."""
+    from fissure_segmentation_amd.optim import FlatAdam
+    torch.manual_seed(0)
+
+    def make():
+        torch.manual_seed(1)
+        return torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4)).to(device)
+    a, b = make(), make()
+    oa, ob = torch.optim.Adam(a.parameters(), lr=1e-2), FlatAdam(b.parameters(), lr=1e-2)
+    sa, sb = torch.amp.GradScaler("cuda", init_scale=1024.0), torch.amp.GradScaler("cuda", init_scale=1024.0)
+    for step in range(4):
+        x = torch.randn(32, 8, device=device)
+        for net, opt, sc in ((a, oa, sa), (b, ob, sb)):
+            loss = net(x).square().mean()
+            sc.scale(loss).backward()
+            if step == 2:                                        # an overflow: both must skip the step and halve the scale
+                next(net.parameters()).grad[0, 0] = float("inf")
+            sc.step(opt)
+            sc.update()
+            opt.zero_grad()
+    assert sa.get_scale() == sb.get_scale() == 512.0
+    for p, q in zip(a.parameters(), b.parameters()):
+        torch.testing.assert_close(p, q, rtol=1e-5, atol=1e-6)
+    # (3) FlatAdam -> torch.optim.Adam -> FlatAdam
+    c = make()
+    c.load_state_dict(b.state_dict())
+    oc = torch.optim.Adam(c.parameters(), lr=1e-2)
+    oc.load_state_dict(ob.state_dict())
+    d = make()
+    d.load_state_dict(b.state_dict())
+    od = FlatAdam(d.parameters(), lr=1e-2)
+    od.load_state_dict(oc.state_dict())
+    x = torch.randn(32, 8, device=device)
+    for net, opt in ((b, ob), (c, oc), (d, od)):
+        net(x).square().mean().backward()
+        opt.step()
+    for p, q, r in zip(b.parameters(), c.parameters(), d.parameters()):
+        torch.testing.assert_close(p, q, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(p, r, rtol=1e-6, atol=1e-7)
+    # (2) a parameter without a gradient keeps its value and its moments
+    e, f = make(), make()
+    oe, of = torch.optim.Adam(e.parameters(), lr=1e-2, weight_decay=1e-2), FlatAdam(f.parameters(), lr=1e-2, weight_decay=1e-2)
+    for step in range(3):
+        x = torch.randn(32, 8, device=device)
+        for net, opt in ((e, oe), (f, of)):
+            opt.zero_grad()
+            h = net[0](x) if step != 1 else torch.randn(32, 16, device=device)     # step 1: first layer gets no gradient
+            net[2](torch.relu(h)).square().mean().backward()
+            opt.step()
+    for p, q in zip(e.parameters(), f.parameters()):
+        torch.testing.assert_close(p, q, rtol=2e-3, atol=1e-5)     # global step counter: bias correction differs slightly
