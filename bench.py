@@ -99,6 +99,27 @@ def cpu_baseline(B, N, k, classes, budget_s=12.0, max_steps=8):
                       f"oracle/ref_cpu.DGCNNSeg fwd+CE+GDL+bwd+Adam, {dt:.2f} s/step"}
 
 
+def _dump_memmap(path, net, opt):
+    """address ranges of the step's long-lived buffers and of every allocator segment (with its graph pool), written
+    before the first replay: a GPU memory fault names an address, this names its owner"""
+    def rng(t):
+        return [hex(t.data_ptr()), hex(t.data_ptr() + t.numel() * t.element_size())]
+    out = {"tensors": {}, "segments": []}
+    if isinstance(opt, FlatAdam):
+        out["tensors"].update({"flat.data": rng(opt.flat.data), "flat.grad": rng(opt.flat.grad)})
+        if opt.inner is None:
+            out["tensors"].update({"exp_avg": rng(opt.exp_avg), "exp_avg_sq": rng(opt.exp_avg_sq)})
+    for n, p in net.named_parameters():
+        if p.grad is not None:
+            out["tensors"]["grad:" + n] = rng(p.grad)
+    for seg in torch.cuda.memory_snapshot():
+        out["segments"].append({"address": hex(seg["address"]), "end": hex(seg["address"] + seg["total_size"]),
+                                "pool": str(seg.get("segment_pool_id")), "type": seg.get("segment_type"),
+                                "allocated": seg.get("allocated_size")})
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +129,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam over the separate tensors instead of FlatAdam")
+    ap.add_argument("--grad-sync", default="flat", choices=["flat", "bucketed"],
+                    help="N>1: all-reduce FlatAdam's flat gradient buffer in place (one collective, no copies) or the "
+                         "bucketed averager (cat -> all-reduce -> foreach copy back)")
+    ap.add_argument("--dump-check", default=None,
+                    help="after the timed steps run ONE more fwd/bwd + gradient average and write rank 0's parameters and "
+                         "averaged gradient to this .npz (tests/test_gpu_parity.py compares it with the oracle's mean of "
+                         "shard gradients)")
     args = ap.parse_args()
 
     torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)  # warm-up and capture use side streams
@@ -158,10 +186,31 @@ def main():
         loss.backward()
         return loss
 
+    # N>1 with FlatAdam: the gradients are gathered into the optimizer's flat buffer (one cat, the tail of the fwd/bwd
+    # graph), that buffer is all-reduced IN PLACE (one collective over 2.5 MB, nothing copied back), and the optimizer
+    # graph scales by 1/world and updates.  The buffer is allocated by FlatAdam's constructor -- before any capture, from
+    # the ordinary allocator -- and lives as long as the optimizer; the two graphs do not share a memory pool.
+    flat_sync = world > 1 and isinstance(opt, FlatAdam) and args.grad_sync == "flat"
+
+    def sync_grads():
+        if flat_sync:
+            dist.all_reduce(opt.flat.grad, op=dist.ReduceOp.SUM)
+        else:
+            averager.finish()
+
+    def apply_grads():
+        if flat_sync:
+            opt.flat.grad.mul_(1.0 / world)
+            opt.step_flat()
+        else:
+            opt.step()
+
     def eager_step():
         loss = fwd_bwd()
-        averager.finish()
-        opt.step()
+        if flat_sync:
+            opt.gather_grads()
+        sync_grads()
+        apply_grads()
         return loss
 
     def fence():
@@ -193,14 +242,18 @@ def main():
                 static_loss = fwd_bwd()
                 if world == 1:
                     opt.step()
+                elif flat_sync:
+                    opt.gather_grads()
             if world > 1:
-                with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode=cmode):
-                    opt.step()
+                with torch.cuda.graph(g2, capture_error_mode=cmode):     # its own pool: nothing of g1's is recycled
+                    apply_grads()
+            if os.environ.get("FSG_DUMP_MEMMAP"):
+                _dump_memmap(os.environ["FSG_DUMP_MEMMAP"] + f".rank{rank}.json", net, opt)
 
             def graph_step():
                 g1.replay()
                 if world > 1:
-                    averager.finish()
+                    sync_grads()
                     g2.replay()
                 return static_loss
             step, launch = graph_step, "hipGraph replay"
@@ -260,6 +313,28 @@ def main():
         print(f"[bench] group timing by graph replay failed ({type(e).__name__}: {e})", file=sys.stderr)
     if not torch.isfinite(loss):
         raise SystemExit("non-finite loss")
+    if args.dump_check:
+        # one more fwd/bwd + gradient average through the SAME launch path as the timed steps, without the update
+        import numpy as np
+        params = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu().numpy()
+        if launch == "hipGraph replay":
+            g1.replay()
+            if world > 1:
+                sync_grads()
+        else:
+            fwd_bwd()
+            if flat_sync:
+                opt.gather_grads()
+            if world > 1:
+                sync_grads()
+        if flat_sync:
+            avg = (opt.flat.grad / world).cpu().numpy()
+        else:
+            avg = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu().numpy()
+        torch.cuda.synchronize()
+        if rank == 0:
+            np.savez(args.dump_check, params=params, avg_grad=avg, world=world, B=B, N=N, k=k or 0, launch=launch,
+                     grad_sync="flat" if flat_sync else "bucketed")
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -317,7 +392,10 @@ def main():
                           "global_batch": B * world, "step": "fwd + (cross-entropy + generalised Dice) + bwd + grad all-reduce + Adam",
                           "launch": launch, "optimizer": "torch.optim.Adam(fused)" if args.torch_adam else
                           "Adam over one flat parameter buffer (optim.FlatAdam: fsg_adam_flat_f32, one launch)",
-                          "parallelism": f"dp{world}"},
+                          "parallelism": f"dp{world}",
+                          "grad_sync": None if world == 1 else
+                          ("one in-place all-reduce of FlatAdam's flat gradient buffer between the fwd/bwd graph and the "
+                           "optimizer graph" if flat_sync else "bucketed averager (cat, all-reduce, copy back)")},
                "roofline": roofline, "roofline_knn": roofline_knn}
         if not dgcnn:
             out["config"]["step"] = ("fwd + cross-entropy + generalised Dice + bwd + Adam" if args.workload == "c3"
