@@ -19,6 +19,20 @@
 // ties go to the lower index exactly like oracle/fsg_oracle.c.
 #include "fsg_common.h"
 
+#ifdef FSG_KNN_STATS
+__device__ unsigned long long fsg_knn_stats[8];
+extern "C" int fsg_debug_knn_stats(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fsg_knn_stats), sizeof(fsg_knn_stats)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(fsg_knn_stats), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#define KSTAT(i, v) atomicAdd(&fsg_knn_stats[i], (unsigned long long)(v))
+#define KSTATMAX(i, v) atomicMax(&fsg_knn_stats[i], (unsigned long long)(v))
+#else
+#define KSTAT(i, v) ((void)0)
+#define KSTATMAX(i, v) ((void)0)
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -105,8 +119,16 @@ struct SegArgs {
 // QAL = true: the query (A) operand lives in LDS instead of 2*KS registers per lane and the two 16-query blocks run one
 // after the other -- the register budget then allows 16 waves per workgroup at 64 channels (128 VGPRs), and both phases
 // are latency-bound, i.e. scale with the number of resident waves.
-template <int KS, int WAVES, int SURV, int CH, int CK, bool SEG = false, bool QAL = false>
-__global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *__restrict__ x, const float *__restrict__ xx,
+// STREAM = true: only the FIRST chunk a workgroup visits -- the one that holds its own queries, so that spatially ordered
+// clouds get their tightest bound at once -- goes through the LDS distance block and the full selection.  For every later
+// chunk each row's K-th best distance tau is known and only ~K * CH / (candidates seen) of the CH new distances can beat it:
+// they are compared against tau straight out of the accumulators (3 VALU operations per value, nothing parked in LDS),
+// the few survivors are appended to the row's list (LDS atomic counter + one 8-byte store; the list lives in the row's
+// idle distance storage) and one small rank-by-counting merge per row and chunk refreshes the best list and tau.  A
+// chunk whose lists overflow (adversarial candidate order, massive ties) is simply redone through the distance block.
+// Exactness is untouched: everything with d <= tau is kept and tau never drops below the final K-th distance.
+template <int KS, int WAVES, int SURV, int CH, int CK, bool SEG = false, bool QAL = false, bool STREAM = false>
+__global__ __launch_bounds__(WAVES * 64, (STREAM && WAVES == 8) ? 4 : 1) void knn_rows_mfma_kernel(const float *__restrict__ x, const float *__restrict__ xx,
                                                              int N, long sb, long sc, int c_knn, int k, int flags,
                                                              int32_t *__restrict__ idx_out,
                                                              float *__restrict__ dist_out, SegArgs sa) {
@@ -119,6 +141,8 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
     // A operand copy (QAL only): [2 query halves][4*KS channels][16 queries].  Lane (l4, l15) reads channel 4s + l4,
     // query l15 of a half -> word 16 (4s + l4) + l15: the 64 lanes of a wave hit the 64 LDS banks exactly once.
     float *qal = reinterpret_cast<float *>(ccount + QB);
+    int *lcount = reinterpret_cast<int *>(qal + (QAL ? 4 * KS * QB : 0));                 // [QB] survivors of a streamed chunk
+    float *tauf = reinterpret_cast<float *>(lcount + QB);                                 // [QB] K-th best distance so far
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: scalar
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -157,8 +181,12 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
     const float *xxb = SEG ? nullptr : xx + (long)b * N;
     const int drop = (!SEG && (flags & FSG_KNN_DROP_FIRST)) ? 1 : 0;
     const int KK = k + drop;
+    const int LCAP = SURV - KK;   // STREAM: list slots per row behind the carried copy (the merge handles SURV entries)
 
-    if (tid < QB) ccount[tid] = 0;
+    if (tid < QB) {
+        ccount[tid] = 0;
+        if (STREAM) { lcount[tid] = 0; tauf[tid] = INFINITY; }
+    }
 
     // A operand: queries, rows l15 of the two 16-row blocks, channel 4s + l4; resident for the whole sweep
     float qa[QAL ? 1 : 2][QAL ? 1 : KS];
@@ -196,252 +224,405 @@ __global__ __launch_bounds__(WAVES * 64) void knn_rows_mfma_kernel(const float *
     const bool fix_diag = (flags & FSG_KNN_FIX_DIAG) != 0;
     if (QAL) __syncthreads();   // A operand copy complete
 
-    for (int c0 = 0; c0 < N; c0 += CH) {
-        // ---------------------------------------------------------------- phase A: distance block into LDS
-        if (SEG) {
-            __syncthreads();  // qsh written (first chunk) / previous chunk's rows consumed
-            for (int cidx = tid; cidx < CH; cidx += WAVES * 64) {
-                const int jc = c0 + cidx;
-                float cx = 0.f, cy = 0.f, cz = 0.f;
-                if (jc < N) { cx = xb[3L * jc]; cy = xb[3L * jc + 1]; cz = xb[3L * jc + 2]; }
+    // rank-by-counting merge of one row (one wave): sv[0..cc) = the carried best list (ascending), sv[cc..total) = new
+    // survivors in any order, total <= SURV; the KK smallest (distance key, index) entries land in carry[qi][rank]
+    auto rank_merge = [&](const u64 *sv, int qi, int cc, int total) {
+        __builtin_amdgcn_wave_barrier();
+        // rank of every entry among the `total` entries (distinct keys: the index is part of the key); rank < K goes
+        // to slot `rank`.  sv[0..cc) is the carried best list, ascending, so only the NEW survivors sv[cc..total) are
+        // counted by looping (LDS broadcast reads); against the sorted prefix a carried entry knows its rank (its
+        // position) and a survivor finds it with a 7-step binary search.
+        auto prefix_rank = [&](int i, u64 e) {
+            if (i < cc) return i;
+            int lo = 0;
+#pragma unroll
+            for (int step = 64; step >= 1; step >>= 1) {
+                const int m = lo + step;
+                if (m <= cc && sv[m - 1] < e) lo = m;
+            }
+            return lo;
+        };
+        const u64 e0 = lane < total ? sv[lane] : ~0ull;
+        int r0 = 0;
+        if (SURV <= 64 || total <= 64) {   // the usual case: one entry per lane
 #pragma unroll 8
-                for (int qr = 0; qr < QB; ++qr) {
-                    const float dx = qsh[3 * qr] - cx, dy = qsh[3 * qr + 1] - cy, dz = qsh[3 * qr + 2] - cz;
-                    const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                    rows[qr * STRIDE + cidx] = jc < N ? d : INFINITY;
-                }
+            for (int t = cc; t < total; ++t) r0 += sv[t] < e0 ? 1 : 0;   // same address in every lane
+            r0 += prefix_rank(lane, e0);
+            if (lane < total && r0 < KK) carry[qi * CK + r0] = e0;
+        } else {
+            const u64 e1 = (64 + lane) < total ? sv[(64 + lane) % SURV] : ~0ull;
+            int r1 = 0;
+#pragma unroll 8
+            for (int t = cc; t < total; ++t) {
+                const u64 xk = sv[t];
+                r0 += xk < e0 ? 1 : 0;
+                r1 += xk < e1 ? 1 : 0;
             }
+            r0 += prefix_rank(lane, e0);
+            r1 += prefix_rank(64 + lane, e1);
+            if (lane < total && r0 < KK) carry[qi * CK + r0] = e0;
+            if ((64 + lane) < total && r1 < KK) carry[qi * CK + r1] = e1;
         }
-        // Phase A proper (every variant up to 64 channels): the wave's CH/16/WAVES tiles over two operand register sets
-        // (no copies), unconditional loads off one per-lane offset, and the diagonal / out-of-range fix-ups only in the
-        // tiles that can need them (wave-uniform tests).  The first version of this loop spent ~230 VALU issues per
-        // tile on per-load predicates, 64-bit address pairs and operand copies against 32 MFMAs (rocprofv3:
-        // SQ_INSTS_VALU 17.1 M vs SQ_INSTS_MFMA 2.1 M per launch at C=64).
-        // (Requesting the next chunk's first tile before the end-of-chunk barrier was tried: the 17 registers held
-        // across the barrier cost more in spills at 64 channels than the hidden latency returns.)
-        constexpr bool full_chunk = !SEG;   // (SEG fills the rows above; the launcher checks that c_knn * stride_c fits the resource)
-        if (full_chunk) {
-            constexpr int TPW = CH / 16 / WAVES;
-            static_assert(TPW % 2 == 0, "tiles per wave must be even (two operand register sets)");
-            // operand loads through a buffer resource over the c_knn channel rows of this cloud: ONE per-lane byte offset
-            // (channel l4, candidate col) + a scalar offset of four channel rows per MFMA step, instead of 16 per-lane
-            // 64-bit pointers (32 VGPRs -- the compiler's choice for plain pointers); channels >= c_knn fall outside the
-            // resource and read as 0, which is exactly the zero padding of the last K group.
-            const uintptr_t xba = reinterpret_cast<uintptr_t>(xb);   // uniform by construction: tell the compiler so
-            const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xba);
-            const unsigned xhi = __builtin_amdgcn_readfirstlane((unsigned)(xba >> 32));
-            // the resource ends with column N-1 of the LAST channel row: a read past it returns 0, every read before it
-            // stays inside this cloud's own extent (with a channel stride > N, or the last cloud of a tensor, "the whole
-            // row of every channel" would reach beyond the allocation); columns >= N of the earlier rows read whatever
-            // lies between the rows -- those columns are overwritten with +inf below
-            const int nrec = __builtin_amdgcn_readfirstlane((int)((((long)c_knn - 1) * sc + N) * 4));
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                reinterpret_cast<void *>(((uintptr_t)xhi << 32) | xlo), 0, nrec, 0x00020000);
-            const unsigned col0 = (unsigned)(c0 + wave * 16 + l15);   // this lane's candidate in the wave's first tile
-            const unsigned sc32f = (unsigned)sc;
-            float b0[KS], b1[KS], x0, x1;
-            auto ld = [&](float (&bt)[KS], float &xt, unsigned col) {
-                const unsigned vo = ((unsigned)l4 * sc32f + col) * 4u;
-#pragma unroll
-                for (int s = 0; s < KS; ++s)
-                    bt[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (unsigned)(16 * s) * sc32f, 0));
-                xt = xxb[min(col, (unsigned)(N - 1))];   // columns >= N: any finite value, the epilogue writes +inf
-            };
-            auto tile = [&](const float (&bt)[KS], float xc, int t) {
-                float *dst = rows + (l4 * 4) * STRIDE + t * 16 + l15;
-                if (c0 + t * 16 >= N || (flags & 512)) {   // tile beyond the cloud (wave-uniform): nothing to compute
-                                                           // (flag 512: timing ablation of phase A)
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) dst[((r >> 2) * 16 + (r & 3)) * STRIDE] = INFINITY;
-                    return;
-                }
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                if (QAL) {
-                    // the A operand is re-read from LDS for every tile ON PURPOSE (it would cost 2 KS registers): the
-                    // offset goes through an empty asm so that the reads are not hoisted out of the tile loop
-                    int qoff = l4 * 16 + l15;
-                    asm volatile("" : "+v"(qoff));
-#pragma unroll
-                    for (int s = 0; s < KS; ++s) {   // two independent accumulator chains, alternating
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qal[64 * s + qoff], bt[s], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qal[64 * KS + 64 * s + qoff], bt[s], acc1, 0, 0, 0);
-                    }
-                } else {
-#pragma unroll
-                    for (int s = 0; s < KS; ++s) {
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[0][QAL ? 0 : s], bt[s], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[QAL ? 0 : 1][QAL ? 0 : s], bt[s], acc1, 0, 0, 0);
-                    }
-                }
-                const int drel = c0 + t * 16 - q0;   // wave-uniform: columns drel .. drel+15 against the rows 0 .. 31
-                if ((fix_diag && drel > -16 && drel < QB) || c0 + t * 16 + 16 > N) {
-                    const int jc = c0 + t * 16 + l15;
-#pragma unroll
-                    for (int blk = 0; blk < 2; ++blk) {
-                        const f32x4 acc = blk ? acc1 : acc0;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int qr = blk * 16 + l4 * 4 + e;
-                            const float tt = xxq[blk][e] - 2.0f * acc[e];
-                            float d = tt + xc;
-                            if (fix_diag && jc == q0 + qr) d = 0.f;
-                            if (jc >= N) d = INFINITY;
-                            dst[(blk * 16 + e) * STRIDE] = d;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int blk = 0; blk < 2; ++blk) {
-                        const f32x4 acc = blk ? acc1 : acc0;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float tt = xxq[blk][e] - 2.0f * acc[e];
-                            dst[(blk * 16 + e) * STRIDE] = tt + xc;
-                        }
-                    }
-                }
-            };
-            ld(b0, x0, col0);
-#pragma unroll 1
-            for (int i = 0; i < TPW; i += 2) {
-                ld(b1, x1, col0 + (unsigned)((i + 1) * WAVES * 16));
-                tile(b0, x0, wave + i * WAVES);
-                if (i + 2 < TPW) ld(b0, x0, col0 + (unsigned)((i + 2) * WAVES * 16));
-                tile(b1, x1, wave + (i + 1) * WAVES);
-            }
-        }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+    };
 
-        // ---------------------------------------------------------------- phase B: exact selection, one wave per row
-        for (int qi = wave; qi < QB; qi += WAVES) {
-            if (q0 + qi >= NQ || (flags & 256)) break;  // flag 256: timing ablation of phase B
-            const float *row = rows + qi * STRIDE;
-            float v[VPL];
+    // operand loads through a buffer resource over the c_knn channel rows of this cloud (dense mode)
+    // operand loads through a buffer resource over the c_knn channel rows of this cloud: ONE per-lane byte offset
+    // (channel l4, candidate col) + a scalar offset of four channel rows per MFMA step, instead of 16 per-lane
+    // 64-bit pointers (32 VGPRs -- the compiler's choice for plain pointers); channels >= c_knn fall outside the
+    // resource and read as 0, which is exactly the zero padding of the last K group.
+    const uintptr_t xba = reinterpret_cast<uintptr_t>(xb);   // uniform by construction: tell the compiler so
+    const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xba);
+    const unsigned xhi = __builtin_amdgcn_readfirstlane((unsigned)(xba >> 32));
+    // the resource ends with column N-1 of the LAST channel row: a read past it returns 0, every read before it
+    // stays inside this cloud's own extent (with a channel stride > N, or the last cloud of a tensor, "the whole
+    // row of every channel" would reach beyond the allocation); columns >= N of the earlier rows read whatever
+    // lies between the rows -- those columns are overwritten with +inf below
+    const int nrec = __builtin_amdgcn_readfirstlane((int)((((long)c_knn - 1) * sc + N) * 4));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void *>(((uintptr_t)xhi << 32) | xlo), 0, nrec, 0x00020000);
+
+    const unsigned sc32f = (unsigned)sc;
+    constexpr int TPC = CH / 16;          // tiles per chunk
+    constexpr int TPW = TPC / WAVES;      // tiles per wave and chunk
+    static_assert(SEG || TPW % 2 == 0, "tiles per wave must be even (two operand register sets)");
+    const int nch = (N + CH - 1) / CH;
+    // STREAM: the chunk that holds the workgroup's own queries goes first (ring order from there on)
+    const int cd = (STREAM && nch > 0) ? min(q0 / CH, nch - 1) : 0;
+    auto chunk_base = [&](int ring) { return ((cd + ring) % nch) * CH; };   // wave-uniform
+
+    auto ld = [&](float (&bt)[KS], float &xt, unsigned col) {
+        const unsigned vo = ((unsigned)l4 * sc32f + col) * 4u;
 #pragma unroll
-            for (int s = 0; s < VPL / 4; ++s) {
-                const f32x4 w = *reinterpret_cast<const f32x4 *>(row + s * 256 + 4 * lane);
+        for (int s = 0; s < KS; ++s)
+            bt[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (unsigned)(16 * s) * sc32f, 0));
+        xt = xxb[min(col, (unsigned)(N - 1))];   // columns >= N: any finite value, the epilogue writes +inf
+    };
+    // products of one 16-candidate tile against the 32 queries: two independent accumulator chains, alternating
+    auto mma = [&](const float (&bt)[KS], f32x4 &acc0, f32x4 &acc1) {
+        if (QAL) {
+            // the A operand is re-read from LDS for every tile ON PURPOSE (it would cost 2 KS registers): the offset
+            // goes through an empty asm so that the reads are not hoisted out of the tile loop
+            int qoff = l4 * 16 + l15;
+            asm volatile("" : "+v"(qoff));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 * s + e] = w[e];
+            for (int s = 0; s < KS; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qal[64 * s + qoff], bt[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qal[64 * KS + 64 * s + qoff], bt[s], acc1, 0, 0, 0);
             }
-            // the row now lives in registers: its LDS storage (4 KB, 8-byte aligned) becomes the survivor buffer of this
-            // wave (up to SURV entries).  LDS serves a wave's instructions in order, so the reads above are ahead of every
-            // write below; the empty asm keeps the compiler from moving a store (different type: no alias assumed) up.
-            asm volatile("" ::: "memory");
-            u64 *sv = reinterpret_cast<u64 *>(rows + qi * STRIDE);
-            const int cc = ccount[qi];
-            unsigned tau;
-            if (cc >= KK) {
-                tau = (unsigned)(carry[qi * CK + KK - 1] >> 32);   // K-th best so far: tighter than any chunk estimate
-            } else {
-                float f1 = INFINITY, f2 = INFINITY;                // two smallest values of this lane
+        } else {
 #pragma unroll
-                for (int e = 0; e < VPL; ++e) {
-                    const float hi = fmaxf(v[e], f1);
-                    f1 = fminf(v[e], f1);
-                    f2 = fminf(f2, hi);
-                }
-                if (lane < cc) {  // carried entries (fewer than K) also count as candidates of the bound
-                    const float cv = o2f((unsigned)(carry[qi * CK + lane] >> 32));
-                    const float hi = fmaxf(cv, f1);
-                    f1 = fminf(cv, f1);
-                    f2 = fminf(f2, hi);
-                }
-                const unsigned m1 = f2o(f1), m2 = f2o(f2);
-                // upper bound of the K-th smallest of the 128 lane minima: binary search on the top 16 key bits (two
-                // wave-wide compares + population counts per round), the 16 low bits are rounded up
-                unsigned prefix = 0u;
-#pragma unroll 4
-                for (int bit = 31; bit >= 16; --bit) {   // sign, exponent and 7 mantissa bits: the bound is within 0.8 %
-                    const unsigned t = prefix | ((1u << bit) - 1u);
-                    const int c = __popcll(__ballot(m1 <= t)) + __popcll(__ballot(m2 <= t));
-                    if (c < KK) prefix |= 1u << bit;
-                }
-                tau = prefix | 0xFFFFu;
+            for (int s = 0; s < KS; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[0][QAL ? 0 : s], bt[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[QAL ? 0 : 1][QAL ? 0 : s], bt[s], acc1, 0, 0, 0);
             }
-            const float tau_f = tau >= 0xFF800000u ? INFINITY : o2f(tau);   // keys above +inf are NaN patterns
-            // compact the survivors behind the carried list: per-lane count, wave prefix sum, per-lane stores
-            if (lane < cc) sv[lane] = carry[qi * CK + lane];
-            int mine = 0;
-#pragma unroll
-            for (int e = 0; e < VPL; ++e) {
-                const int j = c0 + (e >> 2) * 256 + 4 * lane + (e & 3);
-                mine += (v[e] <= tau_f && j < N) ? 1 : 0;
-            }
-            const int incl = wave_incl_scan(mine, lane);
-            const int total = cc + __builtin_amdgcn_readlane(incl, 63);
-            if (total <= SURV) {
-                int pos = cc + incl - mine;
-#pragma unroll
-                for (int e = 0; e < VPL; ++e) {
-                    const int j = c0 + (e >> 2) * 256 + 4 * lane + (e & 3);
-                    if (v[e] <= tau_f && j < N) sv[pos++] = ((u64)f2o(v[e]) << 32) | (unsigned)j;
-                }
-            }
-            if (total <= SURV) {
-                __builtin_amdgcn_wave_barrier();
-                // rank of every entry among the `total` entries (distinct keys: the index is part of the key); rank < K goes
-                // to slot `rank`.  sv[0..cc) is the carried best list, ascending, so only the NEW survivors sv[cc..total) are
-                // counted by looping (LDS broadcast reads); against the sorted prefix a carried entry knows its rank (its
-                // position) and a survivor finds it with a 7-step binary search.
-                auto prefix_rank = [&](int i, u64 e) {
-                    if (i < cc) return i;
-                    int lo = 0;
-#pragma unroll
-                    for (int step = 64; step >= 1; step >>= 1) {
-                        const int m = lo + step;
-                        if (m <= cc && sv[m - 1] < e) lo = m;
-                    }
-                    return lo;
-                };
-                const u64 e0 = lane < total ? sv[lane] : ~0ull;
-                int r0 = 0;
-                if (SURV <= 64 || total <= 64) {   // the usual case: one entry per lane
-#pragma unroll 8
-                    for (int t = cc; t < total; ++t) r0 += sv[t] < e0 ? 1 : 0;   // same address in every lane
-                    r0 += prefix_rank(lane, e0);
-                    if (lane < total && r0 < KK) carry[qi * CK + r0] = e0;
-                } else {
-                    const u64 e1 = (64 + lane) < total ? sv[(64 + lane) % SURV] : ~0ull;
-                    int r1 = 0;
-#pragma unroll 8
-                    for (int t = cc; t < total; ++t) {
-                        const u64 xk = sv[t];
-                        r0 += xk < e0 ? 1 : 0;
-                        r1 += xk < e1 ? 1 : 0;
-                    }
-                    r0 += prefix_rank(lane, e0);
-                    r1 += prefix_rank(64 + lane, e1);
-                    if (lane < total && r0 < KK) carry[qi * CK + r0] = e0;
-                    if ((64 + lane) < total && r1 < KK) carry[qi * CK + r1] = e1;
-                }
-                __builtin_amdgcn_wave_barrier();
-            } else {
-                // slow exact path (massive ties): KK rounds of wave arg-min over the 16 row values + carried entry
-                u64 mykeys[VPL + 1];
-#pragma unroll
-                for (int e = 0; e < VPL; ++e) {
-                    const int j = c0 + (e >> 2) * 256 + 4 * lane + (e & 3);
-                    mykeys[e] = (v[e] <= tau_f && j < N) ? (((u64)f2o(v[e]) << 32) | (unsigned)j) : ~0ull;
-                }
-                mykeys[VPL] = lane < cc ? carry[qi * CK + lane] : ~0ull;
-                for (int r = 0; r < KK; ++r) {
-                    u64 best = mykeys[0];
-#pragma unroll
-                    for (int e = 1; e <= VPL; ++e) best = mykeys[e] < best ? mykeys[e] : best;
-#pragma unroll
-                    for (int off = 32; off >= 1; off >>= 1) {
-                        const u64 o = __shfl_xor(best, off);
-                        best = o < best ? o : best;
-                    }
-#pragma unroll
-                    for (int e = 0; e <= VPL; ++e) mykeys[e] = mykeys[e] == best ? ~0ull : mykeys[e];
-                    if (lane == 0) carry[qi * CK + r] = best;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (lane == 0) ccount[qi] = min(total, KK);
         }
-        __syncthreads();  // rows are rewritten by the next chunk; carry/ccount visible
+    };
+    // tile tl of the chunk at c0: distances into the LDS block
+    auto tile = [&](const float (&bt)[KS], float xc, int c0, int tl) {
+        float *dst = rows + (l4 * 4) * STRIDE + tl * 16 + l15;
+        if (c0 + tl * 16 >= N || (flags & 512)) {   // tile beyond the cloud (wave-uniform): nothing to compute
+                                                    // (flag 512: timing ablation of phase A)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) dst[((r >> 2) * 16 + (r & 3)) * STRIDE] = INFINITY;
+            return;
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        mma(bt, acc0, acc1);
+        const int drel = c0 + tl * 16 - q0;   // wave-uniform: columns drel .. drel+15 against the rows 0 .. 31
+        if ((fix_diag && drel > -16 && drel < QB) || c0 + tl * 16 + 16 > N) {
+            const int jc = c0 + tl * 16 + l15;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const f32x4 acc = blk ? acc1 : acc0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int qr = blk * 16 + l4 * 4 + e;
+                    const float tt = xxq[blk][e] - 2.0f * acc[e];
+                    float d = tt + xc;
+                    if (fix_diag && jc == q0 + qr) d = 0.f;
+                    if (jc >= N) d = INFINITY;
+                    dst[(blk * 16 + e) * STRIDE] = d;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const f32x4 acc = blk ? acc1 : acc0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float tt = xxq[blk][e] - 2.0f * acc[e];
+                    dst[(blk * 16 + e) * STRIDE] = tt + xc;
+                }
+            }
+        }
+    };
+    // STREAM, epochs after the first chunk: the same products, but each distance is only compared with its row's tau;
+    // survivors go to the row's list (slot = LDS atomic on the row's counter; entries beyond LCAP are dropped and the
+    // epoch is redone through the distance block)
+    float tq[2][4];
+    auto ftile = [&](const float (&bt)[KS], float xc, int c0, int tl) {
+        if (c0 + tl * 16 >= N) return;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        mma(bt, acc0, acc1);
+        const int jc = c0 + tl * 16 + l15;
+        const int drel = c0 + tl * 16 - q0;
+        const bool special = (fix_diag && drel > -16 && drel < QB) || c0 + tl * 16 + 16 > N;   // wave-uniform
+        float d[2][4];
+        bool any = false;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const f32x4 acc = blk ? acc1 : acc0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float tt = xxq[blk][e] - 2.0f * acc[e];
+                float dd = tt + xc;
+                if (special) {
+                    if (fix_diag && jc == q0 + blk * 16 + l4 * 4 + e) dd = 0.f;
+                    if (jc >= N) dd = INFINITY;
+                }
+                d[blk][e] = dd;
+                any |= dd <= tq[blk][e] && (!special || jc < N);
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(any) != 0) {   // late in the sweep most tiles have no survivor at all
+            int slot[2][4];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)     // all slot requests first (independent LDS atomics in flight together) ...
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    slot[blk][e] = LCAP;
+                    if (d[blk][e] <= tq[blk][e] && (!special || jc < N)) slot[blk][e] = atomicAdd(&lcount[blk * 16 + l4 * 4 + e], 1);
+                }
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)     // ... then the stores
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (slot[blk][e] < LCAP)
+                        reinterpret_cast<u64 *>(rows + (blk * 16 + l4 * 4 + e) * STRIDE)[KK + slot[blk][e]] =
+                            ((u64)f2o(d[blk][e]) << 32) | (unsigned)jc;
+        }
+    };
+
+    // Epochs.  Two-phase mode: one chunk per epoch, every chunk through the distance block (phase A) and the full
+    // selection (phase B).  STREAM: after the first chunk the epochs double (as many chunks as were seen before), so
+    // the expected number of survivors per row and epoch stays about K -- one small merge per row and epoch.
+    int done = 0;
+    while (done < nch) {
+        const bool stream_ok = STREAM && !SEG && done > 0 && !(flags & 1024);   // flag 1024: every chunk through LDS
+        // epoch length: as many chunks as were seen before (survivors per row ~ K), or more while the expected number of
+        // survivors K * span / done stays well inside the list (factor 1.5 of headroom)
+        const int span = stream_ok ? min(nch - done, done) : 1;
+        bool redo = false;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const bool fast = stream_ok && attempt == 0;
+            const int nsub = fast ? 1 : span;      // the redo walks the epoch chunk by chunk
+            for (int sub = 0; sub < nsub; ++sub) {
+                const int c0 = chunk_base(done + sub);
+                // ------------------------------------------------------------ phase A
+                if (SEG) {
+                    __syncthreads();  // qsh written (first chunk) / previous chunk's rows consumed
+                    for (int cidx = tid; cidx < CH; cidx += WAVES * 64) {
+                        const int jc = c0 + cidx;
+                        float cx = 0.f, cy = 0.f, cz = 0.f;
+                        if (jc < N) { cx = xb[3L * jc]; cy = xb[3L * jc + 1]; cz = xb[3L * jc + 2]; }
+        #pragma unroll 8
+                        for (int qr = 0; qr < QB; ++qr) {
+                            const float dx = qsh[3 * qr] - cx, dy = qsh[3 * qr + 1] - cy, dz = qsh[3 * qr + 2] - cz;
+                            const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                            rows[qr * STRIDE + cidx] = jc < N ? d : INFINITY;
+                        }
+                    }
+                }
+                // Phase A proper (every variant up to 64 channels): the wave's CH/16/WAVES tiles over two operand register sets
+                // (no copies), unconditional loads off one per-lane offset, and the diagonal / out-of-range fix-ups only in the
+                // tiles that can need them (wave-uniform tests).  The first version of this loop spent ~230 VALU issues per
+                // tile on per-load predicates, 64-bit address pairs and operand copies against 32 MFMAs (rocprofv3:
+                // SQ_INSTS_VALU 17.1 M vs SQ_INSTS_MFMA 2.1 M per launch at C=64).
+                // (Requesting the next chunk's first tile before the end-of-chunk barrier was tried: the 17 registers held
+                // across the barrier cost more in spills at 64 channels than the hidden latency returns.)
+
+                if (!SEG) {
+                    if (fast) {
+#pragma unroll
+                        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int qr = blk * 16 + l4 * 4 + e;
+                                tq[blk][e] = q0 + qr < NQ ? tauf[qr] : -INFINITY;   // rows beyond the cloud never accept
+                            }
+                    }
+                    // the wave's i-th tile of the epoch is tile T = wave + i * WAVES of the epoch's chunk sequence
+                    const int ntile = (fast ? span : 1) * TPW;
+                    auto where = [&](int i, int &cb, int &tl) {      // wave-uniform
+                        const int T = wave + i * WAVES;
+                        cb = fast ? chunk_base(done + T / TPC) : c0;
+                        tl = T % TPC;
+                    };
+                    float b0[KS], b1[KS], x0, x1;
+                    int cb0, tl0, cb1, tl1;
+                    where(0, cb0, tl0);
+                    ld(b0, x0, (unsigned)(cb0 + tl0 * 16 + l15));
+#pragma unroll 1
+                    for (int i = 0; i < ntile; i += 2) {
+                        where(i + 1, cb1, tl1);
+                        ld(b1, x1, (unsigned)(cb1 + tl1 * 16 + l15));
+                        if (fast) ftile(b0, x0, cb0, tl0); else tile(b0, x0, cb0, tl0);
+                        if (i + 2 < ntile) {
+                            where(i + 2, cb0, tl0);
+                            ld(b0, x0, (unsigned)(cb0 + tl0 * 16 + l15));
+                        }
+                        if (fast) ftile(b1, x1, cb1, tl1); else tile(b1, x1, cb1, tl1);
+                    }
+                }
+                __syncthreads();
+
+                if (fast) {
+                    // -------------------------------------------------------- streamed epoch: small merge per row, or redo
+                    const int mine_l = tid < QB ? lcount[tid] : 0;
+                    redo = __syncthreads_or(mine_l > LCAP) != 0;
+                    if (tid == 0) { KSTAT(0, 1); KSTAT(1, redo ? 1 : 0); KSTAT(5, span); }
+                    if (tid < QB) { KSTAT(2, mine_l); KSTAT(3, 1); KSTATMAX(4, mine_l); }
+                    if (redo) {
+                        if (tid < QB) lcount[tid] = 0;
+                        break;   // attempt 1 (the barrier above orders the list reads before the block is rewritten)
+                    }
+                    for (int qi = wave; qi < QB; qi += WAVES) {
+                        if (q0 + qi >= NQ || (flags & 256)) break;
+                        const int lc = lcount[qi];
+                        if (lc > 0) {
+                            u64 *sv = reinterpret_cast<u64 *>(rows + qi * STRIDE);
+                            const int cc = ccount[qi];
+                            // the survivors sit at sv[KK .. KK+lc), the carried copy goes to sv[0..cc); cc < KK (a first
+                            // chunk with fewer than KK candidates followed by a short one) leaves a gap to close
+                            u64 mv0 = 0, mv1 = 0;
+                            if (cc < KK) {
+                                if (lane < lc) mv0 = sv[KK + lane];
+                                if (64 + lane < lc) mv1 = sv[KK + 64 + lane];
+                                __builtin_amdgcn_wave_barrier();
+                                if (lane < lc) sv[cc + lane] = mv0;
+                                if (64 + lane < lc) sv[cc + 64 + lane] = mv1;
+                            }
+                            if (lane < cc) sv[lane] = carry[qi * CK + lane];
+                            __builtin_amdgcn_wave_barrier();
+                            const int total = cc + lc;
+                            rank_merge(sv, qi, cc, total);
+                            if (lane == 0) {
+                                const int ncc = min(total, KK);
+                                ccount[qi] = ncc;
+                                lcount[qi] = 0;
+                                if (ncc >= KK) tauf[qi] = o2f((unsigned)(carry[qi * CK + KK - 1] >> 32));
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    continue;
+                }
+
+                // ---------------------------------------------------------------- phase B: exact selection, one wave per row
+                for (int qi = wave; qi < QB; qi += WAVES) {
+                    if (q0 + qi >= NQ || (flags & 256)) break;  // flag 256: timing ablation of phase B
+                    const float *row = rows + qi * STRIDE;
+                    float v[VPL];
+        #pragma unroll
+                    for (int s = 0; s < VPL / 4; ++s) {
+                        const f32x4 w = *reinterpret_cast<const f32x4 *>(row + s * 256 + 4 * lane);
+        #pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * s + e] = w[e];
+                    }
+                    // the row now lives in registers: its LDS storage (4 KB, 8-byte aligned) becomes the survivor buffer of this
+                    // wave (up to SURV entries).  LDS serves a wave's instructions in order, so the reads above are ahead of every
+                    // write below; the empty asm keeps the compiler from moving a store (different type: no alias assumed) up.
+                    asm volatile("" ::: "memory");
+                    u64 *sv = reinterpret_cast<u64 *>(rows + qi * STRIDE);
+                    const int cc = ccount[qi];
+                    unsigned tau;
+                    if (cc >= KK) {
+                        tau = (unsigned)(carry[qi * CK + KK - 1] >> 32);   // K-th best so far: tighter than any chunk estimate
+                    } else {
+                        float f1 = INFINITY, f2 = INFINITY;                // two smallest values of this lane
+        #pragma unroll
+                        for (int e = 0; e < VPL; ++e) {
+                            const float hi = fmaxf(v[e], f1);
+                            f1 = fminf(v[e], f1);
+                            f2 = fminf(f2, hi);
+                        }
+                        if (lane < cc) {  // carried entries (fewer than K) also count as candidates of the bound
+                            const float cv = o2f((unsigned)(carry[qi * CK + lane] >> 32));
+                            const float hi = fmaxf(cv, f1);
+                            f1 = fminf(cv, f1);
+                            f2 = fminf(f2, hi);
+                        }
+                        const unsigned m1 = f2o(f1), m2 = f2o(f2);
+                        // upper bound of the K-th smallest of the 128 lane minima: binary search on the top 16 key bits (two
+                        // wave-wide compares + population counts per round), the 16 low bits are rounded up
+                        unsigned prefix = 0u;
+        #pragma unroll 4
+                        for (int bit = 31; bit >= 16; --bit) {   // sign, exponent and 7 mantissa bits: the bound is within 0.8 %
+                            const unsigned t = prefix | ((1u << bit) - 1u);
+                            const int c = __popcll(__ballot(m1 <= t)) + __popcll(__ballot(m2 <= t));
+                            if (c < KK) prefix |= 1u << bit;
+                        }
+                        tau = prefix | 0xFFFFu;
+                    }
+                    const float tau_f = tau >= 0xFF800000u ? INFINITY : o2f(tau);   // keys above +inf are NaN patterns
+                    // compact the survivors behind the carried list: per-lane count, wave prefix sum, per-lane stores
+                    if (lane < cc) sv[lane] = carry[qi * CK + lane];
+                    int mine = 0;
+        #pragma unroll
+                    for (int e = 0; e < VPL; ++e) {
+                        const int j = c0 + (e >> 2) * 256 + 4 * lane + (e & 3);
+                        mine += (v[e] <= tau_f && j < N) ? 1 : 0;
+                    }
+                    const int incl = wave_incl_scan(mine, lane);
+                    const int total = cc + __builtin_amdgcn_readlane(incl, 63);
+                    if (total <= SURV) {
+                        int pos = cc + incl - mine;
+        #pragma unroll
+                        for (int e = 0; e < VPL; ++e) {
+                            const int j = c0 + (e >> 2) * 256 + 4 * lane + (e & 3);
+                            if (v[e] <= tau_f && j < N) sv[pos++] = ((u64)f2o(v[e]) << 32) | (unsigned)j;
+                        }
+                    }
+                    if (total <= SURV) {
+                        rank_merge(sv, qi, cc, total);
+                    } else {
+                        // slow exact path (massive ties): KK rounds of wave arg-min over the 16 row values + carried entry
+                        u64 mykeys[VPL + 1];
+        #pragma unroll
+                        for (int e = 0; e < VPL; ++e) {
+                            const int j = c0 + (e >> 2) * 256 + 4 * lane + (e & 3);
+                            mykeys[e] = (v[e] <= tau_f && j < N) ? (((u64)f2o(v[e]) << 32) | (unsigned)j) : ~0ull;
+                        }
+                        mykeys[VPL] = lane < cc ? carry[qi * CK + lane] : ~0ull;
+                        for (int r = 0; r < KK; ++r) {
+                            u64 best = mykeys[0];
+        #pragma unroll
+                            for (int e = 1; e <= VPL; ++e) best = mykeys[e] < best ? mykeys[e] : best;
+        #pragma unroll
+                            for (int off = 32; off >= 1; off >>= 1) {
+                                const u64 o = __shfl_xor(best, off);
+                                best = o < best ? o : best;
+                            }
+        #pragma unroll
+                            for (int e = 0; e <= VPL; ++e) mykeys[e] = mykeys[e] == best ? ~0ull : mykeys[e];
+                            if (lane == 0) carry[qi * CK + r] = best;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) {
+                        const int ncc = min(total, KK);
+                        ccount[qi] = ncc;
+                        if (STREAM && ncc >= KK) tauf[qi] = o2f((unsigned)(carry[qi * CK + KK - 1] >> 32));
+                    }
+                }
+
+                __syncthreads();  // rows are rewritten by the next chunk; carry/ccount visible
+            }
+            if (!redo || attempt == 1) break;
+        }
+        done += span;
     }
     // ---------------------------------------------------------------- output: rank r of row qi -> lane r
     for (int qi = wave; qi < QB; qi += WAVES) {
@@ -495,21 +676,22 @@ int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int
                        (long)stride_c, c_knn, xx_scratch);
     FSG_CHECK_LAUNCH("fsg_knn_dense_f32/sqnorm");
     dim3 grid(fsg_cdiv(N, QB), B);
-#define FSG_KNN_RM(KS, WV, SV, CHK, CKK) FSG_KNN_RMQ(KS, WV, SV, CHK, CKK, false)
-#define FSG_KNN_RMQ(KS, WV, SV, CHK, CKK, QL)                                                                          \
+#define FSG_KNN_RM(KS, WV, SV, CHK, CKK) FSG_KNN_RMQS(KS, WV, SV, CHK, CKK, false, false)
+#define FSG_KNN_RMQ(KS, WV, SV, CHK, CKK, QL) FSG_KNN_RMQS(KS, WV, SV, CHK, CKK, QL, false)
+#define FSG_KNN_RMQS(KS, WV, SV, CHK, CKK, QL, STRM)                                                                   \
     do {                                                                                                               \
         const size_t lds = sizeof(float) * QB * ((CHK) + 4) + sizeof(u64) * (QB * (CKK)) + sizeof(int) * QB +           \
-                           ((QL) ? sizeof(float) * 4 * (KS) * QB : 0);                                                 \
+                           ((QL) ? sizeof(float) * 4 * (KS) * QB : 0) + ((STRM) ? 2 * sizeof(int) * QB : 0);           \
         static bool granted = false;                                                                                   \
         if (!granted) {                                                                                                \
-            if (hipFuncSetAttribute((const void *)knn_rows_mfma_kernel<KS, WV, SV, CHK, CKK, false, QL>,               \
+            if (hipFuncSetAttribute((const void *)knn_rows_mfma_kernel<KS, WV, SV, CHK, CKK, false, QL, STRM>,         \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {             \
                 fsg_set_error("fsg_knn_dense_f32: cannot raise dynamic LDS to %zu", lds);                              \
                 return FSG_ERR_HIP;                                                                                    \
             }                                                                                                          \
             granted = true;                                                                                            \
         }                                                                                                              \
-        hipLaunchKernelGGL((knn_rows_mfma_kernel<KS, WV, SV, CHK, CKK, false, QL>), grid, dim3((WV) * 64), lds, st, x,      \
+        hipLaunchKernelGGL((knn_rows_mfma_kernel<KS, WV, SV, CHK, CKK, false, QL, STRM>), grid, dim3((WV) * 64), lds, st, x, \
                            xx_scratch, N,                                                                              \
                            (long)stride_b, (long)stride_c, c_knn, k, flags, idx_out, dist_out, SegArgs{});             \
     } while (0)
@@ -519,6 +701,20 @@ int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int
     const bool half = small_k && (flags & 2048);
     // 16 waves per workgroup wherever the registers allow (both phases are latency-bound); flag 8192: the 8-wave variants
     const bool w8 = (flags & 8192) != 0;
+    // streamed selection (STREAM = true, 512-candidate chunks, 16 waves): the default; flag 131072 = the two-phase kernel
+    // over 1024-candidate chunks for every chunk (A/B timing, tests)
+    if ((flags & 262144) && c_knn > 16 && c_knn <= 64 && small_k) {   // experiment: two 8-wave workgroups per CU, 256-candidate chunks
+        FSG_KNN_RMQS(16, 8, 128, 256, 32, true, true);
+        FSG_CHECK_LAUNCH("fsg_knn_dense_f32/rows_mfma_stream8");
+        return FSG_OK;
+    }
+    if (!(flags & (131072 | 8192 | 2048)) && c_knn <= 64) {
+        if (c_knn <= 4) { if (small_k) FSG_KNN_RMQS(1, 16, 128, 512, 32, false, true); else FSG_KNN_RMQS(1, 16, 128, 512, 64, false, true); }
+        else if (c_knn <= 16) { if (small_k) FSG_KNN_RMQS(4, 16, 128, 512, 32, false, true); else FSG_KNN_RMQS(4, 16, 128, 512, 64, false, true); }
+        else { if (small_k) FSG_KNN_RMQS(16, 16, 128, 512, 32, true, true); else FSG_KNN_RMQS(16, 16, 128, 512, 64, true, true); }
+        FSG_CHECK_LAUNCH("fsg_knn_dense_f32/rows_mfma_stream");
+        return FSG_OK;
+    }
     if (c_knn <= 4) { if (!w8) FSG_KNN_RM(1, 16, 128, 1024, 64); else FSG_KNN_RM(1, 8, 128, 1024, 64); }
     else if (c_knn <= 16) { if (!w8) FSG_KNN_RM(4, 16, 128, 1024, 64); else FSG_KNN_RM(4, 8, 128, 1024, 64); }
     else if (c_knn <= 64) {
@@ -534,6 +730,7 @@ int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int
     }
 #undef FSG_KNN_RM
 #undef FSG_KNN_RMQ
+#undef FSG_KNN_RMQS
     FSG_CHECK_LAUNCH("fsg_knn_dense_f32/rows_mfma");
     return FSG_OK;
 }

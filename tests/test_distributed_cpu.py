@@ -111,3 +111,67 @@ def test_gloo_world2_finish_without_zero_grad_between_steps():
     for step in range(3):
         for i in range(nparam):                       # mean over ranks of (rank+1)(step+1) + i
             assert abs(out[0][step][i] - (1.5 * (step + 1) + i)) < 1e-6, (step, i, out[0][step][i])
+
+
+def _worker_flat(rank, world, port, out):
+    """the flat scheme of bench.py at N > 1 (`--grad-sync flat`): backward -> FlatAdam.gather_grads() -> ONE in-place
+    all-reduce of the flat gradient buffer -> scale by 1/world -> FlatAdam.step_flat(); the buffer is the optimizer's own,
+    allocated once, never copied back into the .grad tensors"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from fissure_segmentation_amd import distributed as D
+    from fissure_segmentation_amd.optim import FlatAdam
+    D.init_from_env(backend="gloo")
+    torch.manual_seed(100 + rank)
+    model = _net()
+    D.broadcast_parameters(model)
+    opt = FlatAdam(model.parameters(), lr=1e-2)
+    ptr = opt.flat.grad.data_ptr()
+    torch.manual_seed(7)
+    x = torch.randn(6, 3, 32)
+    lo, hi = D.shard_batch(6, rank, world)
+    grads = []
+    for _ in range(3):
+        opt.zero_grad()
+        model(x[lo:hi]).square().mean().backward()
+        opt.gather_grads()
+        dist.all_reduce(opt.flat.grad, op=dist.ReduceOp.SUM)
+        opt.flat.grad.mul_(1.0 / world)
+        grads.append(opt.flat.grad.clone())
+        opt.step_flat()
+        assert opt.flat.grad.data_ptr() == ptr
+    out[rank] = {"w": [p.detach().clone() for p in model.parameters()], "g": grads}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_flat_gradient_allreduce_in_place():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_flat, args=(world, port, out), nprocs=world, join=True)
+    for wa, wb in zip(out[0]["w"], out[1]["w"]):
+        assert torch.equal(wa, wb)                    # replicas stay identical through three optimizer steps
+    # serial reference: mean of the two shard gradients, torch.optim.Adam over the separate tensors
+    torch.manual_seed(100)
+    ref = _net()
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    twin = _net()
+    torch.manual_seed(7)
+    x = torch.randn(6, 3, 32)
+    for step in range(3):
+        shard_grads = []
+        for lo, hi in ((0, 3), (3, 6)):
+            twin.load_state_dict(ref.state_dict())    # BatchNorm running stats are per replica; the gradients do not read them
+            twin.zero_grad()
+            twin(x[lo:hi]).square().mean().backward()
+            shard_grads.append(torch.cat([p.grad.reshape(-1) for p in twin.parameters()]))
+        mean = (shard_grads[0] + shard_grads[1]) / 2
+        torch.testing.assert_close(out[0]["g"][step], mean, rtol=1e-5, atol=1e-7)
+        off = 0
+        for p in ref.parameters():
+            p.grad = mean[off:off + p.numel()].view_as(p).clone()
+            off += p.numel()
+        opt.step()
+    for wa, p in zip(out[0]["w"], ref.parameters()):
+        torch.testing.assert_close(wa, p.detach(), rtol=1e-4, atol=1e-6)

@@ -1935,3 +1935,20 @@ def test_bench_two_rank_rehearsal_averages_the_shard_gradients(fsg, device, tmp_
     err = np.linalg.norm(got - want) / np.linalg.norm(want)
     print("\\nDDP rehearsal: averaged gradient vs oracle mean of shards, rel L2 =", err)
     assert err <= 1e-2      # the oracle builds its own dynamic graphs here: ~1e-4 of the rows pick another k-th neighbour
+
+
+@pytest.mark.parametrize("B,C,Np,k,flags", [(2, 64, 2048, 20, 131072), (1, 3, 1700, 40, 131072), (2, 16, 520, 20, 131072),
+                                            (1, 64, 2048, 20, 131072 + 1024), (2, 64, 1100, 20, 262144), (1, 5, 300, 8, 131072)])
+def test_knn_streamed_variant_bit_exact(fsg, device, B, C, Np, k, flags):
+    """the opt-in streamed kernel (first chunk through the LDS block, later chunks filtered against tau on the accumulators,
+    overflowing epochs redone): same indices and distance bits as the C oracle, incl. a cloud whose last chunk is 8 points"""
+    x = cloud(900 + Np + C, B, C, Np)
+    idx, dist = fsg.functional.knn_graph(G(x, device), k, return_dist=True, _debug_flags=flags)
+    idx_o, dist_o = c_api.knn_dense(x, k, fix_diag=True)
+    assert np.array_equal(N(idx), idx_o)
+    assert np.array_equal(N(dist).view(np.int32), dist_o.view(np.int32))
+    # massive ties: every streamed epoch overflows and is redone through the distance block
+    xt = np.zeros((1, C, Np), np.float32)
+    xt[0, 0] = np.arange(Np) % 7
+    idx = fsg.functional.knn_graph(G(xt, device), k, _debug_flags=flags)
+    assert np.array_equal(N(idx), c_api.knn_dense(xt, k, fix_diag=True)[0])

@@ -1,13 +1,14 @@
 """Phase split / A-B switches of the production kNN kernel at the BASELINE shapes.  Variants are timed round-robin (five
 rounds of 20 launches each, best median) so that clock ramp-up does not favour whichever variant runs last.
-flags: 256 no phase B, 512 no phase A, 65536 plain (not XCD-aware) workgroup placement."""
+flags: 256 no phase B, 512 no phase A, 131072 the streamed kernel (filter on the accumulators after the first chunk), +1024 with every
+chunk through the LDS block, 262144 two 8-wave streamed workgroups per CU, 65536 plain (not XCD-aware) workgroup placement."""
 import sys, torch, numpy as np
 sys.path[:0] = ["/root/repo", "/root/repo/tests"]
 import fissure_segmentation_amd as fsg
 from golden_util import cloud
 F = fsg.functional
 dev = torch.device("cuda:0")
-VARIANTS = (("full", 0), ("noB", 256), ("neither", 768), ("half-chunks", 2048), ("8-wave", 8192))
+VARIANTS = (("two-phase", 0), ("tp-noB", 256), ("tp-neither", 768), ("stream", 131072), ("stream-allLDS", 131072 + 1024), ("stream8x2", 262144))
 def med(fn, n=20):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ts = []
