@@ -519,6 +519,8 @@ __global__ __launch_bounds__(WAVES * 64, (STREAM && WAVES == 8) ? 4 : 1) void kn
                     continue;
                 }
 
+                // (Two rows per wave at once -- two interleaved dependency chains -- was measured: 88.9 vs 90.4 us at N=2048,
+                // 560 vs 543 us at N=8192 k=40: the selection is not bound by the latency of one chain.)
                 // ---------------------------------------------------------------- phase B: exact selection, one wave per row
                 for (int qi = wave; qi < QB; qi += WAVES) {
                     if (q0 + qi >= NQ || (flags & 256)) break;  // flag 256: timing ablation of phase B
@@ -617,7 +619,6 @@ __global__ __launch_bounds__(WAVES * 64, (STREAM && WAVES == 8) ? 4 : 1) void kn
                         if (STREAM && ncc >= KK) tauf[qi] = o2f((unsigned)(carry[qi * CK + KK - 1] >> 32));
                     }
                 }
-
                 __syncthreads();  // rows are rewritten by the next chunk; carry/ccount visible
             }
             if (!redo || attempt == 1) break;
@@ -701,14 +702,16 @@ int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int
     const bool half = small_k && (flags & 2048);
     // 16 waves per workgroup wherever the registers allow (both phases are latency-bound); flag 8192: the 8-wave variants
     const bool w8 = (flags & 8192) != 0;
-    // streamed selection (STREAM = true, 512-candidate chunks, 16 waves): the default; flag 131072 = the two-phase kernel
-    // over 1024-candidate chunks for every chunk (A/B timing, tests)
-    if ((flags & 262144) && c_knn > 16 && c_knn <= 64 && small_k) {   // experiment: two 8-wave workgroups per CU, 256-candidate chunks
-        FSG_KNN_RMQS(16, 8, 128, 256, 32, true, true);
-        FSG_CHECK_LAUNCH("fsg_knn_dense_f32/rows_mfma_stream8");
-        return FSG_OK;
-    }
-    if (!(flags & (131072 | 8192 | 2048)) && c_knn <= 64) {
+    // streamed selection (STREAM = true, 512-candidate chunks, 16 waves), flag 131072.  Exact (same parity suite) but
+    // MEASURED SLOWER than the two-phase kernel and therefore opt-in: B=8 N=2048 k=20 C=64 101 vs 88 us, C=3 70 vs 52 us;
+    // B=4 N=8192 k=40 C=64 567 vs 542 us (tools/knn_ablate_phases.py, eager timing incl. the squared-norm launch).  What the
+    // instrumented build (-DFSG_KNN_STATS, tools/knn_stream_stats.py) shows: the filter works as designed -- 57 survivors
+    // per row for a 1536-candidate epoch (expected 60), 3.7 % of the workgroups redo an epoch -- but a streamed epoch costs
+    // as much as the distance block + full selection it replaces: with 2-6 tiles per wave and epoch the operand-load
+    // latency, the two barriers and the rank-by-counting merge (which dominates the selection either way) are all exposed,
+    // and 512-candidate chunks are 14 us slower than 1024-candidate ones for the same reason.  Two co-resident 8-wave
+    // workgroups per CU (flag 262144: 256-candidate first chunk, 50 KB of LDS, 101 VGPRs) change nothing: 101 us.
+    if ((flags & 131072) && !(flags & (8192 | 2048)) && c_knn <= 64) {
         if (c_knn <= 4) { if (small_k) FSG_KNN_RMQS(1, 16, 128, 512, 32, false, true); else FSG_KNN_RMQS(1, 16, 128, 512, 64, false, true); }
         else if (c_knn <= 16) { if (small_k) FSG_KNN_RMQS(4, 16, 128, 512, 32, false, true); else FSG_KNN_RMQS(4, 16, 128, 512, 64, false, true); }
         else { if (small_k) FSG_KNN_RMQS(16, 16, 128, 512, 32, true, true); else FSG_KNN_RMQS(16, 16, 128, 512, 64, true, true); }
