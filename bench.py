@@ -151,6 +151,9 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inputs", default="uniform", choices=["uniform", "surface"], help="synthetic input set (SURVEY 8d)")
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
+                    help="MFMA operand type of the dense contractions (functional.set_mfma_operands); default: what "
+                         "BASELINE.json names for the workload -- fp32 for config 2, bf16 for configs 3, 4, 5")
     ap.add_argument("--min-seconds", type=float, default=3.0,
                     help="repeat the timed block of --steps steps until the GPU has been busy this long; the MEDIAN block is "
                          "reported (ms_per_step, value), every block is bracketed by barrier + synchronize")
@@ -173,6 +176,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     B, N, k, desc = WORKLOADS[args.workload]
     classes = 4
+    dtype = args.dtype or ("f32" if args.workload in ("c2", "c2s") else "bf16")
+    fsg.functional.set_mfma_operands(dtype)      # graph build, BatchNorm statistics and stored tensors stay fp32 either way
+    desc = desc.replace("fp32", "bf16 MFMA operands" if dtype == "bf16" else "fp32")
 
     torch.manual_seed(0)
     dgcnn = args.workload in ("c2", "c4", "c2s")
@@ -478,11 +484,13 @@ def main():
                             "algorithmic_bytes_per_step": bytes_bwd, "us_per_step": round(1e6 * t_step, 1),
                             "launches_per_step": len(calls) / n_timed,
                             "note": "the layer is latency-bound at these sizes (levels 3-5 hold 1024 / 256 / 64 points)"}
-        dtype = "f32"
         out = {"metric": METRIC[args.workload], "value": round(B * N * world * args.steps / elapsed, 1),
                "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+               "precision": ("fp32 everywhere" if dtype == "f32" else
+                             "bf16 operands / fp32 accumulation in the per-edge EdgeConv contraction (v_mfma_f32_32x32x16_bf16) and "
+                             "the vendor GEMMs; graph build, BatchNorm statistics, stored activations and gradients fp32"),
                "config": {"workload": desc, "clouds_per_gpu": B, "points_per_cloud": N, "k": k, "inputs": args.inputs,
                           "global_batch": B * world, "step": "fwd + (cross-entropy + generalised Dice) + bwd + grad all-reduce + Adam",
                           "launch": launch, "optimizer": "torch.optim.Adam(fused)" if args.torch_adam else

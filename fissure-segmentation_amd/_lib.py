@@ -22,6 +22,8 @@ SIGNATURES = {
     "fsg_knn_dense_f32": ([_P, _I, _I, _L, _L, _I, _I, _I, _P, _P, _P, _P], _I),
     "fsg_edge_gather_fwd_f32": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
     "fsg_edge_gather_bwd_f32": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "fsg_edge_gather_fwd_bf16": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "fsg_edge_gather_bwd_bf16": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
     "fsg_graph_reverse_csr_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),
     "fsg_graph_reverse_csr": ([_P, _I, _I, _I, _P, _P, _P, _P], _I),
     "fsg_edge_weights_fwd_f32": ([_P, _I, _I, _P, _P], _I),
@@ -36,6 +38,8 @@ SIGNATURES = {
     "fsg_edgeconv2_bwd_workspace_bytes": ([_I, _I, _I, _I], ctypes.c_size_t),
     "fsg_edgeconv2_fwd_f32": ([_P] * 11 + [_I] * 5 + [_F] * 5 + [_P] * 12, _I),
     "fsg_edgeconv2_bwd_f32": ([_P, _P, _L, _P, _L] + [_P] * 16 + [_I] * 5 + [_F] + [_P] * 8, _I),
+    "fsg_edgeconv2_fwd_bf16": ([_P] * 11 + [_I] * 5 + [_F] * 5 + [_P] * 12, _I),
+    "fsg_edgeconv2_bwd_bf16": ([_P, _P, _L, _P, _L] + [_P] * 16 + [_I] * 5 + [_F] + [_P] * 8, _I),
     "fsg_bn_act_workspace_bytes": ([ctypes.c_long, _I], ctypes.c_size_t),
     "fsg_bn_act_fwd_f32": ([_P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P], _I),
     "fsg_bn_act_bwd_f32": ([_P, _P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _F, _P, _P, _P, _P, _P], _I),

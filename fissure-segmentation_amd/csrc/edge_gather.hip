@@ -12,8 +12,10 @@ namespace {
 constexpr int BLOCK = 256;
 constexpr int CCHUNK = 8;  // channels per workgroup: amortises the idx load, keeps the grid large
 
-__global__ __launch_bounds__(BLOCK) void edge_fwd_kernel(const float *__restrict__ x, const int32_t *__restrict__ idx,
-                                                          float *__restrict__ edge, int C, int N, int k) {
+// T = float or __bf16 (storage type of x / edge; the subtraction is done in fp32 and rounded once)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void edge_fwd_kernel(const T *__restrict__ x, const int32_t *__restrict__ idx,
+                                                          T *__restrict__ edge, int C, int N, int k) {
     const int b = blockIdx.z;
     const int c0 = blockIdx.y * CCHUNK;
     const long NK = (long)N * k;
@@ -21,19 +23,20 @@ __global__ __launch_bounds__(BLOCK) void edge_fwd_kernel(const float *__restrict
     if (e >= NK) return;
     const int i = (int)(e / k);
     const int j = idx[(long)b * NK + e];
-    const float *xb = x + (long)b * C * N;
-    float *rel = edge + (long)b * 2 * C * NK + e;
+    const T *xb = x + (long)b * C * N;
+    T *rel = edge + (long)b * 2 * C * NK + e;
     const int cend = min(c0 + CCHUNK, C);
     for (int c = c0; c < cend; ++c) {
-        const float xi = xb[(long)c * N + i];
-        const float xj = xb[(long)c * N + j];
-        rel[(long)c * NK] = xj - xi;
-        rel[(long)(C + c) * NK] = xi;
+        const float xi = (float)xb[(long)c * N + i];
+        const float xj = (float)xb[(long)c * N + j];
+        rel[(long)c * NK] = (T)(xj - xi);
+        rel[(long)(C + c) * NK] = (T)xi;
     }
 }
 
 // grad_x[b,c,i] += sum_s (g_ctr - g_rel)[b,c,i,s] ; grad_x[b,c,idx[b,i,s]] += g_rel[b,c,i,s]
-__global__ __launch_bounds__(BLOCK) void edge_bwd_kernel(const float *__restrict__ g, const int32_t *__restrict__ idx,
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void edge_bwd_kernel(const T *__restrict__ g, const int32_t *__restrict__ idx,
                                                           float *__restrict__ gx, int C, int N, int k) {
     const int b = blockIdx.z;
     const int c0 = blockIdx.y * CCHUNK;
@@ -43,11 +46,11 @@ __global__ __launch_bounds__(BLOCK) void edge_bwd_kernel(const float *__restrict
     const int i = (int)(e / k);
     const int j = idx[(long)b * NK + e];
     float *gxb = gx + (long)b * C * N;
-    const float *gr = g + (long)b * 2 * C * NK + e;
+    const T *gr = g + (long)b * 2 * C * NK + e;
     const int cend = min(c0 + CCHUNK, C);
     for (int c = c0; c < cend; ++c) {
-        const float r = gr[(long)c * NK];
-        const float ct = gr[(long)(C + c) * NK];
+        const float r = (float)gr[(long)c * NK];
+        const float ct = (float)gr[(long)(C + c) * NK];
         atomicAdd(gxb + (long)c * N + j, r);
         atomicAdd(gxb + (long)c * N + i, ct - r);
     }
@@ -62,7 +65,7 @@ extern "C" int fsg_edge_gather_fwd_f32(const float *x, const int32_t *idx, float
     FSG_REQUIRE(B <= 65535 && fsg_cdiv(C, CCHUNK) <= 65535, "fsg_edge_gather_fwd_f32: grid too large");
     if (B == 0) return FSG_OK;
     dim3 grid(fsg_cdiv((long)N * k, BLOCK), fsg_cdiv(C, CCHUNK), B);
-    hipLaunchKernelGGL(edge_fwd_kernel, grid, dim3(BLOCK), 0, (hipStream_t)stream, x, idx, edge, C, N, k);
+    hipLaunchKernelGGL(edge_fwd_kernel<float>, grid, dim3(BLOCK), 0, (hipStream_t)stream, x, idx, edge, C, N, k);
     FSG_CHECK_LAUNCH("fsg_edge_gather_fwd_f32");
     return FSG_OK;
 }
@@ -79,7 +82,40 @@ extern "C" int fsg_edge_gather_bwd_f32(const float *grad_edge, const int32_t *id
         return FSG_ERR_HIP;
     }
     dim3 grid(fsg_cdiv((long)N * k, BLOCK), fsg_cdiv(C, CCHUNK), B);
-    hipLaunchKernelGGL(edge_bwd_kernel, grid, dim3(BLOCK), 0, st, grad_edge, idx, grad_x, C, N, k);
+    hipLaunchKernelGGL(edge_bwd_kernel<float>, grid, dim3(BLOCK), 0, st, grad_edge, idx, grad_x, C, N, k);
     FSG_CHECK_LAUNCH("fsg_edge_gather_bwd_f32");
+    return FSG_OK;
+}
+
+// bf16 storage (fsg_edge_gather_{fwd,bwd}_bf16; 8d: s = 2 bytes per feature element): x and edge are bf16, the
+// difference is formed in fp32 and rounded once; the backward reads a bf16 grad_edge and accumulates grad_x in FP32
+// (hardware fp32 atomics; there is no bf16 atomic add) -- the caller rounds it to the leaf's type.
+extern "C" int fsg_edge_gather_fwd_bf16(const void *x, const int32_t *idx, void *edge, int B, int C, int N, int k,
+                                        fsg_stream_t stream) {
+    FSG_REQUIRE(x && idx && edge, "fsg_edge_gather_fwd_bf16: NULL pointer");
+    FSG_REQUIRE(B >= 0 && C > 0 && N > 0 && k > 0, "fsg_edge_gather_fwd_bf16: bad shape");
+    FSG_REQUIRE(B <= 65535 && fsg_cdiv(C, CCHUNK) <= 65535, "fsg_edge_gather_fwd_bf16: grid too large");
+    if (B == 0) return FSG_OK;
+    dim3 grid(fsg_cdiv((long)N * k, BLOCK), fsg_cdiv(C, CCHUNK), B);
+    hipLaunchKernelGGL(edge_fwd_kernel<__bf16>, grid, dim3(BLOCK), 0, (hipStream_t)stream, (const __bf16 *)x, idx,
+                       (__bf16 *)edge, C, N, k);
+    FSG_CHECK_LAUNCH("fsg_edge_gather_fwd_bf16");
+    return FSG_OK;
+}
+
+extern "C" int fsg_edge_gather_bwd_bf16(const void *grad_edge, const int32_t *idx, float *grad_x, int B, int C, int N,
+                                        int k, fsg_stream_t stream) {
+    FSG_REQUIRE(grad_edge && idx && grad_x, "fsg_edge_gather_bwd_bf16: NULL pointer");
+    FSG_REQUIRE(B >= 0 && C > 0 && N > 0 && k > 0, "fsg_edge_gather_bwd_bf16: bad shape");
+    FSG_REQUIRE(B <= 65535 && fsg_cdiv(C, CCHUNK) <= 65535, "fsg_edge_gather_bwd_bf16: grid too large");
+    if (B == 0) return FSG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)B * C * N, st) != hipSuccess) {
+        fsg_set_error("fsg_edge_gather_bwd_bf16: memset failed");
+        return FSG_ERR_HIP;
+    }
+    dim3 grid(fsg_cdiv((long)N * k, BLOCK), fsg_cdiv(C, CCHUNK), B);
+    hipLaunchKernelGGL(edge_bwd_kernel<__bf16>, grid, dim3(BLOCK), 0, st, (const __bf16 *)grad_edge, idx, grad_x, C, N, k);
+    FSG_CHECK_LAUNCH("fsg_edge_gather_bwd_bf16");
     return FSG_OK;
 }

@@ -23,6 +23,18 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// bf16 operand mode (fsg_edgeconv2_{fwd,bwd}_bf16): the per-edge products run on v_mfma_f32_32x32x16_bf16 -- operands
+// rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) on their way out of LDS, fp32 accumulation, everything else
+// (gathers, BatchNorm statistics, selection, stored tensors) unchanged in fp32.  Lane (ql = lane % 32, half = lane / 32)
+// holds the eight k-values 16 s + 8 half + 0..7 of K-block s for row / column ql of both operands.
+__device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (__bf16)v[i];
+    return r;
+}
 
 constexpr int C1 = 64;          // width of the first layer (all reference configurations)
 constexpr int LD1 = C1 + 1;     // padded LDS row: column reads by 32 lanes hit 32 banks
@@ -57,7 +69,7 @@ struct Tile {
 };
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int C2>
+template <int C2, bool BF>
 __global__ __launch_bounds__(256) void ec2_fwd_kernel(const float *__restrict__ pq, const int32_t *__restrict__ idx,
                                                        const float *__restrict__ w2, const float *__restrict__ gamma1,
                                                        const float *__restrict__ beta1, const float *__restrict__ mean1,
@@ -142,9 +154,22 @@ __global__ __launch_bounds__(256) void ec2_fwd_kernel(const float *__restrict__ 
                 const int rt = pr / CT, ct = pr - rt * CT;
                 const float *yrow = Y + (rt * 32 + ql) * LD1 + half;
                 const float *wrow = W + (ct * 32 + ql) * LD1 + half;
+                if (BF) {
+#pragma unroll
+                    for (int s = 0; s < C1 / 16; ++s) {
+                        float a[8], w[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            a[i] = yrow[16 * s + 7 * half + i];     // (yrow already carries + half)
+                            w[i] = wrow[16 * s + 7 * half + i];
+                        }
+                        acc[pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(a), pack8(w), acc[pi], 0, 0, 0);
+                    }
+                } else {
 #pragma unroll 8
-                for (int s = 0; s < C1 / 2; ++s)
-                    acc[pi] = __builtin_amdgcn_mfma_f32_32x32x2f32(yrow[2 * s], wrow[2 * s], acc[pi], 0, 0, 0);
+                    for (int s = 0; s < C1 / 2; ++s)
+                        acc[pi] = __builtin_amdgcn_mfma_f32_32x32x2f32(yrow[2 * s], wrow[2 * s], acc[pi], 0, 0, 0);
+                }
             }
         }
         __syncthreads();  // every wave is done reading z1
@@ -225,7 +250,7 @@ __global__ __launch_bounds__(256) void ec2_fwd_kernel(const float *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-template <int C2>
+template <int C2, bool BF>
 __global__ __launch_bounds__(256) void ec2_bwd_kernel(
     const float *__restrict__ pq, const int32_t *__restrict__ idx, const float *__restrict__ w2,
     const float *__restrict__ gamma1, const float *__restrict__ beta1, const float *__restrict__ mean1,
@@ -318,12 +343,27 @@ __global__ __launch_bounds__(256) void ec2_bwd_kernel(
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.f;
             const bool rowok = rt * 32 + ql < rvalid;  // padding rows must contribute z1 = 0, not f(b1)
+            if (BF) {
+#pragma unroll
+                for (int s = 0; s < C1 / 16; ++s) {
+                    float a[8], w[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int ch = 16 * s + 8 * half + i;
+                        const float z = lrelu(__builtin_fmaf(yrow[ch - half], A1s[ch], A1s[C1 + ch]), slope);
+                        a[i] = rowok ? z : 0.f;
+                        w[i] = wrow[ch - half];
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(a), pack8(w), acc, 0, 0, 0);
+                }
+            } else {
 #pragma unroll 8
-            for (int s = 0; s < C1 / 2; ++s) {
-                const int ch = 2 * s + half;
-                float z = lrelu(__builtin_fmaf(yrow[2 * s], A1s[ch], A1s[C1 + ch]), slope);
-                z = rowok ? z : 0.f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z, wrow[2 * s], acc, 0, 0, 0);
+                for (int s = 0; s < C1 / 2; ++s) {
+                    const int ch = 2 * s + half;
+                    float z = lrelu(__builtin_fmaf(yrow[2 * s], A1s[ch], A1s[C1 + ch]), slope);
+                    z = rowok ? z : 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z, wrow[2 * s], acc, 0, 0, 0);
+                }
             }
             // dy2 = a2 (h2 [s = arg] - db2 - yhat2 dg2) splits into a part that is affine in y2 -- every edge, ONE fma per
             // accumulator element: A + Bc y2 with A = a2 (mu2 r2 dg2 - db2), Bc = -a2 r2 dg2 -- and the selected-edge term
@@ -359,9 +399,23 @@ __global__ __launch_bounds__(256) void ec2_bwd_kernel(
             f32x16 acc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            if (BF) {
+#pragma unroll
+                for (int s = 0; s < C2 / 16; ++s) {
+                    float a[8], w[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int kk = 16 * s + 8 * half + i;           // layer-2 channel
+                        a[i] = drow[kk - half];                          // (drow already carries + half)
+                        w[i] = W[kk * LD1 + ct * 32 + ql];
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(a), pack8(w), acc, 0, 0, 0);
+                }
+            } else {
 #pragma unroll 8
-            for (int s = 0; s < C2 / 2; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(drow[2 * s], wcol[2 * s * LD1], acc, 0, 0, 0);
+                for (int s = 0; s < C2 / 2; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(drow[2 * s], wcol[2 * s * LD1], acc, 0, 0, 0);
+            }
             const int c1 = ct * 32 + ql;
             const float a1 = A1s[c1], b1 = A1s[C1 + c1], mu1 = mean1[c1], r1 = invstd1[c1];
             float sb = 0.f, sg = 0.f;
@@ -391,11 +445,25 @@ __global__ __launch_bounds__(256) void ec2_bwd_kernel(
                 const float a1 = A1s[c1], b1 = A1s[C1 + c1];
                 const float *dcol = D + half * LD2 + ct2 * 32 + ql;
                 const float *ycol = Y1 + half * LD1 + c1;
-                for (int s = 0; s < Rpad / 2; ++s) {
-                    const int row = 2 * s + half;
-                    float z = lrelu(__builtin_fmaf(ycol[2 * s * LD1], a1, b1), slope);
-                    z = row < rvalid ? z : 0.f;
-                    accw[wi] = __builtin_amdgcn_mfma_f32_32x32x2f32(dcol[2 * s * LD2], z, accw[wi], 0, 0, 0);
+                if (BF) {
+                    for (int s = 0; s < Rpad / 16; ++s) {     // K = edge rows, 16 per MFMA
+                        float a[8], zz[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int row = 16 * s + 8 * half + i;
+                            a[i] = D[row * LD2 + ct2 * 32 + ql];
+                            const float z = lrelu(__builtin_fmaf(Y1[row * LD1 + c1], a1, b1), slope);
+                            zz[i] = row < rvalid ? z : 0.f;
+                        }
+                        accw[wi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(a), pack8(zz), accw[wi], 0, 0, 0);
+                    }
+                } else {
+                    for (int s = 0; s < Rpad / 2; ++s) {
+                        const int row = 2 * s + half;
+                        float z = lrelu(__builtin_fmaf(ycol[2 * s * LD1], a1, b1), slope);
+                        z = row < rvalid ? z : 0.f;
+                        accw[wi] = __builtin_amdgcn_mfma_f32_32x32x2f32(dcol[2 * s * LD2], z, accw[wi], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -535,7 +603,7 @@ extern "C" size_t fsg_edgeconv2_workspace_bytes(int B, int N, int k, int C2) {
     return sizeof(float) * (rec1 + rec2) + scratch1 + 256;
 }
 
-extern "C" int fsg_edgeconv2_fwd_f32(const float *pq, const int32_t *idx, const float *w2, const float *gamma1,
+static int ec2_fwd_impl(bool bf16, const float *pq, const int32_t *idx, const float *w2, const float *gamma1,
                                      const float *beta1, float *running_mean1, float *running_var1, const float *gamma2,
                                      const float *beta2, float *running_mean2, float *running_var2, int B, int N, int k,
                                      int C2, int training, float momentum1, float momentum2, float eps1, float eps2,
@@ -564,29 +632,23 @@ extern "C" int fsg_edgeconv2_fwd_f32(const float *pq, const int32_t *idx, const 
             return rc;
     }
     const size_t lds = sizeof(float) * ((size_t)C2 * LD1 + (size_t)Rpad * (C2 + 1) + 3 * 4 * C2);
-    if (C2 == 64) {
-        static bool granted = false;
-        if (!granted) {
-            if (hipFuncSetAttribute((const void *)ec2_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) {
-                fsg_set_error("fsg_edgeconv2_fwd_f32: cannot raise dynamic LDS");
-                return FSG_ERR_HIP;
-            }
-            granted = true;
-        }
-        hipLaunchKernelGGL(ec2_fwd_kernel<64>, dim3(B, G), dim3(256), lds, st, pq, idx, w2, gamma1, beta1, mean1, invstd1,
-                           gamma2, N, k, TP, Rpad, training, slope, ysel2, arg2, ssum2, part2);
-    } else {
-        static bool granted = false;
-        if (!granted) {
-            if (hipFuncSetAttribute((const void *)ec2_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) {
-                fsg_set_error("fsg_edgeconv2_fwd_f32: cannot raise dynamic LDS");
-                return FSG_ERR_HIP;
-            }
-            granted = true;
-        }
-        hipLaunchKernelGGL(ec2_fwd_kernel<128>, dim3(B, G), dim3(256), lds, st, pq, idx, w2, gamma1, beta1, mean1,
-                           invstd1, gamma2, N, k, TP, Rpad, training, slope, ysel2, arg2, ssum2, part2);
-    }
+#define FSG_EC2_FWD(CC, BFX)                                                                                             \
+    do {                                                                                                                 \
+        static bool granted = false;                                                                                     \
+        if (!granted) {                                                                                                  \
+            if (hipFuncSetAttribute((const void *)ec2_fwd_kernel<CC, BFX>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                    160 * 1024 - 512) != hipSuccess) {                                                   \
+                fsg_set_error("fsg_edgeconv2_fwd: cannot raise dynamic LDS");                                            \
+                return FSG_ERR_HIP;                                                                                      \
+            }                                                                                                            \
+            granted = true;                                                                                              \
+        }                                                                                                                \
+        hipLaunchKernelGGL((ec2_fwd_kernel<CC, BFX>), dim3(B, G), dim3(256), lds, st, pq, idx, w2, gamma1, beta1, mean1,    \
+                           invstd1, gamma2, N, k, TP, Rpad, training, slope, ysel2, arg2, ssum2, part2);                 \
+    } while (0)
+    if (C2 == 64) { if (bf16) FSG_EC2_FWD(64, true); else FSG_EC2_FWD(64, false); }
+    else { if (bf16) FSG_EC2_FWD(128, true); else FSG_EC2_FWD(128, false); }
+#undef FSG_EC2_FWD
     FSG_CHECK_LAUNCH("fsg_edgeconv2_fwd_f32/mlp");
     if (training) {
         if ((rc = fsg_ec_finalize_launch(part2, B * G, C2, eps2, momentum2, mean2, invstd2, running_mean2, running_var2,
@@ -594,6 +656,28 @@ extern "C" int fsg_edgeconv2_fwd_f32(const float *pq, const int32_t *idx, const 
             return rc;
     }
     return fsg_ec_apply_launch(ysel2, gamma2, beta2, mean2, invstd2, B, N, C2, slope, out, out_pm, st);
+}
+
+extern "C" int fsg_edgeconv2_fwd_f32(const float *pq, const int32_t *idx, const float *w2, const float *gamma1,
+                                     const float *beta1, float *running_mean1, float *running_var1, const float *gamma2,
+                                     const float *beta2, float *running_mean2, float *running_var2, int B, int N, int k,
+                                     int C2, int training, float momentum1, float momentum2, float eps1, float eps2,
+                                     float slope, float *out, float *out_pm, float *ssum1, float *mean1, float *invstd1,
+                                     float *ysel2, uint8_t *arg2, float *ssum2, float *mean2, float *invstd2,
+                                     void *workspace, fsg_stream_t stream) {
+    return ec2_fwd_impl(false, pq, idx, w2, gamma1, beta1, running_mean1, running_var1, gamma2, beta2, running_mean2, running_var2, B, N, k, C2, training, momentum1, momentum2, eps1, eps2, slope, out, out_pm, ssum1, mean1, invstd1, ysel2, arg2, ssum2, mean2, invstd2, workspace, stream);
+}
+
+// same arguments and tensors (all fp32); the per-edge 64 x C2 contraction runs with bf16 operands on
+// v_mfma_f32_32x32x16_bf16 (fp32 accumulation): BASELINE configs 3-5 name bf16 as their compute type
+extern "C" int fsg_edgeconv2_fwd_bf16(const float *pq, const int32_t *idx, const float *w2, const float *gamma1,
+                                     const float *beta1, float *running_mean1, float *running_var1, const float *gamma2,
+                                     const float *beta2, float *running_mean2, float *running_var2, int B, int N, int k,
+                                     int C2, int training, float momentum1, float momentum2, float eps1, float eps2,
+                                     float slope, float *out, float *out_pm, float *ssum1, float *mean1, float *invstd1,
+                                     float *ysel2, uint8_t *arg2, float *ssum2, float *mean2, float *invstd2,
+                                     void *workspace, fsg_stream_t stream) {
+    return ec2_fwd_impl(true, pq, idx, w2, gamma1, beta1, running_mean1, running_var1, gamma2, beta2, running_mean2, running_var2, B, N, k, C2, training, momentum1, momentum2, eps1, eps2, slope, out, out_pm, ssum1, mean1, invstd1, ysel2, arg2, ssum2, mean2, invstd2, workspace, stream);
 }
 
 int fsg_ec_bwd_point_launch(const float *gout, const float *gout_pm, long ld_pm, const float *gout_pm2, long ld_pm2,
@@ -629,7 +713,7 @@ extern "C" size_t fsg_edgeconv2_bwd_workspace_bytes(int B, int N, int k, int C2)
     return sizeof(float) * (point_rec + dw + p1 + du + (size_t)B * N * C2) + 256;
 }
 
-extern "C" int fsg_edgeconv2_bwd_f32(const float *grad_out, const float *grad_out_pm, int64_t ld_pm, const float *grad_out_pm2,
+static int ec2_bwd_impl(bool bf16, const float *grad_out, const float *grad_out_pm, int64_t ld_pm, const float *grad_out_pm2,
                                      int64_t ld_pm2, const float *pq, const int32_t *idx,
                                      const int32_t *rowptr, const int32_t *col, const float *w2, const float *gamma1,
                                      const float *beta1, const float *mean1, const float *invstd1, const float *ssum1,
@@ -663,23 +747,23 @@ extern "C" int fsg_edgeconv2_bwd_f32(const float *grad_out, const float *grad_ou
     const float invM = 1.0f / ((float)B * (float)N * (float)k);
     const size_t lds = sizeof(float) * ((size_t)C2 * LD1 + (size_t)Rpad * LD1 + (size_t)Rpad * (C2 + 1) + (size_t)TP * C2 +
                                         2 * C1 + 2 * C1) + (size_t)TP * C2 + 2 * (size_t)Rpad + 16;
-#define FSG_EC2_BWD(CC)                                                                                                  \
+#define FSG_EC2_BWD(CC, BFX)                                                                                                \
     do {                                                                                                                 \
         static bool granted = false;                                                                                     \
         if (!granted) {                                                                                                  \
-            if (hipFuncSetAttribute((const void *)ec2_bwd_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
+            if (hipFuncSetAttribute((const void *)ec2_bwd_kernel<CC, BFX>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                     160 * 1024 - 512) != hipSuccess) {                                                   \
                 fsg_set_error("fsg_edgeconv2_bwd_f32: cannot raise dynamic LDS");                                        \
                 return FSG_ERR_HIP;                                                                                      \
             }                                                                                                            \
             granted = true;                                                                                              \
         }                                                                                                                \
-        hipLaunchKernelGGL(ec2_bwd_kernel<CC>, dim3(B, G), dim3(256), lds, st, pq, idx, w2, gamma1, beta1, mean1, invstd1, \
+        hipLaunchKernelGGL((ec2_bwd_kernel<CC, BFX>), dim3(B, G), dim3(256), lds, st, pq, idx, w2, gamma1, beta1, mean1, invstd1, \
                            gamma2, mean2, invstd2, grad_beta2, grad_gamma2, h2, arg2, N, k, TP, Rpad, training, invM,    \
                            slope, du1, dw_part, p1_part);                                                                \
     } while (0)
-    if (C2 == 64) FSG_EC2_BWD(64);
-    else FSG_EC2_BWD(128);
+    if (C2 == 64) { if (bf16) FSG_EC2_BWD(64, true); else FSG_EC2_BWD(64, false); }
+    else { if (bf16) FSG_EC2_BWD(128, true); else FSG_EC2_BWD(128, false); }
 #undef FSG_EC2_BWD
     FSG_CHECK_LAUNCH("fsg_edgeconv2_bwd_f32/mlp");
     if ((rc = fsg_ec_sum_launch(dw_part, B * G, C2 * C1, 1, grad_w2, nullptr, st)) != FSG_OK) return rc;
@@ -688,4 +772,27 @@ extern "C" int fsg_edgeconv2_bwd_f32(const float *grad_out, const float *grad_ou
                        gamma1, mean1, invstd1, grad_beta1, grad_gamma1, N, k, training, invM, grad_pq);
     FSG_CHECK_LAUNCH("fsg_edgeconv2_bwd_f32/gather");
     return FSG_OK;
+}
+
+extern "C" int fsg_edgeconv2_bwd_f32(const float *grad_out, const float *grad_out_pm, int64_t ld_pm, const float *grad_out_pm2,
+                                     int64_t ld_pm2, const float *pq, const int32_t *idx,
+                                     const int32_t *rowptr, const int32_t *col, const float *w2, const float *gamma1,
+                                     const float *beta1, const float *mean1, const float *invstd1, const float *ssum1,
+                                     const float *gamma2, const float *beta2, const float *mean2, const float *invstd2,
+                                     const float *ysel2, const uint8_t *arg2, int B, int N, int k, int C2, int training,
+                                     float slope, float *grad_pq, float *grad_w2, float *grad_gamma1, float *grad_beta1,
+                                     float *grad_gamma2, float *grad_beta2, void *workspace, fsg_stream_t stream) {
+    return ec2_bwd_impl(false, grad_out, grad_out_pm, ld_pm, grad_out_pm2, ld_pm2, pq, idx, rowptr, col, w2, gamma1, beta1, mean1, invstd1, ssum1, gamma2, beta2, mean2, invstd2, ysel2, arg2, B, N, k, C2, training, slope, grad_pq, grad_w2, grad_gamma1, grad_beta1, grad_gamma2, grad_beta2, workspace, stream);
+}
+
+// the three per-tile products of the backward (y2 recompute, dz1 = dy2 W2, dW2 += dy2^T z1) with bf16 operands
+extern "C" int fsg_edgeconv2_bwd_bf16(const float *grad_out, const float *grad_out_pm, int64_t ld_pm, const float *grad_out_pm2,
+                                     int64_t ld_pm2, const float *pq, const int32_t *idx,
+                                     const int32_t *rowptr, const int32_t *col, const float *w2, const float *gamma1,
+                                     const float *beta1, const float *mean1, const float *invstd1, const float *ssum1,
+                                     const float *gamma2, const float *beta2, const float *mean2, const float *invstd2,
+                                     const float *ysel2, const uint8_t *arg2, int B, int N, int k, int C2, int training,
+                                     float slope, float *grad_pq, float *grad_w2, float *grad_gamma1, float *grad_beta1,
+                                     float *grad_gamma2, float *grad_beta2, void *workspace, fsg_stream_t stream) {
+    return ec2_bwd_impl(true, grad_out, grad_out_pm, ld_pm, grad_out_pm2, ld_pm2, pq, idx, rowptr, col, w2, gamma1, beta1, mean1, invstd1, ssum1, gamma2, beta2, mean2, invstd2, ysel2, arg2, B, N, k, C2, training, slope, grad_pq, grad_w2, grad_gamma1, grad_beta1, grad_gamma2, grad_beta2, workspace, stream);
 }

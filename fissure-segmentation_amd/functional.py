@@ -48,6 +48,73 @@ def no_autocast():
     return _contextlib.nullcontext()
 
 
+# bf16 OPERAND MODE (BASELINE configs 3-5 name bf16 as their compute type).  What it changes: the operands of the dense
+# contractions -- the per-edge 64 x C2 product of the two-layer EdgeConv (fsg_edgeconv2_{fwd,bwd}_bf16 on
+# v_mfma_f32_32x32x16_bf16) and the point-wise / Linear GEMMs that go to the vendor library -- are rounded to bf16,
+# accumulation stays fp32.  What it never changes: the graph build (always fp32: indices equal the fp32 CPU path), BatchNorm
+# statistics, selection, every stored activation and every gradient tensor (fp32).  Switched on explicitly
+# (`set_mfma_operands("bf16")` / `with mfma_operands("bf16")`) or by an ambient `torch.autocast("cuda", torch.bfloat16)`
+# around a model forward; the backward of every op follows the mode its forward ran in.
+_mfma_mode = "f32"
+
+
+def set_mfma_operands(kind):
+    global _mfma_mode
+    if kind not in ("f32", "bf16"):
+        raise ValueError("MFMA operand type must be 'f32' or 'bf16'")
+    _mfma_mode = kind
+
+
+@_contextlib.contextmanager
+def mfma_operands(kind):
+    global _mfma_mode
+    old = _mfma_mode
+    set_mfma_operands(kind)
+    try:
+        yield
+    finally:
+        _mfma_mode = old
+
+
+def bf16_operands():
+    return _mfma_mode == "bf16"
+
+
+# The vendor GEMMs (point-wise head, Linear layers) can run with bf16 operands too, but every call then pays a cast pass
+# over its fp32 activations and gradients (all stored tensors stay fp32): measured on MI355X at the config-4 shape the
+# step got SLOWER (4.64 vs 4.17 ms), so this half of the mode is a separate opt-in (FSG_BF16_VENDOR_GEMM=1 /
+# `set_bf16_vendor_gemm(True)`); the hand-written kernels convert their operands on the way out of LDS at no extra traffic.
+_bf16_vendor = _os.environ.get("FSG_BF16_VENDOR_GEMM", "0") == "1"
+
+
+def set_bf16_vendor_gemm(flag):
+    global _bf16_vendor
+    _bf16_vendor = bool(flag)
+
+
+def _bf16_gemm():
+    return _mfma_mode == "bf16" and _bf16_vendor
+
+
+def _ambient_bf16():
+    return torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
+
+
+_MM_OUT_DTYPE = True
+
+
+def _bf16_mm(a, b):
+    """a (M,K) @ b (K,N) with bf16 operands and fp32 accumulation -> fp32 (vendor GEMM, hipBLASLt)"""
+    global _MM_OUT_DTYPE
+    a16, b16 = a.to(torch.bfloat16), b.to(torch.bfloat16)
+    if _MM_OUT_DTYPE:
+        try:
+            return torch.mm(a16, b16, out_dtype=torch.float32)
+        except (TypeError, RuntimeError):
+            _MM_OUT_DTYPE = False
+    return torch.mm(a16, b16).float()
+
+
 _deterministic = bool(_os.environ.get("FSG_DETERMINISTIC"))
 
 
@@ -96,12 +163,15 @@ class _EdgeGather(torch.autograd.Function):
     def forward(ctx, x, idx):
         B, C, N = x.shape
         k = idx.shape[2]
-        xc = _f32c(x)
-        out = torch.empty(B, 2 * C, N, k, dtype=torch.float32, device=x.device)
+        half = x.dtype == torch.bfloat16       # bf16 storage: fsg_edge_gather_*_bf16
+        xc = x.detach().contiguous() if half else _f32c(x)
+        out = torch.empty(B, 2 * C, N, k, dtype=xc.dtype, device=x.device)
         with torch.cuda.device(x.device):
-            _lib.call("fsg_edge_gather_fwd_f32", _p(xc), _p(idx), _p(out), B, C, N, k, _stream())
+            _lib.call("fsg_edge_gather_fwd_bf16" if half else "fsg_edge_gather_fwd_f32", _p(xc), _p(idx), _p(out), B, C, N, k,
+                      _stream())
         ctx.save_for_backward(idx)
         ctx.shape = (B, C, N, k)
+        ctx.half = half
         return out
 
     @staticmethod
@@ -109,11 +179,13 @@ class _EdgeGather(torch.autograd.Function):
     def backward(ctx, g):
         (idx,) = ctx.saved_tensors
         B, C, N, k = ctx.shape
-        g = _f32c(g)
-        gx = torch.empty(B, C, N, dtype=torch.float32, device=g.device)
+        half = ctx.half and g.dtype == torch.bfloat16
+        g = g.detach().contiguous() if half else _f32c(g)
+        gx = torch.empty(B, C, N, dtype=torch.float32, device=g.device)      # accumulated in fp32 in both modes
         with torch.cuda.device(g.device):
-            _lib.call("fsg_edge_gather_bwd_f32", _p(g), _p(idx), _p(gx), B, C, N, k, _stream())
-        return gx, None
+            _lib.call("fsg_edge_gather_bwd_bf16" if half else "fsg_edge_gather_bwd_f32", _p(g), _p(idx), _p(gx), B, C, N, k,
+                      _stream())
+        return (gx.to(torch.bfloat16) if ctx.half else gx), None
 
 
 def edge_features(x, idx):
@@ -159,11 +231,18 @@ class _LinearPM(torch.autograd.Function):
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        ctx.bf16 = False
         x2 = x.reshape(-1, x.shape[-1])
         N, K = w.shape
         M = x2.shape[0]
         if _small(M, N, K, x2, w):
             y = gemm_small(x2, K, 1, w, 1, K, b.contiguous() if b is not None else None, M, N, K)
+            return y.view(*x.shape[:-1], N)
+        ctx.bf16 = _bf16_gemm() and x.is_cuda
+        if ctx.bf16:
+            y = _bf16_mm(x2, w.t())
+            if b is not None:
+                y += b
             return y.view(*x.shape[:-1], N)
         return torch.nn.functional.linear(x, w, b)
 
@@ -177,27 +256,32 @@ class _LinearPM(torch.autograd.Function):
         if not g2.is_contiguous():
             g2 = g2.contiguous()
         if ctx.needs_input_grad[0]:
-            gx = _linear_dx(g2, w).view_as(x)
+            gx = _linear_dx(g2, w, bf16=ctx.bf16).view_as(x)
         if ctx.needs_input_grad[1]:
-            gw = _linear_dw(g2, x2)
+            gw = _linear_dw(g2, x2, bf16=ctx.bf16)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = _bias_grad(g2)
         return gx, gw, gb
 
 
-def _linear_dx(g2, w, out=None):
+def _linear_dx(g2, w, out=None, bf16=False):
     """dX = dY W for dY (M,N), W (N,K); `out`: accumulate into an existing (M,K) gradient instead (one GEMM with beta = 1)"""
     N, K = w.shape
     M = g2.shape[0]
+    if bf16:
+        r = _bf16_mm(g2, w)
+        return r if out is None else out.add_(r)
     if out is not None:
         return out.addmm_(g2, w)
     return gemm_small(g2, N, 1, w, K, 1, None, M, K, N) if _small(M, K, N, g2, w) else g2 @ w
 
 
-def _linear_dw(g2, x2):
+def _linear_dw(g2, x2, bf16=False):
     """dW = dY^T X: a tiny output behind a long reduction (see _LinearPM)"""
     M, N = g2.shape
     K = x2.shape[1]
+    if bf16:
+        return _bf16_mm(g2.t(), x2)
     S = 16 if (M % 16 == 0 and M >= 4096) else 1
     if _small(N, K, M, g2, x2):
         return gemm_small(g2, 1, N, x2, K, 1, None, N, K, M)
@@ -235,6 +319,10 @@ class _LinearPM2(torch.autograd.Function):
     def forward(ctx, x, w1, w2):
         ctx.save_for_backward(x, w1, w2)
         x2 = x.reshape(-1, x.shape[-1])
+        ctx.bf16 = _bf16_gemm() and x.is_cuda
+        if ctx.bf16:
+            x16 = x2.to(torch.bfloat16)
+            return _bf16_mm(x16, w1.t()), _bf16_mm(x16, w2.t())
         return torch.nn.functional.linear(x2, w1), torch.nn.functional.linear(x2, w2)
 
     @staticmethod
@@ -247,10 +335,10 @@ class _LinearPM2(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             for g, w in zip(gs, (w1, w2)):
                 if g is not None:
-                    gx = _linear_dx(g, w) if gx is None else _linear_dx(g, w, out=gx)
+                    gx = _linear_dx(g, w, bf16=ctx.bf16) if gx is None else _linear_dx(g, w, out=gx, bf16=ctx.bf16)
             gx = gx.view_as(x) if gx is not None else None
-        gw1 = _linear_dw(gs[0], x2) if (gs[0] is not None and ctx.needs_input_grad[1]) else None
-        gw2 = _linear_dw(gs[1], x2) if (gs[1] is not None and ctx.needs_input_grad[2]) else None
+        gw1 = _linear_dw(gs[0], x2, bf16=ctx.bf16) if (gs[0] is not None and ctx.needs_input_grad[1]) else None
+        gw2 = _linear_dw(gs[1], x2, bf16=ctx.bf16) if (gs[1] is not None and ctx.needs_input_grad[2]) else None
         return gx, gw1, gw2
 
 
@@ -330,7 +418,11 @@ class _LinearReLU(torch.autograd.Function):
     @_amp_fwd
     def forward(ctx, x, w, b):
         x2 = x.reshape(-1, x.shape[-1])
-        out = torch._addmm_activation(b, x2, w.t(), use_gelu=False)
+        ctx.bf16 = _bf16_gemm() and x.is_cuda
+        if ctx.bf16:
+            out = torch.relu_(_bf16_mm(x2, w.t()).add_(b))
+        else:
+            out = torch._addmm_activation(b, x2, w.t(), use_gelu=False)
         ctx.save_for_backward(x, w, out)
         return out.view(*x.shape[:-1], w.shape[0])
 
@@ -340,8 +432,8 @@ class _LinearReLU(torch.autograd.Function):
         x, w, out = ctx.saved_tensors
         g2 = torch.ops.aten.threshold_backward(g.reshape(-1, g.shape[-1]).contiguous(), out, 0)
         x2 = x.reshape(-1, x.shape[-1])
-        gx = _linear_dx(g2, w).view_as(x) if ctx.needs_input_grad[0] else None
-        gw = _linear_dw(g2, x2) if ctx.needs_input_grad[1] else None
+        gx = _linear_dx(g2, w, bf16=ctx.bf16).view_as(x) if ctx.needs_input_grad[0] else None
+        gw = _linear_dw(g2, x2, bf16=ctx.bf16) if ctx.needs_input_grad[1] else None
         gb = _bias_grad(g2) if ctx.needs_input_grad[2] else None
         return gx, gw, gb
 
@@ -505,7 +597,8 @@ def with_deferred_bn_counters(forward):
 
     @functools.wraps(forward)
     def wrapped(self, x, *args, **kwargs):
-        with deferred_bn_counters(), no_autocast():
+        mode = mfma_operands("bf16") if (x.is_cuda and _ambient_bf16()) else _contextlib.nullcontext()
+        with deferred_bn_counters(), mode, no_autocast():
             if torch.is_tensor(x) and x.is_floating_point() and x.dtype != torch.float32:
                 x = x.float()
             return forward(self, x, *args, **kwargs)
@@ -696,8 +789,10 @@ class _EdgeConv2(torch.autograd.Function):
             mean2, invstd2 = rm2.detach().float().contiguous(), torch.rsqrt(rv2.detach().float() + eps2).contiguous()
         ws = new(_lib.lib.fsg_edgeconv2_workspace_bytes(B, N, k, C2), dtype=torch.uint8)
         t = bool(training)
+        ctx.bf16 = bf16_operands()
         with torch.cuda.device(dev):
-            _lib.call("fsg_edgeconv2_fwd_f32", _p(pq), _p(idx), _p(w2), _p(g1), _p(b1), _p(rm1 if t else None),
+            _lib.call("fsg_edgeconv2_fwd_bf16" if ctx.bf16 else "fsg_edgeconv2_fwd_f32", _p(pq), _p(idx), _p(w2), _p(g1), _p(b1),
+                      _p(rm1 if t else None),
                       _p(rv1 if t else None), _p(g2), _p(b2), _p(rm2 if t else None), _p(rv2 if t else None), B, N, k, C2,
                       int(t), mom1, mom2, eps1, eps2, slope, _p(out), _p(out_pm), _p(ssum1), _p(mean1), _p(invstd1),
                       _p(ysel2), _p(arg2), _p(ssum2), _p(mean2), _p(invstd2), _p(ws), _stream())
@@ -721,7 +816,8 @@ class _EdgeConv2(torch.autograd.Function):
         dg2, db2 = torch.empty_like(g2), torch.empty_like(b2)
         ws = torch.empty(_lib.lib.fsg_edgeconv2_bwd_workspace_bytes(B, N, k, C2), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            _lib.call("fsg_edgeconv2_bwd_f32", _p(g), _p(g_pm), ld1, _p(g_pm2), ld2, _p(pq), _p(idx), _p(rowptr), _p(col),
+            _lib.call("fsg_edgeconv2_bwd_bf16" if ctx.bf16 else "fsg_edgeconv2_bwd_f32", _p(g), _p(g_pm), ld1, _p(g_pm2), ld2,
+                      _p(pq), _p(idx), _p(rowptr), _p(col),
                       _p(w2), _p(g1),
                       _p(b1), _p(mean1), _p(invstd1), _p(ssum1), _p(g2), _p(b2), _p(mean2), _p(invstd2), _p(ysel2),
                       _p(arg2), B, N, k, C2, int(training), slope, _p(gpq), _p(gw2), _p(dg1), _p(db1), _p(dg2), _p(db2),

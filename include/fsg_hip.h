@@ -66,6 +66,13 @@ int fsg_edge_gather_fwd_f32(const float *x, const int32_t *idx, float *edge, int
                             int k, fsg_stream_t stream);
 int fsg_edge_gather_bwd_f32(const float *grad_edge, const int32_t *idx, float *grad_x, int B, int C,
                             int N, int k, fsg_stream_t stream);
+/* bf16 storage of the same op (BASELINE configs 3-5; SURVEY 8d counts the edge tensor at 2 bytes per element):
+ * x, edge and grad_edge are bf16 (raw 16-bit patterns), the difference is formed in fp32 and rounded once;
+ * grad_x is accumulated and returned in FP32 (B,C,N). */
+int fsg_edge_gather_fwd_bf16(const void *x, const int32_t *idx, void *edge, int B, int C, int N, int k,
+                             fsg_stream_t stream);
+int fsg_edge_gather_bwd_bf16(const void *grad_edge, const int32_t *idx, float *grad_x, int B, int C, int N,
+                             int k, fsg_stream_t stream);
 
 /*
  * Reverse graph (CSR by destination) of a kNN graph -- needed by the gather-style backward below.
@@ -152,6 +159,25 @@ int fsg_edgeconv2_bwd_f32(const float *grad_out, const float *grad_out_pm, int64
                           const float *ysel2, const uint8_t *arg2, int B, int N, int k, int C2, int training,
                           float slope, float *grad_pq, float *grad_w2, float *grad_gamma1, float *grad_beta1,
                           float *grad_gamma2, float *grad_beta2, void *workspace, fsg_stream_t stream);
+/* bf16 operand mode of the same two entry points (same arguments, every tensor fp32): the per-edge 64 x C2 contraction
+ * of the forward and the three per-tile products of the backward (y2 recompute, dz1 = dy2 W2, dW2 += dy2^T z1) run on
+ * v_mfma_f32_32x32x16_bf16 -- operands rounded to bf16 on their way out of LDS, fp32 accumulation; gathers, BatchNorm
+ * statistics, selection and all stored tensors are unchanged.  The graph (idx) is always built in fp32. */
+int fsg_edgeconv2_fwd_bf16(const float *pq, const int32_t *idx, const float *w2, const float *gamma1,
+                           const float *beta1, float *running_mean1, float *running_var1, const float *gamma2,
+                           const float *beta2, float *running_mean2, float *running_var2, int B, int N, int k, int C2,
+                           int training, float momentum1, float momentum2, float eps1, float eps2, float slope,
+                           float *out, float *out_pm, float *ssum1, float *mean1, float *invstd1, float *ysel2,
+                           uint8_t *arg2, float *ssum2, float *mean2, float *invstd2, void *workspace,
+                           fsg_stream_t stream);
+int fsg_edgeconv2_bwd_bf16(const float *grad_out, const float *grad_out_pm, int64_t ld_pm, const float *grad_out_pm2,
+                           int64_t ld_pm2, const float *pq, const int32_t *idx,
+                           const int32_t *rowptr, const int32_t *col, const float *w2, const float *gamma1,
+                           const float *beta1, const float *mean1, const float *invstd1, const float *ssum1,
+                           const float *gamma2, const float *beta2, const float *mean2, const float *invstd2,
+                           const float *ysel2, const uint8_t *arg2, int B, int N, int k, int C2, int training,
+                           float slope, float *grad_pq, float *grad_w2, float *grad_gamma1, float *grad_beta1,
+                           float *grad_gamma2, float *grad_beta2, void *workspace, fsg_stream_t stream);
 
 /*
  * Fused BatchNorm + LeakyReLU on point-major rows (M, C), C % 64 == 0: the stage behind every 1x1 conv of the

@@ -1952,3 +1952,102 @@ def test_knn_streamed_variant_bit_exact(fsg, device, B, C, Np, k, flags):
     xt[0, 0] = np.arange(Np) % 7
     idx = fsg.functional.knn_graph(G(xt, device), k, _debug_flags=flags)
     assert np.array_equal(N(idx), c_api.knn_dense(xt, k, fix_diag=True)[0])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bf16 operand mode (BASELINE configs 3-5): *_bf16 entry points, tolerances stated against the fp32 path / oracle.
+
+def test_edge_gather_bf16(fsg, device):
+    """fsg_edge_gather_{fwd,bwd}_bf16: bf16 storage, difference formed in fp32 and rounded once (so it equals torch's
+    bf16 arithmetic on the gathered operands exactly); the gradient is accumulated in fp32."""
+    x = cloud(55, 2, 16, 300)
+    idx = c_api.knn_dense(x, 12)[0]
+    xb = G(x, device).bfloat16().requires_grad_(True)
+    it = G(idx, device)
+    e = fsg.functional.edge_features(xb, it)
+    assert e.dtype == torch.bfloat16 and e.shape == (2, 32, 300, 12)
+    xf = xb.detach().float()
+    nb = torch.gather(xf.unsqueeze(-1).expand(-1, -1, -1, 12), 2, it.long().unsqueeze(1).expand(-1, 16, -1, -1))
+    want = torch.cat([(nb - xf.unsqueeze(-1)).bfloat16(), xb.detach().unsqueeze(-1).expand(-1, -1, -1, 12)], 1)
+    assert torch.equal(e, want)
+    g = torch.randn_like(e)
+    e.backward(g)
+    xr = xf.clone().requires_grad_(True)
+    fsg.functional.edge_features(xr, it).backward(g.float())
+    assert xb.grad.dtype == torch.bfloat16
+    assert float((xb.grad.float() - xr.grad).abs().max()) <= 1e-2 * float(xr.grad.abs().max())    # one bf16 rounding
+
+
+def _find_node(fn, name, seen=None):
+    seen = set() if seen is None else seen
+    if fn is None or fn in seen:
+        return None
+    seen.add(fn)
+    if type(fn).__name__ == name:
+        return fn
+    for nxt, _ in fn.next_functions:
+        r = _find_node(nxt, name, seen)
+        if r is not None:
+            return r
+    return None
+
+
+@pytest.mark.parametrize("B,C,Np,k,C2", [(2, 3, 300, 20, 64), (1, 15, 130, 40, 128)])
+def test_edgeconv2_bf16_vs_f32(fsg, device, B, C, Np, k, C2):
+    """fsg_edgeconv2_{fwd,bwd}_bf16 against the fp32 kernels.  Forward, same inputs: operands carry 8 mantissa bits
+    (relative 2^-9 each), products accumulate in fp32 over 64 channels -> outputs within 1e-2 of their scale.  Backward:
+    a 1e-2 change of y2 re-routes the max over the k edges in many places, so the two BACKWARD entry points are compared on
+    the SAME saved forward state (the fp32 forward's): gradients within 2e-2 in norm."""
+    from fissure_segmentation_amd.models.dgcnn import EdgeConv
+    F_hip = fsg.functional
+    x = cloud(60 + C, B, C, Np)
+    ec = fill_state_dict(EdgeConv(C, [64, C2], k, first_layer=True), 61).to(device).train()
+    xt = G(x, device).requires_grad_(True)
+    y32 = ec(xt)
+    with F_hip.mfma_operands("bf16"), torch.no_grad():
+        y16 = ec(G(x, device))
+    assert not torch.equal(y32, y16)                       # the bf16 entry point really ran
+    assert float((y16 - y32).abs().max()) <= 1e-2 * float(y32.abs().max())
+    node = _find_node(y32.grad_fn, "_EdgeConv2Backward")
+    assert node is not None and node.bf16 is False
+    gr = G(np.random.default_rng(62).standard_normal(tuple(y32.shape)).astype(np.float32), device)
+    params = [xt] + list(ec.parameters())
+    g32 = torch.autograd.grad(y32, params, gr, retain_graph=True)
+    node.bf16 = True                                       # same graph, same saved tensors, bf16 backward entry point
+    g16 = torch.autograd.grad(y32, params, gr)
+    scale = max(float(q.norm()) for q in g32)
+    assert any(not torch.equal(a, b) for a, b in zip(g16, g32))
+    for a, b in zip(g16, g32):
+        assert float((a - b).norm()) <= 2e-2 * float(b.norm()) + 1e-3 * scale
+
+
+@pytest.mark.parametrize("how", ["switch", "autocast"])
+def test_dgcnnseg_bf16_mode_vs_fp32_oracle(fsg, device, monkeypatch, how):
+    """DGCNNSeg in bf16 operand mode -- switched on explicitly or by an ambient torch.autocast(bfloat16) -- against the
+    fp32 oracle with the HIP graphs replayed (the graphs themselves are still bit-exact fp32 builds of the kernel's own
+    input).  Stated tolerance: mean |logit error| <= 1.5e-2 and max <= 0.15 on logits of scale ~1 (a 1e-2 perturbation of
+    the first EdgeConv's features passes three train-mode BatchNorms and re-routes max-pools on its way to the logits);
+    the input gradient keeps its direction (cosine >= 0.9) -- the backward kernels themselves are compared at 2e-2 on a
+    fixed forward state in test_edgeconv2_bf16_vs_f32."""
+    from fissure_segmentation_amd.models.dgcnn import DGCNNSeg
+    ref = fill_state_dict(ref_cpu.DGCNNSeg(k=20, in_features=3, num_classes=4), 7).train()
+    net = DGCNNSeg(k=20, in_features=3, num_classes=4)
+    net.load_state_dict(ref.state_dict())
+    net = net.to(device).train()
+    x = cloud(77, 2, 3, 1024)
+    tape = GraphTape(fsg, monkeypatch)
+    xt = G(x, device).requires_grad_(True)
+    ctx = fsg.functional.mfma_operands("bf16") if how == "switch" else torch.autocast("cuda", dtype=torch.bfloat16)
+    with ctx:
+        y = net(xt)
+    assert y.dtype == torch.float32
+    gr = np.random.default_rng(78).standard_normal(tuple(y.shape)).astype(np.float32)
+    y.backward(G(gr, device))
+    tape.check_exact_and_replay(max_flipped_rows=0.2)     # bf16 features: the oracle's own graphs differ more often
+    xr = torch.from_numpy(x).requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(torch.from_numpy(gr))
+    err = float(np.abs(N(y) - yr.detach().numpy()).max())
+    gerr = _rel(N(xt.grad), xr.grad.numpy())
+    print("\\nBF16", how, "max |logit error|", err, "grad_x rel", gerr)
+    assert 1e-6 < err <= 3e-2 and gerr <= 5e-2
