@@ -1,16 +1,32 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun -- tools/refresh_profiles.sh): everything profiles/ is built from, into gpurun_out/refresh/.
-# Afterwards, in the repo:  python tools/refresh_profiles_collect.py
+# Runs on the GPU box (gpurun -- tools/refresh_profiles.sh [tag]): everything profiles/ is built from, into gpurun_out/refresh/.
+# Afterwards, in the repo:  python tools/refresh_profiles_collect.py <tag>
 set -e
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/refresh
 rm -rf $out; mkdir -p $out
 cd $R
 python3 bench.py > $out/bench_c2.json 2> $out/bench_c2.err
-for w in c4 c3 c5; do python3 bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline >> $out/bench_other.jsonl 2>> $out/bench_other.err; done
+for w in c4 c3 c5 c2s c3f; do python3 bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline >> $out/bench_other.jsonl 2>> $out/bench_other.err; done
+python3 bench.py --steps 20 --warmup 3 --inputs surface --no-cpu-baseline >> $out/bench_other.jsonl 2>> $out/bench_other.err
+python3 bench.py --workload c4 --dtype f32 --steps 20 --warmup 3 --no-cpu-baseline >> $out/bench_other.jsonl 2>> $out/bench_other.err
 python3 tools/bench_infer.py >> $out/bench_other.jsonl 2>> $out/bench_other.err
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline > $out/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 3 --eager --no-cpu-baseline > $out/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $R/bench.py --steps 5 --warmup 3 --eager --no-cpu-baseline > $out/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --min-seconds 0.1 > $out/stats.log 2>&1
+for w in c3 c4 c5; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$w -- python3 $R/bench.py --workload $w --steps 50 --warmup 5 --no-cpu-baseline --min-seconds 0.1 > $out/stats_$w.log 2>&1
+done
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 3 --eager --no-cpu-baseline --min-seconds 0 > $out/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $R/bench.py --steps 5 --warmup 3 --eager --no-cpu-baseline --min-seconds 0 > $out/pmc_write.log 2>&1
+# SQ counters of the dominant kernel alone (kNN at the config-2 shape, 64 channels): MFMA busy, VALU / LDS activity, waits
+i=0
+for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY" \
+           "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT" \
+           "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc_knn/p$i -- python3 $R/tools/prof_knn_phaseA.py > $out/pmc_knn_p$i.log 2>&1
+done
+cd $R
+python3 tools/summarise_knn_pmc.py $out/pmc_knn > $out/knn_sq_counters.txt
 grep -h ms_per_step $out/stats.log | cut -c1-200

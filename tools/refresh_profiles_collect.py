@@ -24,6 +24,26 @@ shutil.copy(os.path.join(src, "bench_other.jsonl"), os.path.join(prof, f"{tag}_b
 fetch = newest(os.path.join("pmc_fetch", "**", "*counter_collection.csv"))
 write = newest(os.path.join("pmc_write", "**", "*counter_collection.csv"))
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarise_pmc.py"), fetch, write, tag])
-subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "mfma_utilisation.py")])
-print("bench:", bench["ms_per_step"], "ms/step", bench["value"], bench["unit"], "roofline", bench["roofline"]["frac"],
-      "knn", bench["roofline_knn"]["frac"], "cpu", bench.get("cpu_baseline", {}).get("value"))
+subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "mfma_utilisation.py"), tag])
+# kernel statistics of the other configurations (configs 3, 4, 5) and the SQ counter summary of the dominant kernel
+for w in ("c3", "c4", "c5"):
+    try:
+        st = newest(os.path.join(f"stats_{w}", "**", "*kernel_stats.csv"))
+    except ValueError:
+        continue
+    ln = [l for l in open(os.path.join(src, f"stats_{w}.log")) if '"ms_per_step"' in l][-1]
+    with open(os.path.join(prof, f"{tag}_bench_{w}_kernel_stats.csv"), "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --workload {w} --steps 50 --warmup 5 --no-cpu-baseline --min-seconds 0.1\n")
+        f.write(f"# {json.loads(ln)['config']['workload']}; {json.loads(ln)['ms_per_step']} ms/step under the profiler (warm-up, capture and the eager\n")
+        f.write("# per-entry-point timing steps are part of the trace: divide Calls by the fsg adam_flat_kernel row for per-step counts)\n")
+        f.write(open(st).read())
+sq = os.path.join(src, "knn_sq_counters.txt")
+if os.path.exists(sq):
+    with open(os.path.join(prof, f"{tag}_knn_sq_counters.txt"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --pmc <4 counters per pass> -- python3 tools/prof_knn_phaseA.py (fsg_knn_dense_f32, B=8 N=2048 C=64 k=20);\n")
+        f.write("# means over the launches of knn_rows_mfma_kernel, summed over the device's SEs/XCDs as rocprofv3 reports them.\n")
+        f.write("# SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs) = matrix-pipe busy cycles per SIMD; SQ_BUSY_CYCLES / 32 = kernel cycles.\n")
+        f.write(open(sq).read())
+rl = bench["roofline"]
+print("bench:", bench["ms_per_step"], "ms/step", bench["value"], bench["unit"], "roofline", rl["bound"], rl["frac"],
+      "group hbm", bench["roofline_group_hbm"]["frac_vs_reference_bytes"], "cpu", bench.get("cpu_baseline", {}).get("value"))
