@@ -567,15 +567,14 @@ __global__ __launch_bounds__(WAVES * 64, (STREAM && WAVES == 8) ? 4 : 1) void kn
                         }
                         tau = prefix | 0xFFFFu;
                     }
-                    const float tau_f = tau >= 0xFF800000u ? INFINITY : o2f(tau);   // keys above +inf are NaN patterns
+                    // columns >= N hold +inf in the block, so `v <= tau` rejects them by itself unless tau is +inf (fewer than K
+                    // candidates so far): then tau is replaced by the largest finite value and +inf entries never pass
+                    const float tau_f = tau >= 0x7F800000u + 0x80000000u ? 3.4028234e38f : o2f(tau);
                     // compact the survivors behind the carried list: per-lane count, wave prefix sum, per-lane stores
                     if (lane < cc) sv[lane] = carry[qi * CK + lane];
                     int mine = 0;
         #pragma unroll
-                    for (int e = 0; e < VPL; ++e) {
-                        const int j = c0 + (e >> 2) * 256 + 4 * lane + (e & 3);
-                        mine += (v[e] <= tau_f && j < N) ? 1 : 0;
-                    }
+                    for (int e = 0; e < VPL; ++e) mine += v[e] <= tau_f ? 1 : 0;
                     const int incl = wave_incl_scan(mine, lane);
                     const int total = cc + __builtin_amdgcn_readlane(incl, 63);
                     if (total <= SURV) {
@@ -583,7 +582,7 @@ __global__ __launch_bounds__(WAVES * 64, (STREAM && WAVES == 8) ? 4 : 1) void kn
         #pragma unroll
                         for (int e = 0; e < VPL; ++e) {
                             const int j = c0 + (e >> 2) * 256 + 4 * lane + (e & 3);
-                            if (v[e] <= tau_f && j < N) sv[pos++] = ((u64)f2o(v[e]) << 32) | (unsigned)j;
+                            if (v[e] <= tau_f) sv[pos++] = ((u64)f2o(v[e]) << 32) | (unsigned)j;
                         }
                     }
                     if (total <= SURV) {
@@ -594,7 +593,7 @@ __global__ __launch_bounds__(WAVES * 64, (STREAM && WAVES == 8) ? 4 : 1) void kn
         #pragma unroll
                         for (int e = 0; e < VPL; ++e) {
                             const int j = c0 + (e >> 2) * 256 + 4 * lane + (e & 3);
-                            mykeys[e] = (v[e] <= tau_f && j < N) ? (((u64)f2o(v[e]) << 32) | (unsigned)j) : ~0ull;
+                            mykeys[e] = v[e] <= tau_f ? (((u64)f2o(v[e]) << 32) | (unsigned)j) : ~0ull;
                         }
                         mykeys[VPL] = lane < cc ? carry[qi * CK + lane] : ~0ull;
                         for (int r = 0; r < KK; ++r) {
