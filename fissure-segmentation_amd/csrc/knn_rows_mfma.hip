@@ -542,12 +542,18 @@ __global__ __launch_bounds__(WAVES * 64, (STREAM && WAVES == 8) ? 4 : 1) void kn
                     if (cc >= KK) {
                         tau = (unsigned)(carry[qi * CK + KK - 1] >> 32);   // K-th best so far: tighter than any chunk estimate
                     } else {
-                        float f1 = INFINITY, f2 = INFINITY;                // two smallest values of this lane
+                        // Upper bound of the row's K-th smallest value: the K-th smallest of a set of DISTINCT row elements.
+                        // Carried lists of up to 32 entries (CK == 32): one minimum per lane (64 elements); longer lists: the two
+                        // smallest of every lane (128 elements).  Binary search on the top 16 key bits, low bits rounded up.
+                        constexpr bool TWO = CK > 32;
+                        float f1 = INFINITY, f2 = INFINITY;
         #pragma unroll
                         for (int e = 0; e < VPL; ++e) {
-                            const float hi = fmaxf(v[e], f1);
+                            if (TWO) {
+                                const float hi = fmaxf(v[e], f1);
+                                f2 = fminf(f2, hi);
+                            }
                             f1 = fminf(v[e], f1);
-                            f2 = fminf(f2, hi);
                         }
                         if (lane < cc) {  // carried entries (fewer than K) also count as candidates of the bound
                             const float cv = o2f((unsigned)(carry[qi * CK + lane] >> 32));
@@ -556,13 +562,12 @@ __global__ __launch_bounds__(WAVES * 64, (STREAM && WAVES == 8) ? 4 : 1) void kn
                             f2 = fminf(f2, hi);
                         }
                         const unsigned m1 = f2o(f1), m2 = f2o(f2);
-                        // upper bound of the K-th smallest of the 128 lane minima: binary search on the top 16 key bits (two
-                        // wave-wide compares + population counts per round), the 16 low bits are rounded up
                         unsigned prefix = 0u;
         #pragma unroll 4
                         for (int bit = 31; bit >= 16; --bit) {   // sign, exponent and 7 mantissa bits: the bound is within 0.8 %
                             const unsigned t = prefix | ((1u << bit) - 1u);
-                            const int c = __popcll(__ballot(m1 <= t)) + __popcll(__ballot(m2 <= t));
+                            int c = __popcll(__ballot(m1 <= t));
+                            if (TWO) c += __popcll(__ballot(m2 <= t));
                             if (c < KK) prefix |= 1u << bit;
                         }
                         tau = prefix | 0xFFFFu;
