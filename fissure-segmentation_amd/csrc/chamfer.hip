@@ -166,11 +166,11 @@ __global__ __launch_bounds__(256) void chamfer_bwd_y_kernel(const float *__restr
 }  // namespace
 
 int fsg_csr_bipartite_launch(const int32_t *idx, int B, int NS, int N, int k, int32_t *rowptr, int32_t *col, int32_t *cnt,
-                             hipStream_t st);   // edgeconv.hip
+                             int32_t *tmp, hipStream_t st);   // edgeconv.hip
 
 extern "C" size_t fsg_chamfer_nn_bwd_workspace_bytes(int B, int N, int M) {
     if (B <= 0 || N <= 0 || M <= 0) return 0;
-    return sizeof(int32_t) * ((size_t)B * (M + 1) + (size_t)B * N + (size_t)B * 16 * M);
+    return sizeof(int32_t) * ((size_t)B * (M + 1) + (size_t)B * N + (size_t)B * 16 * M + (size_t)B * N);   // + sort copy
 }
 
 extern "C" int fsg_chamfer_nn_f32(const float *x, const float *y, int B, int N, int M, float *dist, int32_t *arg,
@@ -191,7 +191,8 @@ extern "C" int fsg_chamfer_nn_bwd_f32(const float *x, const float *y, const int3
     if (B == 0) return FSG_OK;
     if (workspace) {   // reproducible path: reverse graph of arg (N sources, one slot each -> M targets), ordered sums
         int32_t *rowptr = (int32_t *)workspace, *col = rowptr + (size_t)B * (M + 1), *cnt = col + (size_t)B * N;
-        const int rc = fsg_csr_bipartite_launch(arg, B, N, M, 1, rowptr, col, cnt, (hipStream_t)stream);
+        int32_t *tmp = cnt + (size_t)B * 16 * M;   // a collapsed reconstruction gives single targets thousands of in-edges
+        const int rc = fsg_csr_bipartite_launch(arg, B, N, M, 1, rowptr, col, cnt, tmp, (hipStream_t)stream);
         if (rc == FSG_OK) {
             hipLaunchKernelGGL(chamfer_bwd_x_kernel, dim3(fsg_cdiv(N, 256), B), dim3(256), 0, (hipStream_t)stream, x, y, arg,
                                g_dist, N, M, grad_x);

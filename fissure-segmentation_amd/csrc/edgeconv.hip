@@ -222,18 +222,35 @@ __global__ __launch_bounds__(1024) void csr_scan_fill_kernel(const int32_t *__re
 // In-edge order: the slots of a destination are handed out by LDS atomics, i.e. in no particular order, and the backward
 // sums its in-edges in slot order -- the gradients would differ in the last bits from run to run.  One wave per
 // destination sorts its slice ascending by (source, slot) (rank by counting through an LDS copy), which makes the
-// reverse graph, and with it the whole EdgeConv backward, reproducible.  Rows above CSR_SORT_CAP in-edges stay as filled.
+// reverse graph, and with it the whole EdgeConv backward, reproducible.  Rows above CSR_SORT_CAP in-edges (hub points; a
+// collapsed reconstruction in the Chamfer backward) do not fit the LDS copy: they are copied to `tmp` (NK ints per cloud, same
+// offsets) and ranked from there -- O(deg^2 / 64) global loads for that one row; without `tmp` they stay as filled.
 constexpr int CSR_SORT_CAP = 1024;
 __global__ __launch_bounds__(256) void csr_sort_rows_kernel(const int32_t *__restrict__ rowptr, int32_t *__restrict__ col, int N,
-                                                            int NK) {
+                                                            int NK, int32_t *__restrict__ tmp) {
     __shared__ int32_t buf[4][CSR_SORT_CAP];
     const int b = blockIdx.y, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + wave;
     if (j >= N) return;
     const int32_t *rp = rowptr + (long)b * (N + 1);
     const int beg = rp[j], deg = rp[j + 1] - beg;
-    if (deg < 2 || deg > CSR_SORT_CAP) return;
+    if (deg < 2) return;
     int32_t *row = col + (long)b * NK + beg;
+    if (deg > CSR_SORT_CAP) {
+        if (!tmp) return;
+        int32_t *cp = tmp + (long)b * NK + beg;
+        for (int t = lane; t < deg; t += 64) cp[t] = row[t];
+        __threadfence_block();                       // the wave's own stores, re-read below by other lanes of the same wave
+        __builtin_amdgcn_wave_barrier();
+        for (int t0 = 0; t0 < deg; t0 += 64) {
+            const int t = t0 + lane;
+            const int32_t e = t < deg ? __builtin_nontemporal_load(cp + t) : 0x7fffffff;
+            int rank = 0;
+            for (int u = 0; u < deg; ++u) rank += __builtin_nontemporal_load(cp + u) < e ? 1 : 0;
+            if (t < deg) row[rank] = e;
+        }
+        return;
+    }
     int32_t *mine = buf[wave];
     for (int t = lane; t < deg; t += 64) mine[t] = row[t];
     __builtin_amdgcn_wave_barrier();
@@ -611,13 +628,14 @@ int fsg_ec_sum_launch(const float *partials, int R, int L, int nvec, float *out0
 }
 
 extern "C" size_t fsg_graph_reverse_csr_workspace_bytes(int B, int N, int k) {
-    (void)k;
-    return sizeof(int32_t) * (size_t)(B > 0 ? B : 0) * FSG_CSR_SPLIT * (size_t)(N > 0 ? N : 0);
+    // per-slice counts of the multi-workgroup builder + one copy of the edge list for rows above the LDS sort capacity
+    const size_t b = (size_t)(B > 0 ? B : 0), n = (size_t)(N > 0 ? N : 0);
+    return sizeof(int32_t) * (b * FSG_CSR_SPLIT * n + b * n * (size_t)(k > 0 ? k : 0));
 }
 
 // shared with chamfer.hip: reverse of a bipartite graph (NS sources x k slots -> N destinations), multi-workgroup builder
 int fsg_csr_bipartite_launch(const int32_t *idx, int B, int NS, int N, int k, int32_t *rowptr, int32_t *col, int32_t *cnt,
-                             hipStream_t st) {
+                             int32_t *tmp, hipStream_t st) {
     const int G = FSG_CSR_SPLIT;
     const size_t ldsN = sizeof(int) * (size_t)N;
     if (ldsN > 64 * 1024 || B > 65535) return FSG_ERR_UNSUPPORTED;
@@ -632,7 +650,7 @@ int fsg_csr_bipartite_launch(const int32_t *idx, int B, int NS, int N, int k, in
         hipLaunchKernelGGL(csr_fill_kernel, dim3(B, G), dim3(1024), ldsN, st, idx, NS, N, k, G, cnt, col);
         FSG_CHECK_LAUNCH("fsg_graph_reverse_csr/fill");
     }
-    hipLaunchKernelGGL(csr_sort_rows_kernel, dim3(fsg_cdiv(N, 4), B), dim3(256), 0, st, rowptr, col, N, NS * k);
+    hipLaunchKernelGGL(csr_sort_rows_kernel, dim3(fsg_cdiv(N, 4), B), dim3(256), 0, st, rowptr, col, N, NS * k, tmp);
     FSG_CHECK_LAUNCH("fsg_graph_reverse_csr/sort");
     return FSG_OK;
 }
@@ -643,7 +661,8 @@ extern "C" int fsg_graph_reverse_csr(const int32_t *idx, int B, int N, int k, in
     FSG_REQUIRE(B >= 0 && N > 0 && k > 0 && k <= 64 && N <= 8192 * 4, "fsg_graph_reverse_csr: bad shape N=%d k=%d", N, k);
     if (B == 0) return FSG_OK;
     if (workspace) {
-        const int rc = fsg_csr_bipartite_launch(idx, B, N, N, k, rowptr, col, (int32_t *)workspace, (hipStream_t)stream);
+        int32_t *cnt = (int32_t *)workspace, *tmp = cnt + (size_t)B * FSG_CSR_SPLIT * N;
+        const int rc = fsg_csr_bipartite_launch(idx, B, N, N, k, rowptr, col, cnt, tmp, (hipStream_t)stream);
         if (rc != FSG_ERR_UNSUPPORTED) return rc;
     }
     const size_t lds = sizeof(int) * ((size_t)N + 1024);
@@ -658,7 +677,8 @@ extern "C" int fsg_graph_reverse_csr(const int32_t *idx, int B, int N, int k, in
     }
     hipLaunchKernelGGL(csr_build_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, idx, N, k, rowptr, col);
     FSG_CHECK_LAUNCH("fsg_graph_reverse_csr");
-    hipLaunchKernelGGL(csr_sort_rows_kernel, dim3(fsg_cdiv(N, 4), B), dim3(256), 0, (hipStream_t)stream, rowptr, col, N, N * k);
+    hipLaunchKernelGGL(csr_sort_rows_kernel, dim3(fsg_cdiv(N, 4), B), dim3(256), 0, (hipStream_t)stream, rowptr, col, N, N * k,
+                       (int32_t *)nullptr);
     FSG_CHECK_LAUNCH("fsg_graph_reverse_csr/sort");
     return FSG_OK;
 }

@@ -78,7 +78,8 @@ int fsg_edge_gather_bwd_bf16(const void *grad_edge, const int32_t *idx, float *g
  * Reverse graph (CSR by destination) of a kNN graph -- needed by the gather-style backward below.
  *   idx (B,N,k) int32 -> rowptr (B,N+1) int32, col (B,N*k) int32 with col = (source point << 6) | slot.
  *   The in-edges of a destination are sorted ascending by (source, slot) -- the backward that walks them is then
- *   reproducible from run to run (destinations with more than 1024 in-edges keep the order they were filled in).
+ *   reproducible from run to run.  Destinations with more than 1024 in-edges (hub points) are sorted through a copy in
+ *   the workspace; without a workspace they keep the order they were filled in.
  *   workspace: fsg_graph_reverse_csr_workspace_bytes(B,N,k) bytes, or NULL (then one workgroup per cloud builds the
  *   graph; with the workspace 16 workgroups per cloud share the edge list: count / scan / fill).
  */
