@@ -114,6 +114,24 @@ class PTLayerGrads(ctypes.Structure):
                                   "bn2_g", "bn2_b", "lw2_w", "lw2_b")]
 
 
+_experiments = None
+
+
+def experiments():
+    """libfsg_hip_experiments.so: the superseded kNN designs (cross-checks for tests/, baselines for tools/) -- test
+    infrastructure, loaded on first use, never by the product path"""
+    global _experiments
+    if _experiments is None:
+        path = os.path.join(_HERE, "libfsg_hip_experiments.so")
+        if not os.path.exists(path):
+            raise ImportError(f"{path} not found: `make -C {os.path.join(_HERE, 'csrc')} all` builds it")
+        x = ctypes.CDLL(path)
+        x.fsg_knn_experiment_f32.argtypes, x.fsg_knn_experiment_f32.restype = SIGNATURES["fsg_knn_dense_f32"][0], _I
+        x.fsg_last_error.restype = ctypes.c_char_p
+        _experiments = x
+    return _experiments
+
+
 def call(name, *args):
     if _timing is None:
         rc = getattr(lib, name)(*args)

@@ -115,13 +115,6 @@ __global__ __launch_bounds__(BLOCK) void knn_dense_rows_kernel(
 
 int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k,
                              int flags, int32_t *idx_out, float *dist_out, float *xx_scratch, hipStream_t st);
-int fsg_knn_pipe_launch(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k, int flags,
-                        int32_t *idx_out, float *dist_out, float *xx_scratch, hipStream_t st);
-int fsg_knn_mfma_launch(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k, int flags,
-                        int32_t *idx_out, float *dist_out, float *xx_scratch, hipStream_t st);  // knn_mfma.hip
-int fsg_knn_filter_launch(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k, int flags,
-                          int32_t *idx_out, float *dist_out, float *xx_scratch, hipStream_t st);  // knn_filter.hip
-
 extern "C" int fsg_knn_dense_f32(const float *x, int B, int N, int64_t stride_b, int64_t stride_c,
                                  int c_knn, int k, int flags, int32_t *idx_out, float *dist_out,
                                  float *xx_scratch, fsg_stream_t stream) {
@@ -133,23 +126,12 @@ extern "C" int fsg_knn_dense_f32(const float *x, int B, int N, int64_t stride_b,
     FSG_REQUIRE(N <= 32768, "fsg_knn_dense_f32: N=%d > 32768 unsupported", N);
     if (B == 0) return FSG_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (flags & FSG_KNN_FORCE_MFMA) {  // the first matrix-core design (per-lane filter + sorting network), kept for tests
-        const int rc = fsg_knn_mfma_launch(x, B, N, stride_b, stride_c, c_knn, k, flags, idx_out, dist_out, xx_scratch, st);
-        if (rc != FSG_ERR_UNSUPPORTED) return rc;
-    } else if (!(flags & FSG_KNN_FORCE_ROWS)) {  // production paths
-        // The wave-specialised pipeline (knn_pipe.hip: MFMA producer waves + selection consumer waves over a double-buffered
-        // LDS block) was MEASURED SLOWER than the two-phase kernel (C=3: 85 vs 65 us, C=64: 147 vs 136 us): the selection is
-        // VALU-throughput-bound (~1000 vector ops per query and chunk), so overlapping it with the MFMA phase buys nothing
-        // while 512-candidate chunks double the number of selection passes.  Opt-in (flag 4096) for tests/experiments.
-        static const bool filter_default = getenv("FSG_KNN_FILTER") != nullptr;
-        if ((flags & 16384) || (filter_default && !(flags & 32768))) {   // 16384: filter kernel, 32768: two-phase kernel
-            const int rc = fsg_knn_filter_launch(x, B, N, stride_b, stride_c, c_knn, k, flags, idx_out, dist_out, xx_scratch, st);
-            if (rc != FSG_ERR_UNSUPPORTED) return rc;
-        }
-        if (flags & 4096) {
-            const int rc = fsg_knn_pipe_launch(x, B, N, stride_b, stride_c, c_knn, k, flags, idx_out, dist_out, xx_scratch, st);
-            if (rc != FSG_ERR_UNSUPPORTED) return rc;
-        }
+    // The superseded designs (first matrix-core kernel, flag 8; wave-specialised pipeline, 4096; threshold filter, 16384) are
+    // test / benchmark infrastructure and live in libfsg_hip_experiments.so (csrc/knn_experiments.hip), not in the product.
+    FSG_REQUIRE(!(flags & (FSG_KNN_FORCE_MFMA | 4096 | 16384)),
+                "fsg_knn_dense_f32: flags %d select an experimental kernel: call fsg_knn_experiment_f32 of "
+                "libfsg_hip_experiments.so", flags);
+    if (!(flags & FSG_KNN_FORCE_ROWS)) {  // production path
         const int rc = fsg_knn_rows_mfma_launch(x, B, N, stride_b, stride_c, c_knn, k, flags, idx_out, dist_out, xx_scratch, st);
         if (rc != FSG_ERR_UNSUPPORTED) return rc;
     }

@@ -132,6 +132,9 @@ def deterministic():
 
 
 # ------------------------------------------------------------------ dense kNN (utils/general_utils.py:315)
+_KNN_EXPERIMENT_FLAGS = 8 | 4096 | 16384   # first MFMA design, wave-specialised pipeline, threshold filter
+
+
 def knn_graph(x, k, c_knn=None, fix_diag=True, drop_first=False, return_dist=False, force_rows_kernel=False,
               _debug_flags=0):
     """x: (B,C,N) -> idx (B,N,k) int32 [, dist (B,N,k) fp32].  Channel slices are passed by stride."""
@@ -151,6 +154,15 @@ def knn_graph(x, k, c_knn=None, fix_diag=True, drop_first=False, return_dist=Fal
         (_lib.KNN_FORCE_ROWS if force_rows_kernel else 0) | _debug_flags
     xx = torch.empty(B, N, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
+        if _debug_flags & _KNN_EXPERIMENT_FLAGS:   # superseded designs (tests / tools): libfsg_hip_experiments.so
+            xl = _lib.experiments()
+            rc = xl.fsg_knn_experiment_f32(_p(x), B, N, x.stride(0), x.stride(1), c_knn, k, flags, _p(idx), _p(dist), _p(xx),
+                                           _stream())
+            if rc == 0:
+                return (idx, dist) if return_dist else idx
+            if rc != 3:   # FSG_ERR_UNSUPPORTED: shape outside that kernel's envelope -> the production kernel below
+                raise RuntimeError(xl.fsg_last_error().decode())
+            flags &= ~_KNN_EXPERIMENT_FLAGS
         _lib.call("fsg_knn_dense_f32", _p(x), B, N, x.stride(0), x.stride(1), c_knn, k, flags, _p(idx), _p(dist), _p(xx),
                   _stream())
     return (idx, dist) if return_dist else idx

@@ -32,7 +32,7 @@ extern "C" {
 
 #define FSG_KNN_FORCE_ROWS 4 /* use the general "rows in LDS" kernel even where the MFMA kernel applies (tests) */
 
-#define FSG_KNN_FORCE_MFMA 8 /* use the matrix-core kernel wherever it applies (tests, benchmarks)               */
+#define FSG_KNN_FORCE_MFMA 8 /* (experimental kernels: libfsg_hip_experiments.so only; rejected by libfsg_hip.so)     */
 
 #define FSG_KNN_MAX_K 64
 
