@@ -357,6 +357,62 @@ __global__ __launch_bounds__(WAVES * 64, (STREAM && WAVES == 8) ? 4 : 1) void kn
             }
         }
     };
+    // WIDE operand loads (two-phase chunks, N % 4 == 0): the 1024 loads of four bytes per lane that a workgroup issued per
+    // chunk kept the texture path busy for as long as the matrix cores (in-kernel cycle stamps, tools/knn_phase_cycles.py:
+    // phase A took 2.8x its MFMA time, and with the products switched off the loads alone cost the same again).  A wave
+    // now owns 64 consecutive candidates per group: lane (l4, l15) loads channel 4s + l4 of the FOUR candidates
+    // 4 l15 .. 4 l15 + 3 with one 16-byte load (full 256-byte row segments), and the four "virtual tiles" u = 0..3 (candidate
+    // 4 l15 + u in lane l15) reuse the loaded registers -- a quarter of the load instructions.  No software pipelining: the
+    // other three waves of the SIMD keep the matrix pipe busy while one waits for its loads.
+    const bool wide = !SEG && (N & 3) == 0 && !(flags & 1048576);   // flag 1048576: the four-byte loads (A/B timing)
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(xxb), 0, SEG ? 0 : N * 4, 0x00020000);
+    auto ld4 = [&](f32x4 (&bt)[KS], f32x4 &xt, unsigned col) {
+        const unsigned vo = ((unsigned)l4 * sc32f + col) * 4u;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            bt[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (unsigned)(16 * s) * sc32f, 0));
+        xt = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, col * 4u, 0, 0));
+    };
+    // virtual tile u of the group at chunk column cb: this lane's candidate is column cb + 4 l15 + u of the chunk at c0
+    auto gtile = [&](const float (&bt)[KS], float xc, int c0, int cb, int u) {
+        const int colrel = cb + 4 * l15 + u;
+        float *dst = rows + (l4 * 4) * STRIDE + colrel;
+        if (c0 + cb >= N || (flags & 512)) {   // group beyond the cloud (wave-uniform) / timing ablation of phase A
+#pragma unroll
+            for (int r = 0; r < 8; ++r) dst[((r >> 2) * 16 + (r & 3)) * STRIDE] = INFINITY;
+            return;
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        mma(bt, acc0, acc1);
+        const int drel = c0 + cb - q0;   // wave-uniform: the group's columns drel .. drel+63 against the rows 0 .. 31
+        if ((fix_diag && drel > -64 && drel < QB) || c0 + cb + 64 > N) {
+            const int jc = c0 + colrel;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const f32x4 acc = blk ? acc1 : acc0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int qr = blk * 16 + l4 * 4 + e;
+                    const float tt = xxq[blk][e] - 2.0f * acc[e];
+                    float d = tt + xc;
+                    if (fix_diag && jc == q0 + qr) d = 0.f;
+                    if (jc >= N) d = INFINITY;
+                    dst[(blk * 16 + e) * STRIDE] = d;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const f32x4 acc = blk ? acc1 : acc0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float tt = xxq[blk][e] - 2.0f * acc[e];
+                    dst[(blk * 16 + e) * STRIDE] = tt + xc;
+                }
+            }
+        }
+    };
     // STREAM, epochs after the first chunk: the same products, but each distance is only compared with its row's tau;
     // survivors go to the row's list (slot = LDS atomic on the row's counter; entries beyond LCAP are dropped and the
     // epoch is redone through the distance block)
@@ -459,6 +515,25 @@ __global__ __launch_bounds__(WAVES * 64, (STREAM && WAVES == 8) ? 4 : 1) void kn
                         cb = fast ? chunk_base(done + T / TPC) : c0;
                         tl = T % TPC;
                     };
+                    constexpr bool WIDE_OK = TPC % (4 * WAVES) == 0 && KS <= 16;   // 4 KS operand registers per lane
+                    if (WIDE_OK && wide && !fast) {
+                        // (Requesting the next chunk's operands before the selection phase -- 4 KS + 4 registers held across
+                        // it -- was measured: the allocator spills, 226 vs 79 us.)
+                        constexpr int GPW = WIDE_OK ? TPC / 4 / WAVES : 1;   // groups of 64 candidates per wave and chunk
+#pragma unroll 1
+                        for (int g = 0; g < GPW; ++g) {
+                            const int cb = 64 * (wave + g * WAVES);
+                            f32x4 b4[KS], x4;
+                            ld4(b4, x4, (unsigned)(c0 + cb + 4 * l15));
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                float bu[KS];
+#pragma unroll
+                                for (int s2 = 0; s2 < KS; ++s2) bu[s2] = b4[s2][u];
+                                gtile(bu, x4[u], c0, cb, u);
+                            }
+                        }
+                    } else {
                     float b0[KS], b1[KS], x0, x1;
                     int cb0, tl0, cb1, tl1;
                     where(0, cb0, tl0);
@@ -473,6 +548,7 @@ __global__ __launch_bounds__(WAVES * 64, (STREAM && WAVES == 8) ? 4 : 1) void kn
                             ld(b0, x0, (unsigned)(cb0 + tl0 * 16 + l15));
                         }
                         if (fast) ftile(b1, x1, cb1, tl1); else tile(b1, x1, cb1, tl1);
+                    }
                     }
                 }
                 __syncthreads();

@@ -8,7 +8,7 @@ import fissure_segmentation_amd as fsg
 from golden_util import cloud
 F = fsg.functional
 dev = torch.device("cuda:0")
-VARIANTS = (("two-phase", 0), ("tp-1rowB", 524288), ("tp-noB", 256), ("tp-neither", 768), ("stream", 131072))
+VARIANTS = (("two-phase", 0), ("4-byte loads", 1048576), ("tp-noB", 256), ("tp-neither", 768), ("stream", 131072))
 def med(fn, n=20):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ts = []
