@@ -367,17 +367,16 @@ class _SplitCols(torch.autograd.Function):
     @staticmethod
     @_amp_fwd
     def forward(ctx, w, c0):
-        ctx.c0 = c0
+        ctx.c0, ctx.c1 = c0, w.shape[1] - c0
         return w[:, :c0], w[:, c0:]
 
     @staticmethod
     @_amp_bwd
     def backward(ctx, ga, gb):
-        if ga is None or gb is None:
-            R = (ga if ga is not None else gb).shape[0]
-            dev = (ga if ga is not None else gb).device
-            ga = ga if ga is not None else torch.zeros(R, ctx.c0, dtype=torch.float32, device=dev)
-            gb = gb if gb is not None else torch.zeros(R, 0, dtype=torch.float32, device=dev)
+        if ga is None or gb is None:   # one of the two blocks was not used downstream: its gradient is a zero block
+            ref = ga if ga is not None else gb
+            ga = ga if ga is not None else torch.zeros(ref.shape[0], ctx.c0, dtype=ref.dtype, device=ref.device)
+            gb = gb if gb is not None else torch.zeros(ref.shape[0], ctx.c1, dtype=ref.dtype, device=ref.device)
         return torch.cat([ga, gb], dim=1), None
 
 

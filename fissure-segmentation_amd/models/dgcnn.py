@@ -43,9 +43,11 @@ class ConvBlock(nn.Module):
 
     def forward(self, x):
         for layer in self.layers:
-            if isinstance(layer, nn.modules.conv._ConvNd) and layer.kernel_size[0] == 1 and x.is_cuda:
-                # a 1x1 conv is a plain GEMM over the channel axis: call it as one (rocBLAS) instead of going
-                # through MIOpen's convolution solver search
+            if (isinstance(layer, nn.modules.conv._ConvNd) and x.is_cuda and all(k == 1 for k in layer.kernel_size)
+                    and all(v == 1 for v in layer.stride) and all(v == 0 for v in layer.padding)
+                    and all(v == 1 for v in layer.dilation) and layer.groups == 1):
+                # a plain 1x1 conv (unit stride, no padding / dilation / groups) is a GEMM over the channel axis: call it
+                # as one (rocBLAS) instead of going through MIOpen's convolution solver search; anything else is the conv
                 w = layer.weight.reshape(layer.out_channels, layer.in_channels)
                 y = torch.matmul(w, x.flatten(2))
                 if layer.bias is not None:
