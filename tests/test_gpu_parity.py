@@ -1898,7 +1898,7 @@ def test_bench_two_rank_rehearsal_averages_the_shard_gradients(fsg, device, tmp_
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     prefix = str(tmp_path / "ddp")
-    r = subprocess.run([os.path.join(root, "tools", "ddp_rehearsal.sh"), prefix, "--steps", "3", "--warmup", "1"],
+    r = subprocess.run([os.path.join(root, "tools", "ddp_rehearsal.sh"), prefix, "--steps", "3", "--warmup", "1", "--min-seconds", "0"],
                        cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, open(prefix + ".err").read()[-3000:]
     line = json.loads(open(prefix + ".json").read().strip().splitlines()[-1])
@@ -1936,7 +1936,10 @@ def test_bench_two_rank_rehearsal_averages_the_shard_gradients(fsg, device, tmp_
     got = ck["avg_grad"]
     err = np.linalg.norm(got - want) / np.linalg.norm(want)
     print("\\nDDP rehearsal: averaged gradient vs oracle mean of shards, rel L2 =", err)
-    assert err <= 1e-2      # the oracle builds its own dynamic graphs here: ~1e-4 of the rows pick another k-th neighbour
+    # the oracle builds its own dynamic graphs here (~1e-4 of the rows pick another k-th neighbour at the initial weights;
+    # the check runs after a handful of optimizer steps only: --min-seconds 0 -- further into training the feature space
+    # develops more near-ties and the two graphs drift apart: 4e-2 after ~50 steps)
+    assert err <= 1e-2
 
 
 @pytest.mark.parametrize("B,C,Np,k,flags", [(2, 64, 2048, 20, 131072), (1, 3, 1700, 40, 131072), (2, 16, 520, 20, 131072),
