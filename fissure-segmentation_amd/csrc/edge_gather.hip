@@ -119,3 +119,17 @@ extern "C" int fsg_edge_gather_bwd_bf16(const void *grad_edge, const int32_t *id
     FSG_CHECK_LAUNCH("fsg_edge_gather_bwd_bf16");
     return FSG_OK;
 }
+
+// The reference's create_neighbor_features (models/dgcnn.py:15-36) as ONE entry point: dynamic graph over the first c_knn
+// channels (self included, models/dgcnn.py:26-27) + the (B,2C,N,k) edge tensor.  SURVEY 8(b): fsg_knn_gather_fused_*.
+// (The training path never materialises the edge tensor -- fsg_edgeconv{1,2}_* -- this is the reference-semantic op for
+// callers that want exactly what the reference function returns; the graph is returned too.)
+extern "C" int fsg_knn_gather_fused_f32(const float *x, int B, int C, int N, int k, int c_knn, int32_t *idx_out, float *edge,
+                                        float *xx_scratch, fsg_stream_t stream) {
+    FSG_REQUIRE(x && idx_out && edge && xx_scratch, "fsg_knn_gather_fused_f32: NULL pointer");
+    FSG_REQUIRE(c_knn > 0 && c_knn <= C, "fsg_knn_gather_fused_f32: c_knn=%d outside 1..C=%d", c_knn, C);
+    int rc = fsg_knn_dense_f32(x, B, N, (int64_t)C * N, (int64_t)N, c_knn, k, FSG_KNN_FIX_DIAG, idx_out, nullptr, xx_scratch,
+                               stream);
+    if (rc != FSG_OK) return rc;
+    return fsg_edge_gather_fwd_f32(x, idx_out, edge, B, C, N, k, stream);
+}

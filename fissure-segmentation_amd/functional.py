@@ -200,6 +200,21 @@ class _EdgeGather(torch.autograd.Function):
         return (gx.to(torch.bfloat16) if ctx.half else gx), None
 
 
+def knn_edge_features(x, k, knn_only_over_coords=False):
+    """create_neighbor_features (models/dgcnn.py:15-36) with a dynamic graph, one C-ABI call: x (B,C,N) fp32 ->
+    (edge (B,2C,N,k), idx (B,N,k) int32).  Forward only (the differentiable composition is knn_graph + edge_features)."""
+    _need_gpu(x)
+    xc = _f32c(x)
+    B, C, N = xc.shape
+    idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
+    edge = torch.empty(B, 2 * C, N, k, dtype=torch.float32, device=x.device)
+    xx = torch.empty(B, N, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.call("fsg_knn_gather_fused_f32", _p(xc), B, C, N, k, 3 if knn_only_over_coords else C, _p(idx), _p(edge), _p(xx),
+                  _stream())
+    return edge, idx
+
+
 def edge_features(x, idx):
     """x (B,C,N) fp32, idx (B,N,k) int32/int64 -> (B,2C,N,k) = cat(x_j - x_i, x_i)."""
     _need_gpu(x, idx)

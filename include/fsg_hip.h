@@ -66,6 +66,11 @@ int fsg_edge_gather_fwd_f32(const float *x, const int32_t *idx, float *edge, int
                             int k, fsg_stream_t stream);
 int fsg_edge_gather_bwd_f32(const float *grad_edge, const int32_t *idx, float *grad_x, int B, int C,
                             int N, int k, fsg_stream_t stream);
+/* create_neighbor_features (models/dgcnn.py:15-36) in one call: dynamic kNN graph over channels [0, c_knn) with the point
+ * itself as neighbour 0 (:26-27) + the edge tensor.  x (B,C,N) contiguous; idx_out (B,N,k) int32; edge (B,2C,N,k);
+ * xx_scratch (B,N) fp32.  (Reference-semantic op: the training path uses the fused fsg_edgeconv* entries instead.) */
+int fsg_knn_gather_fused_f32(const float *x, int B, int C, int N, int k, int c_knn, int32_t *idx_out, float *edge,
+                             float *xx_scratch, fsg_stream_t stream);
 /* bf16 storage of the same op (BASELINE configs 3-5; SURVEY 8d counts the edge tensor at 2 bytes per element):
  * x, edge and grad_edge are bf16 (raw 16-bit patterns), the difference is formed in fp32 and rounded once;
  * grad_x is accumulated and returned in FP32 (B,C,N). */

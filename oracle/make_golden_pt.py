@@ -196,6 +196,17 @@ def main():
         y = net(T(x))
     save("pt_compat_c3_eval", seed=802, logits=y.numpy())
 
+    # ---- DGCNNReg (models/dgcnn.py:165-209): regression head on the global feature, (B, out, 1); 4 clouds so that the
+    #      head's train-mode BatchNorm sees more than two rows
+    net = fill_state_dict(r_dgcnn.DGCNNReg(k=8, in_features=3, num_classes=6), 871).train()
+    x = cloud(1871, 4, 3, 128)
+    xt = T(x).requires_grad_(True)
+    y = net(xt)
+    g = np.random.default_rng(2871).standard_normal(tuple(y.shape)).astype(np.float32)
+    y.backward(T(g))
+    save("dgcnnreg", seed=871, out=y.detach().numpy(), grad_x=xt.grad.numpy(),
+         keys=np.array(list(net.state_dict().keys())), **pack_grads(net, limit=0))
+
     # ---- predict_full_pointcloud (models/point_seg_net.py:21-48) on the reference's DGCNNSeg, eval mode as in
     #      train.py:test; the randperm rows are recorded for replay
     net = fill_state_dict(r_dgcnn.DGCNNSeg(k=8, in_features=3, num_classes=4), 851).eval()

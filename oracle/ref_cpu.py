@@ -207,6 +207,30 @@ class DGCNNSeg(nn.Module):
         return self.segmentation(torch.cat([ml, g.expand(-1, -1, ml.shape[-1])], 1))
 
 
+class DGCNNReg(nn.Module):
+    """models/dgcnn.py:165-209: four one-layer EdgeConvs 64/64/128/256, global max feature, regression head (B,out,1)."""
+
+    def __init__(self, k, in_features, num_classes, dynamic=True):
+        super().__init__()
+        self.k, self.dynamic, self.num_classes = k, dynamic, num_classes
+        self.ec1 = EdgeConv(in_features, [64], k, first_layer=True)
+        self.ec2 = EdgeConv(64, [64], k)
+        self.ec3 = EdgeConv(64, [128], k)
+        self.ec4 = EdgeConv(128, [256], k)
+        self.global_feature = nn.Sequential(Block(512, 1024, dim=1), nn.AdaptiveMaxPool1d(1))
+        self.regression = nn.Sequential(Block(1024, 512, dim=1), Block(512, 256, dim=1),
+                                        Block(256, num_classes, dim=1, last=True))
+        self.apply(init_weights)
+
+    def forward(self, x):
+        graph = None if self.dynamic else knn(x[:, :3], self.k, self_loop=False)
+        feats = []
+        for ec in (self.ec1, self.ec2, self.ec3, self.ec4):
+            x = ec(x, graph)
+            feats.append(x)
+        return self.regression(self.global_feature(torch.cat(feats, 1)))
+
+
 # ----------------------------------------------------------------------------- PointNet (config 1)
 class MLPBlock(nn.Module):
     """models/point_net.py:11-30 (LeakyReLU default slope 0.01)."""

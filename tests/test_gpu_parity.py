@@ -2057,3 +2057,29 @@ def test_dgcnnseg_bf16_mode_vs_fp32_oracle(fsg, device, monkeypatch, how):
     cos = float(ga @ gb / (np.linalg.norm(ga) * np.linalg.norm(gb)))
     print("\nBF16", how, "logit error mean", float(d.mean()), "max", float(d.max()), "grad_x cosine", cos)
     assert 1e-6 < float(d.max()) <= 0.15 and float(d.mean()) <= 2.5e-2 and cos >= 0.9
+
+
+@pytest.mark.parametrize("B,C,Np,k,coords", [(2, 5, 300, 12, False), (1, 64, 1024, 20, False), (2, 15, 257, 8, True)])
+def test_knn_gather_fused_entry_point(fsg, device, B, C, Np, k, coords):
+    """fsg_knn_gather_fused_f32 = the reference's create_neighbor_features with a dynamic graph (models/dgcnn.py:15-36):
+    graph bit-exact vs the C oracle, edge tensor exact vs the oracle's edge features on that graph"""
+    x = cloud(3000 + C, B, C, Np)
+    edge, idx = fsg.functional.knn_edge_features(G(x, device), k, knn_only_over_coords=coords)
+    idx_o, _ = c_api.knn_dense(x, k, c_knn=3 if coords else None, fix_diag=True)
+    assert np.array_equal(N(idx), idx_o)
+    assert np.array_equal(N(edge), c_api.edge_features(x, idx_o))
+
+
+def test_dgcnnreg_vs_reference_golden(fsg, device):
+    """DGCNNReg (models/dgcnn.py:165-209) against the reference's own forward / backward: output 2e-4 (the regression head
+    normalises FOUR rows per channel in train mode), gradients in norm"""
+    from fissure_segmentation_amd.models.dgcnn import DGCNNReg
+    g = load("dgcnnreg")
+    net = fill_state_dict(DGCNNReg(k=8, in_features=3, num_classes=6), 871)
+    assert [str(s) for s in g["keys"]] == list(net.state_dict().keys())
+    net = net.to(device).train()
+    y, gx = run_model(net, cloud(1871, 4, 3, 128), 2871, device)
+    assert y.shape == (4, 6, 1)
+    np.testing.assert_allclose(N(y), g["out"], rtol=2e-4, atol=2e-4)
+    assert np.linalg.norm(N(gx) - g["grad_x"]) <= 2e-2 * np.linalg.norm(g["grad_x"])
+    _check_packed_grads(net, g, 2e-2, 1e-3)

@@ -336,3 +336,17 @@ def test_farthest_point_sampling_restatement_vs_reference():
         sub, ind = ref_cpu.farthest_point_sampling(T(pts), m, int(ref_ind[0]))
         assert np.array_equal(ind.numpy(), ref_ind), i
         assert np.array_equal(sub.numpy(), g[f"pts{i}"]), i
+
+
+def test_dgcnnreg_restatement_vs_reference():
+    """models/dgcnn.py:165-209 (DGCNNReg: four one-layer EdgeConvs, global max feature, regression head)"""
+    g = load("dgcnnreg")
+    net = fill_state_dict(ref_cpu.DGCNNReg(k=8, in_features=3, num_classes=6), 871).train()
+    assert [str(s) for s in g["keys"]] == list(net.state_dict().keys())
+    xt = T(cloud(1871, 4, 3, 128)).requires_grad_(True)
+    y = net(xt)
+    gr = np.random.default_rng(2871).standard_normal(tuple(y.shape)).astype(np.float32)
+    y.backward(T(gr))
+    np.testing.assert_allclose(y.detach().numpy(), g["out"], **TOL)
+    assert np.linalg.norm(xt.grad.numpy() - g["grad_x"]) <= 1e-3 * np.linalg.norm(g["grad_x"])
+    check_grads_packed(net, g, rtol=2e-3)
