@@ -41,10 +41,12 @@ WORKLOADS = {
     # SURVEY 8(d) secondary rows
     "c2s": (32, 2048, 40, "DGCNN-seg N=2048 k=40 STATIC graph, 32 clouds/GPU, fp32 (bash_scripts/run_dgcnn_seg_experiments.sh:17)"),
     "c3f": (8, 2048, None, "PointTransformer seg N=2048, 8 clouds/GPU, in_features=128 (3 coordinates + 125 features), fp32"),
+    "c3b": (32, 2048, None, "PointTransformer seg N=2048, 32 clouds/GPU (bash_scripts/run_PointTransformer_experiments.sh:5), fp32"),
 }
 METRIC = {"c2": "points/sec fwd+bwd DGCNN-seg N=2048 k=20", "c4": "points/sec fwd+bwd DGCNN-seg N=8192 k=40",
           "c3": "points/sec fwd+bwd PointTransformer-seg N=2048", "c5": "points/sec fwd+bwd PC-AE FoldingNet+Chamfer N=4096",
-          "c2s": "points/sec fwd+bwd DGCNN-seg N=2048 k=40 static", "c3f": "points/sec fwd+bwd PointTransformer-seg N=2048 128 features"}
+          "c2s": "points/sec fwd+bwd DGCNN-seg N=2048 k=40 static", "c3f": "points/sec fwd+bwd PointTransformer-seg N=2048 128 features",
+          "c3b": "points/sec fwd+bwd PointTransformer-seg N=2048 batch 32"}
 EDGE_LAYERS_C = (3, 64, 64)  # input channels of ec1/ec2/ec3 (models/dgcnn.py:130-132 of the reference)
 
 
@@ -188,7 +190,7 @@ def main():
     features = 128 if args.workload == "c3f" else 3
     if dgcnn:
         net = DGCNNSeg(k=k, in_features=3, num_classes=classes, dynamic=args.workload != "c2s").to(device).train()
-    elif args.workload in ("c3", "c3f"):
+    elif args.workload in ("c3", "c3f", "c3b"):
         from fissure_segmentation_amd.models.pointtransformer.seg_model import PointTransformerCompatibility
         net = PointTransformerCompatibility(features, classes).to(device).train()
     else:
@@ -467,7 +469,7 @@ def main():
                 "frac_vs_own_minimal_bytes": round(min_bytes / t_best / 1e9 / HBM_PEAK_GBS, 4),
                 "traffic": tr if isinstance(tr, (int, float)) else None,
                 "target": "north_star: >= 0.40 of the HBM roofline on the reference-materialised bytes"}
-        if args.workload in ("c3", "c3f"):
+        if args.workload in ("c3", "c3f", "c3b"):
             # dominant kernel of the PointTransformer step: the fused vector-attention layer, backward (18 launches).
             # Algorithmic bytes = the tensors the reference materialises per layer (seg_model.py:37-52): grouped keys
             # (n,ns,3+c), grouped values (n,ns,c), p_r (n,ns,c), w before / after linear_w ((n,ns,c) + 2 (n,ns,c/8)), out;
@@ -508,7 +510,7 @@ def main():
                "roofline": roofline, "roofline_group_hbm": roofline_group,
                "entry_points": {n: {k2: round(v, 2) for k2, v in d.items()} for n, d in sorted(per_kernel.items())}}
         if not dgcnn:
-            out["config"]["step"] = ("fwd + cross-entropy + generalised Dice + bwd + Adam" if args.workload in ("c3", "c3f")
+            out["config"]["step"] = ("fwd + cross-entropy + generalised Dice + bwd + Adam" if args.workload in ("c3", "c3f", "c3b")
                                      else "fwd + Chamfer(reconstruction, input) + bwd + Adam")
         if world == 1 and not args.no_cpu_baseline and dgcnn and args.workload != "c2s":
             out["cpu_baseline"] = cpu_baseline(B, N, k, classes)

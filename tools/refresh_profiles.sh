@@ -7,7 +7,7 @@ out=$R/gpurun_out/refresh
 rm -rf $out; mkdir -p $out
 cd $R
 python3 bench.py > $out/bench_c2.json 2> $out/bench_c2.err
-for w in c4 c3 c5 c2s c3f; do python3 bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline >> $out/bench_other.jsonl 2>> $out/bench_other.err; done
+for w in c4 c3 c5 c2s c3f c3b; do python3 bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline >> $out/bench_other.jsonl 2>> $out/bench_other.err; done
 python3 bench.py --steps 20 --warmup 3 --inputs surface --no-cpu-baseline >> $out/bench_other.jsonl 2>> $out/bench_other.err
 python3 bench.py --workload c4 --dtype f32 --steps 20 --warmup 3 --no-cpu-baseline >> $out/bench_other.jsonl 2>> $out/bench_other.err
 python3 tools/bench_infer.py >> $out/bench_other.jsonl 2>> $out/bench_other.err
