@@ -115,6 +115,39 @@ __global__ __launch_bounds__(BLOCK) void knn_dense_rows_kernel(
 
 int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k,
                              int flags, int32_t *idx_out, float *dist_out, float *xx_scratch, hipStream_t st);
+size_t fsg_knn_split_workspace_bytes(int B, int N, int c_knn);
+int fsg_knn_split_launch(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k, int flags,
+                         int32_t *idx_out, float *dist_out, void *ws, size_t ws_bytes, hipStream_t st);
+
+extern "C" size_t fsg_knn_dense_workspace_bytes(int B, int N, int c_knn) {
+    if (B <= 0 || N <= 0 || c_knn <= 0) return 0;
+    const size_t xxb = sizeof(float) * (size_t)B * N, sp = fsg_knn_split_workspace_bytes(B, N, c_knn);
+    return sp > xxb ? sp : xxb;
+}
+
+// Same contract as fsg_knn_dense_f32 with a caller-owned workspace of fsg_knn_dense_workspace_bytes(B, N, c_knn) bytes:
+// inside its envelope the coarse-sweep + exact-refine kernel (knn_split.hip) builds the graph, everything else (and
+// flag 2097152, A/B timing and cross-checks) goes to fsg_knn_dense_f32 with the workspace as its squared-norm scratch.
+extern "C" int fsg_knn_dense_ws_f32(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k,
+                                    int flags, int32_t *idx_out, float *dist_out, void *workspace,
+                                    size_t workspace_bytes, fsg_stream_t stream) {
+    const int drop = (flags & FSG_KNN_DROP_FIRST) ? 1 : 0;
+    FSG_REQUIRE(x && idx_out, "fsg_knn_dense_ws_f32: NULL pointer");
+    FSG_REQUIRE(B >= 0 && N > 0 && c_knn > 0, "fsg_knn_dense_ws_f32: bad shape B=%d N=%d c_knn=%d", B, N, c_knn);
+    FSG_REQUIRE(k >= 1 && k + drop <= N && k + drop <= FSG_KNN_MAX_K,
+                "fsg_knn_dense_ws_f32: need 1 <= k and k+drop <= min(N, %d); got k=%d N=%d", FSG_KNN_MAX_K, k, N);
+    FSG_REQUIRE(workspace == nullptr || workspace_bytes >= sizeof(float) * (size_t)B * N,
+                "fsg_knn_dense_ws_f32: workspace of %zu bytes is smaller than the (B,N) squared norms", workspace_bytes);
+    if (B == 0) return FSG_OK;
+    if (workspace && !(flags & (2097152 | FSG_KNN_FORCE_ROWS | FSG_KNN_FORCE_MFMA | 4096 | 16384 | 131072 | 2048 | 8192))) {
+        const int rc = fsg_knn_split_launch(x, B, N, stride_b, stride_c, c_knn, k, flags, idx_out, dist_out, workspace,
+                                            workspace_bytes, (hipStream_t)stream);
+        if (rc != FSG_ERR_UNSUPPORTED) return rc;
+    }
+    return fsg_knn_dense_f32(x, B, N, stride_b, stride_c, c_knn, k, flags & ~2097152, idx_out, dist_out,
+                             static_cast<float *>(workspace), stream);
+}
+
 extern "C" int fsg_knn_dense_f32(const float *x, int B, int N, int64_t stride_b, int64_t stride_c,
                                  int c_knn, int k, int flags, int32_t *idx_out, float *dist_out,
                                  float *xx_scratch, fsg_stream_t stream) {

@@ -1,0 +1,765 @@
+// Dense kNN graph build, "coarse sweep + exact refine" kernel behind fsg_knn_dense_ws_f32
+// (1024 <= N <= 8192, c_knn <= 64, k + drop <= 64).  Replaces utils/general_utils.py:43-53,315-327 like the two-phase
+// kernel of knn_rows_mfma.hip and returns the SAME bits (indices and distances of oracle/fsg_oracle.c): the matrix
+// cores only nominate candidates, every distance that is ranked or returned is the oracle's fp32 fma chain.
+//
+//   prep    one pass over the cloud: squared norms (the oracle's chain), a point-major fp32 copy (rows for the refine) and
+//           the points split into two bf16 pieces x = hi + lo + r, |r| <= 2^-16 |x| (round-to-nearest-even done in integer
+//           arithmetic, so the bound does not depend on a conversion instruction), stored in the register image of
+//           v_mfma_f32_32x32x16_bf16 operands (one 1-KiB block per 32 points, k-step and piece: a wave loads an operand
+//           with one fully coalesced 16-byte load per lane).  The query image carries -2x.
+//   sweep 1 a workgroup owns 64 queries (two 32-column blocks, resident as B operands); its 8 waves take the candidate
+//           tiles (32 rows, A operand) round-robin.  s~(i,j) = xx_j - 2 (hi_i.hi_j + hi_i.lo_j + lo_i.hi_j) comes out of
+//           three bf16 MFMAs per k-step with xx_j as the accumulator's initial value.  Lane (n, h) holds 16 candidates of
+//           ONE query per tile, so the running minimum of a tile group is a per-lane register: 64 group minima per query.
+//   tau     K-th smallest of the 64 group minima (distinct candidates, so at least K candidates have s~ <= tau);
+//           with |s~ - F| <= eps_i for every candidate (F = the oracle's distance minus the query's own squared norm, see
+//           the bound below) the K-th smallest oracle distance is <= tau + eps_i and every true neighbour has
+//           s~ <= tau + 2 eps_i.
+//   sweep 2 the same MFMAs again (bit-identical values); a lane appends the candidates with s~ <= tau + 2 eps to its
+//           OWN list in LDS (no atomics: one list per query, wave and lane half), ~1.2 K per query in total.
+//   refine  one wave per query: the oracle's distance d = (xx_i - 2 dot) + xx_j, dot = channel-ordered fmaf chain from +0,
+//           for every listed candidate (rows from the point-major copy), (d, j) keys ranked by counting, ranks < K written.
+//   slow    a query whose lists overflow (massive ties, fewer than K finite candidates) is redone by the whole workgroup
+//           from the oracle's distances of ALL candidates: exact, slow, rare.
+//
+// Error bound (n_i = |x_i|, R = max_j |x_j|, both rounded up):
+//   dropped product terms lo.lo + r.(..)   <= 3.1 * 2^-16 n_i R, times the factor 2          -> 1.0e-4 n_i R
+//   fp32 accumulation of 193 terms in the matrix core, any order, truncation allowed          -> 2.6e-5 (R^2 + 2.1 n_i R)
+//   the oracle's own fp32 chains against real arithmetic (dot, both norms, two roundings)     -> 9.0e-6 (n_i + R)^2
+#include "fsg_common.h"
+
+// debug statistics (flag 33554432): [0] queries refined, [1] their listed candidates, [2] queries on the slow path,
+// [3] largest list total
+__device__ unsigned long long fsg_knn_split_stats[4];
+extern "C" int fsg_debug_knn_split_stats(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fsg_knn_split_stats), sizeof(fsg_knn_split_stats)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[4] = {0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(fsg_knn_split_stats), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+
+// cycle stamps (flag 268435456): [workgroup (first 256)][wave][16] shader-clock ticks at the phase boundaries
+__device__ unsigned long long fsg_knn_split_stamps[256 * 8 * 16];
+extern "C" int fsg_debug_knn_split_stamps(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fsg_knn_split_stamps), sizeof(fsg_knn_split_stamps)) != hipSuccess;
+}
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+
+constexpr int QB = 64;        // queries per workgroup
+constexpr int WAVES = 8;
+
+__device__ __forceinline__ unsigned f2o(float d) {
+    const unsigned u = __float_as_uint(d);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float o2f(unsigned k) {
+    return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+// round-to-nearest-even bf16 of a finite float, in integer arithmetic
+__device__ __forceinline__ unsigned bf16_rne(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float bf16_f(unsigned h) { return __uint_as_float(h << 16); }
+
+struct Split { unsigned hi, lo; };
+__device__ __forceinline__ Split split2(float v) {
+    Split s;
+    s.hi = bf16_rne(v);
+    s.lo = bf16_rne(v - bf16_f(s.hi));   // v - hi is exact in fp32
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- prep
+// grid (Np / 32, B), 256 threads: 32 points = one operand tile.
+// KS = k-steps of 16 channels; PACK (c_knn <= 4): all three products share ONE k-step:
+//   k-slots 0-3 hi.qhi, 4-7 hi.qlo, 8-11 lo.qhi, 12-15 zero.
+template <int KS, bool PACK>
+__global__ __launch_bounds__(256) void knn_split_prep_kernel(const float *__restrict__ x, int N, int Np, long sb, long sc,
+                                                             int c_knn, float *__restrict__ xx, float *__restrict__ xt,
+                                                             u32x4 *__restrict__ cand, u32x4 *__restrict__ qry) {
+    constexpr int CP = PACK ? 4 : 16 * KS;
+    __shared__ float slab[CP][33];
+    const int tid = threadIdx.x, b = blockIdx.y, tile = blockIdx.x, j0 = tile * 32;
+    const float *xb = x + (long)b * sb;
+    {
+        const int pt = tid & 31;
+#pragma unroll
+        for (int c = tid >> 5; c < CP; c += 8)
+            slab[c][pt] = (c < c_knn && j0 + pt < N) ? xb[c * sc + j0 + pt] : 0.f;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float a = 0.f;
+        for (int c = 0; c < c_knn; ++c) a = __builtin_fmaf(slab[c][tid], slab[c][tid], a);
+        xx[(long)b * Np + j0 + tid] = (j0 + tid < N) ? a : INFINITY;
+    }
+    for (int e = tid; e < 32 * (CP / 4); e += 256) {
+        const int pt = e / (CP / 4), c4 = e % (CP / 4);
+        f32x4 v = {slab[4 * c4][pt], slab[4 * c4 + 1][pt], slab[4 * c4 + 2][pt], slab[4 * c4 + 3][pt]};
+        *reinterpret_cast<f32x4 *>(xt + ((long)b * Np + j0 + pt) * CP + 4 * c4) = v;
+    }
+    const long T = Np / 32;
+    if (PACK) {
+        if (tid >= 64 && tid < 128) {     // (the first wave carries the norm chain)
+            const int lane = tid & 63, m = lane & 31, h = lane >> 5;
+            unsigned hi[4], lo[4], qhi[4], qlo[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = slab[i][m];
+                const Split s = split2(v), q = split2(-2.0f * v);
+                hi[i] = s.hi; lo[i] = s.lo; qhi[i] = q.hi; qlo[i] = q.lo;
+            }
+            u32x4 c, q;
+            if (h == 0) {
+                c = u32x4{hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16)};
+                q = u32x4{qhi[0] | (qhi[1] << 16), qhi[2] | (qhi[3] << 16), qlo[0] | (qlo[1] << 16), qlo[2] | (qlo[3] << 16)};
+            } else {
+                c = u32x4{lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), 0u, 0u};
+                q = u32x4{qhi[0] | (qhi[1] << 16), qhi[2] | (qhi[3] << 16), 0u, 0u};
+            }
+            const long o = ((long)b * T + tile) * 64 + lane;
+            cand[o] = c;
+            qry[o] = q;
+        }
+    } else {
+        for (int e = tid; e < KS * 2 * 64; e += 256) {
+            const int lane = e & 63, part = (e >> 6) & 1, s = e >> 7;
+            const int m = lane & 31, h = lane >> 5;
+            unsigned cw[8], qw[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float v = slab[16 * s + 8 * h + i][m];
+                const Split sp = split2(v), sq = split2(-2.0f * v);
+                cw[i] = part ? sp.lo : sp.hi;
+                qw[i] = part ? sq.lo : sq.hi;
+            }
+            const long o = ((((long)b * T + tile) * KS + s) * 2 + part) * 64 + lane;
+            cand[o] = u32x4{cw[0] | (cw[1] << 16), cw[2] | (cw[3] << 16), cw[4] | (cw[5] << 16), cw[6] | (cw[7] << 16)};
+            qry[o] = u32x4{qw[0] | (qw[1] << 16), qw[2] | (qw[3] << 16), qw[4] | (qw[5] << 16), qw[6] | (qw[7] << 16)};
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- main
+template <int KS, bool PACK>
+struct Ops {
+    bf16x8 hi[PACK ? 1 : KS], lo[PACK ? 1 : KS];
+};
+
+// m = 2 m + (a <= thr): sixteen of these leave bit e = (a[e] <= thr) when fed e = 15 .. 0.  Plain C on purpose: an inline-asm
+// consumer of MFMA results is invisible to the compiler's hazard recognizer (no wait states between the matrix
+// instruction and the read: stale accumulators, measured as lost neighbours).
+__device__ __forceinline__ unsigned push_le(unsigned m, float a, float thr) { return m + m + (a <= thr ? 1u : 0u); }
+
+// inclusive prefix sum over the 64 lanes on the DPP network (as knn_rows_mfma.hip)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+template <int KS, bool PACK>
+__global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *__restrict__ xx, const float *__restrict__ xt,
+                                                                  const u32x4 *__restrict__ cand,
+                                                                  const u32x4 *__restrict__ qry, int N, int Np, int k,
+                                                                  int flags, int PC, int32_t *__restrict__ idx_out,
+                                                                  float *__restrict__ dist_out) {
+    constexpr int CP = PACK ? 4 : 16 * KS;
+    constexpr int CPQ = CP + 4;
+    constexpr int NOP = PACK ? 1 : KS;     // operand blocks per piece and tile
+    constexpr int OPT = PACK ? 1 : 2 * KS; // 1-KiB operand blocks per tile
+    constexpr int QW = QB / WAVES;         // queries a wave refines
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int T = Np / 32;                       // candidate tiles
+    const int RSW = T + 1;                       // bitmap row stride in 32-bit words (one word per tile + 1: no bank conflicts)
+    // U region: the squared norms and the bitmaps during the sweeps, the row stage of the refine afterwards
+    float *xs = reinterpret_cast<float *>(smem);                              // [Np] squared norms (sweeps only)
+    unsigned *bm = reinterpret_cast<unsigned *>(xs + Np);                     // [QB][RSW] survivor bitmaps (sweep 2)
+    float *mins = reinterpret_cast<float *>(bm);                              // [QB][64] group minima (sweep 1), same storage
+    float *stage = reinterpret_cast<float *>(smem);                           // [WAVES][32][CPQ] candidate rows (refine)
+    float *dl = reinterpret_cast<float *>(smem);                              // slow path: [N] distances
+    const size_t usz = max((size_t)4 * Np + 4 * (((size_t)QB * RSW + 1) & ~(size_t)1), (size_t)4 * WAVES * 32 * CPQ);
+    u64 *plist = reinterpret_cast<u64 *>(smem + ((usz + 15) & ~(size_t)15)); // [WAVES][PC] candidates, then keys, of a batch
+    float *qrow = reinterpret_cast<float *>(plist + WAVES * PC);              // [QB][CPQ]: query row, then its squared norm
+    float *thrL = qrow + QB * CPQ;                                            // [QB]
+    int *slowq = reinterpret_cast<int *>(thrL + QB);                          // [QB]
+    float *red = reinterpret_cast<float *>(slowq + QB);                       // [16]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, h = lane >> 5;
+    const bool stamps = (flags & 268435456) != 0;
+    auto stamp = [&](int i) {
+        if (stamps) {
+            const unsigned wg = blockIdx.x + gridDim.x * blockIdx.y;
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (wg < 256 && lane == 0) fsg_knn_split_stamps[(wg * 8 + wave) * 16 + i] = t;
+        }
+    };
+    stamp(0);
+    int b = blockIdx.y, q0 = blockIdx.x * QB;
+    {   // XCD-aware placement (as knn_rows_mfma.hip): XCD x owns a contiguous eighth of the (cloud, tile) space
+        const unsigned L = blockIdx.x + gridDim.x * blockIdx.y, total = gridDim.x * gridDim.y;
+        if ((total & 7u) == 0 && !(flags & 65536)) {
+            const unsigned V = (L & 7u) * (total >> 3) + (L >> 3);
+            b = (int)(V / gridDim.x);
+            q0 = (int)(V % gridDim.x) * QB;
+        }
+    }
+    const int drop = (flags & FSG_KNN_DROP_FIRST) ? 1 : 0;
+    const int KK = k + drop;
+    const bool fix_diag = (flags & FSG_KNN_FIX_DIAG) != 0;
+    const int TW = (T - wave + WAVES - 1) / WAVES;   // tiles of this wave (round-robin: tile = wave + 8 i)
+    const int G = ((T + WAVES - 1) / WAVES + 3) / 4; // tiles per minimum group (the same for every wave)
+    const float *xxb = xx + (long)b * Np;
+    const float *xtb = xt + (long)b * Np * CP;
+    const u32x4 *candb = cand + (long)b * T * OPT * 64 + lane;
+    const u32x4 *qryb = qry + (long)b * T * OPT * 64 + lane;
+
+    // ---- setup: norms into LDS (+ their maximum), the workgroup's query rows, the query operands
+    float mx = 0.f;
+    for (int j = tid * 4; j < Np; j += WAVES * 64 * 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(xxb + j);
+        *reinterpret_cast<f32x4 *>(xs + j) = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = (j + e < N) ? fmaxf(mx, v[e]) : mx;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (lane == 0) red[wave] = mx;
+    for (int e = tid; e < QB * (CP / 4); e += WAVES * 64) {
+        const int pt = e / (CP / 4), c4 = e % (CP / 4);
+        *reinterpret_cast<f32x4 *>(qrow + pt * CPQ + 4 * c4) =
+            *reinterpret_cast<const f32x4 *>(xtb + (long)(q0 + pt) * CP + 4 * c4);
+    }
+    if (tid < QB) {
+        slowq[tid] = 0;
+        qrow[tid * CPQ + CP] = xxb[q0 + tid];
+    }
+#pragma unroll
+    for (int bk = 0; bk < 2; ++bk)      // this thread's eight minimum slots: groups without a tile stay +inf
+#pragma unroll
+        for (int g = 0; g < 4; ++g) mins[(32 * bk + n) * 64 + wave * 8 + h * 4 + g] = INFINITY;
+    Ops<KS, PACK> qo[2];
+#pragma unroll
+    for (int bk = 0; bk < 2; ++bk) {
+        const u32x4 *p = qryb + (long)(q0 / 32 + bk) * OPT * 64;
+#pragma unroll
+        for (int s = 0; s < NOP; ++s) {
+            qo[bk].hi[s] = __builtin_bit_cast(bf16x8, p[(PACK ? 0 : 2 * s) * 64]);
+            if (!PACK) qo[bk].lo[s] = __builtin_bit_cast(bf16x8, p[(2 * s + 1) * 64]);
+        }
+    }
+
+    auto load_tile = [&](Ops<KS, PACK> &c, int t) {
+        const u32x4 *p = candb + (long)t * OPT * 64;
+#pragma unroll
+        for (int s = 0; s < NOP; ++s) {
+            c.hi[s] = __builtin_bit_cast(bf16x8, p[(PACK ? 0 : 2 * s) * 64]);
+            if (!PACK) c.lo[s] = __builtin_bit_cast(bf16x8, p[(2 * s + 1) * 64]);
+        }
+    };
+    // s~ of the tile's 32 candidates (rows 8 (e/4) + 4 h + e%4) against the 32 queries of block bk (column n)
+    auto scores = [&](const Ops<KS, PACK> &c, const f32x16 &init, int bk) {
+        f32x16 acc = init;
+        if (flags & 536870912) return acc;   // timing ablation: no matrix work
+#pragma unroll
+        for (int s = 0; s < NOP; ++s) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.hi[s], qo[bk].hi[s], acc, 0, 0, 0);
+            if (!PACK) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.hi[s], qo[bk].lo[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.lo[s], qo[bk].hi[s], acc, 0, 0, 0);
+            }
+        }
+        return acc;
+    };
+    auto load_init = [&](int t) {
+        f32x16 r;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(xs + 32 * t + 8 * g4 + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[4 * g4 + e] = v[e];
+        }
+        return r;
+    };
+    // one sweep over the wave's tiles: operands through a ring of three register sets, requested two tiles ahead (a
+    // wave's tile is ~0.3 us of matrix work, an L2 round trip under load several times that); f(scores0, scores1, t, i)
+    // Every workgroup of a cloud starts its sweep at a different tile (rotation by the workgroup's position): 32 workgroups
+    // walking the same tiles in lockstep would all pull the same cache lines out of the same L2 channels at once.
+    const int rot = (int)((blockIdx.x * 5u) % (unsigned)(T / WAVES > 0 ? T / WAVES : 1));
+    auto tile_of = [&](int i) {   // i-th tile of this wave: wave + 8 ((i + rot) mod TW)
+        int ii = i + rot;
+        if (ii >= TW) ii -= TW;
+        return wave + WAVES * ii;
+    };
+    auto sweep = [&](auto &&f) {
+        Ops<KS, PACK> ring[3];
+        f32x16 init[3];
+        const bool noload = (flags & 134217728) != 0;   // timing ablation: the first tile's operands for every tile
+        if (TW > 0) {
+            load_tile(ring[0], tile_of(0));
+            init[0] = load_init(tile_of(0));
+        }
+        if (TW > 1) load_tile(ring[1], tile_of(noload ? 0 : 1));
+        if (noload) load_tile(ring[2], tile_of(0));
+        int gi = 0, g = 0;   // tiles in the open minimum group, its index
+        for (int i0 = 0; i0 < TW; i0 += 3) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int i = i0 + u;
+                if (i < TW) {
+                    const int t = tile_of(i);
+                    if (i + 2 < TW && !noload) load_tile(ring[(u + 2) % 3], tile_of(i + 2));
+                    if (i + 1 < TW) init[(u + 1) % 3] = load_init(tile_of(i + 1));   // a tile ahead: no LDS wait in front of the chain
+                    // the tile's matrix chain runs at raised priority: the two waves of a SIMD then take the matrix pipe in
+                    // turns instead of interleaving their chains (flag 1073741824: off, A/B timing)
+                    ++gi;
+                    const bool gend = gi == G || i + 1 == TW;   // wave-uniform: the minimum group is complete
+#pragma unroll
+                    for (int bk = 0; bk < 2; ++bk) {
+                        if (!(flags & 1073741824)) __builtin_amdgcn_s_setprio(3);
+                        const f32x16 a = scores(ring[u], init[u], bk);
+                        if (!(flags & 1073741824)) __builtin_amdgcn_s_setprio(0);
+                        f(a, bk, t, g, gend);
+                    }
+                    if (gend) { ++g; gi = 0; }
+                }
+            }
+        }
+    };
+    stamp(1);
+    __syncthreads();   // xs, red, qrow
+    stamp(2);
+    if (flags & 67108864) return;   // timing ablation: setup only
+
+    // ---------------------------------------------------------------- sweep 1: group minima
+    {
+        float run[2] = {INFINITY, INFINITY};
+        float *mp[2] = {mins + n * 64 + wave * 8 + h * 4, mins + (32 + n) * 64 + wave * 8 + h * 4};
+        sweep([&](const f32x16 &a, int bk, int t, int g, bool gend) {
+            (void)t;
+            float r = run[bk];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) r = fminf(r, a[e]);
+            if (gend) {
+                mp[bk][g] = r;
+                r = INFINITY;
+            }
+            run[bk] = r;
+        });
+    }
+    stamp(3);
+    __syncthreads();
+    stamp(4);
+    if (flags & 8388608) return;    // timing ablation: setup + sweep 1
+
+    // ---------------------------------------------------------------- tau and the acceptance bound per query
+    {
+        float R2 = red[0];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) R2 = fmaxf(R2, red[w]);
+        const float R = sqrtf(R2) * 1.0001f;
+        // eight lanes per query, eight group minima per lane: the K-th smallest of the 64 by bisection on the key bits with
+        // the counts summed over the eight lanes on the DPP network (no scalar round trips: the ballot version of this
+        // search spent 2000 cycles per query on VALU -> SALU dependencies)
+        const int q = wave * QW + (lane >> 3);
+        const float xq = (q0 + q < N) ? xs[q0 + q] : 0.f;
+        const f32x4 va = *reinterpret_cast<const f32x4 *>(mins + q * 64 + 8 * (lane & 7));
+        const f32x4 vb = *reinterpret_cast<const f32x4 *>(mins + q * 64 + 8 * (lane & 7) + 4);
+        unsigned key[8];
+        // the search runs on distances (minimum + the query's norm): rounding tau up by 2^-11 of a DISTANCE is harmless,
+        // 2^-11 of s~ = d - |x_i|^2 would not be for clouds far from the origin
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            key[e] = f2o(va[e] + xq);
+            key[4 + e] = f2o(vb[e] + xq);
+        }
+        unsigned prefix = 0u;
+#pragma unroll 2
+        for (int bit = 31; bit >= 12; --bit) {
+            const unsigned t = prefix | ((1u << bit) - 1u);
+            int c = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) c += key[e] <= t ? 1 : 0;
+            c += __builtin_amdgcn_update_dpp(0, c, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+            c += __builtin_amdgcn_update_dpp(0, c, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+            c += __builtin_amdgcn_update_dpp(0, c, 0x141, 0xf, 0xf, true);   // row_half_mirror: the other quad of the eight
+            if (c < KK) prefix |= 1u << bit;
+        }
+        const unsigned tau = prefix | 0xFFFu;
+        float thr;
+        if (q0 + q >= N) {
+            thr = -INFINITY;                                   // no such query
+        } else if (tau >= 0xFF800000u || (flags & 4194304)) {  // fewer than K finite minima / flag: force the slow path
+            thr = 3.4028234e38f;
+        } else {
+            const float td = o2f(tau);
+            const float ni = sqrtf(xq) * 1.0001f;
+            const float eps = (1.0e-4f * ni * R + 2.6e-5f * (R * R + 2.1f * ni * R) + 9.2e-6f * (ni + R) * (ni + R)) * 1.001f;
+            thr = (td - xq) + 2.01f * eps + (fabsf(td) + xq) * 2.4e-7f;
+            if (!(thr < 3.4028234e38f)) thr = 3.4028234e38f;
+        }
+        if ((lane & 7) == 0) thrL[q] = thr;
+    }
+    stamp(5);
+    __syncthreads();   // thrL visible; the minima are consumed: the bitmaps may be written
+    stamp(6);
+
+    // ---------------------------------------------------------------- sweep 2: survivor bitmaps, branch-free
+    // bit 16 h + e of word t of row q <-> candidate 32 t + 8 (e / 4) + 4 h + e % 4
+    {
+        const float thr[2] = {thrL[n], thrL[32 + n]};
+        unsigned short *bp[2] = {reinterpret_cast<unsigned short *>(bm + n * RSW) + h,
+                                 reinterpret_cast<unsigned short *>(bm + (32 + n) * RSW) + h};
+        sweep([&](const f32x16 &a, int bk, int t, int g, bool gend) {
+            (void)g;
+            (void)gend;
+            unsigned m = 0;
+#pragma unroll
+            for (int e = 15; e >= 0; --e) m = push_le(m, a[e], thr[bk]);
+            bp[bk][2 * t] = (unsigned short)m;
+        });
+    }
+    stamp(7);
+    __syncthreads();
+    stamp(8);
+    if (flags & 16777216) return;   // timing ablation: ... + tau + sweep 2
+
+    // ---------------------------------------------------------------- refine: the oracle's distances, ranked by counting
+    // lane-per-candidate form (slow path): rows straight from the point-major copy
+    auto exact_d = [&](int q, int j) {
+        const float *row = xtb + (long)j * CP;
+        const float *qr = qrow + q * CPQ;
+        f32x4 v[CP / 4];
+#pragma unroll
+        for (int c4 = 0; c4 < CP / 4; ++c4) v[c4] = *reinterpret_cast<const f32x4 *>(row + 4 * c4);
+        float dot = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < CP / 4; ++c4) {
+            const f32x4 qv = *reinterpret_cast<const f32x4 *>(qr + 4 * c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dot = __builtin_fmaf(qv[e], v[c4][e], dot);
+        }
+        const float tt = qr[CP] - 2.0f * dot;
+        float d = tt + xxb[j];
+        if (fix_diag && j == q0 + q) d = 0.f;
+        return d;
+    };
+    {
+        u64 *pl = plist + wave * PC;
+        float *stg = stage + wave * 32 * CPQ;
+        const int qbase = wave * QW;
+        // ---- this wave's bitmap rows into registers (the stage overwrites the bitmaps), survivor counts of all its queries
+        constexpr int WMAX = 4;                      // bitmap words per lane and query: T <= 256
+        unsigned bw[QW][WMAX];
+        int cnt[QW], incl[QW], tot[QW];
+#pragma unroll
+        for (int u = 0; u < QW; ++u) {
+            const unsigned *row = bm + (qbase + u) * RSW;
+            int c = 0;
+#pragma unroll
+            for (int v = 0; v < WMAX; ++v) {
+                const int wi = lane + 64 * v;
+                const unsigned w = (64 * v < T && wi < T) ? row[wi] : 0u;
+                bw[u][v] = w;
+                c += __popc(w);
+            }
+            cnt[u] = c;
+        }
+#pragma unroll
+        for (int u = 0; u < QW; ++u) incl[u] = wave_incl_scan(cnt[u]);
+#pragma unroll
+        for (int u = 0; u < QW; ++u) {
+            tot[u] = __builtin_amdgcn_readlane(incl[u], 63);
+            const bool exists = q0 + qbase + u < N;
+            const bool bad = exists && (tot[u] > PC || tot[u] < KK);   // too many (ties) / too few (cannot happen): slow path
+            if ((flags & 33554432) && lane == 0 && exists) {
+                atomicAdd(&fsg_knn_split_stats[0], 1ull);
+                atomicAdd(&fsg_knn_split_stats[1], (unsigned long long)tot[u]);
+                atomicMax(&fsg_knn_split_stats[3], (unsigned long long)tot[u]);
+                if (bad) atomicAdd(&fsg_knn_split_stats[2], 1ull);
+            }
+            if (bad) {
+                if (lane == 0) slowq[qbase + u] = 1;
+                tot[u] = 0;
+                cnt[u] = 0;
+#pragma unroll
+                for (int v = 0; v < WMAX; ++v) bw[u][v] = 0u;
+            }
+        }
+        stamp(9);
+        __syncthreads();   // every wave holds its bitmaps in registers: xs and bm are dead, the row stage may overwrite them
+        stamp(10);
+
+        constexpr int LPR = CP / 4;                  // lanes (16-byte pieces) per candidate row
+        constexpr int RPI = 64 / LPR;                // rows per load instruction
+        constexpr int NI = RPI >= 32 ? 1 : 32 / RPI; // load instructions per pass of 32 rows
+        const int lrow = lane / LPR, lpc = lane % LPR;
+        int qnext = 0;
+        while (qnext < QW) {      // wave-uniform: a batch = as many of the next queries as fit PC candidates
+            int st[QW], en[QW];
+            bool in[QW];
+            int base = 0;
+            bool open = true;
+            int qend = qnext;
+#pragma unroll
+            for (int u = 0; u < QW; ++u) {
+                st[u] = base;
+                in[u] = false;
+                if (open && u >= qnext) {
+                    if (base + tot[u] <= PC) {
+                        in[u] = true;
+                        base += tot[u];
+                        qend = u + 1;
+                    } else {
+                        open = false;
+                    }
+                }
+                en[u] = base;
+            }
+            const int P = base;
+            qnext = qend;
+            // ---- decode: bit 16 h + e of word t <-> candidate 32 t + 8 (e / 4) + 4 h + e % 4
+#pragma unroll
+            for (int u = 0; u < QW; ++u) {
+                if (in[u] && tot[u] > 0) {
+                    int pos = st[u] + incl[u] - cnt[u];
+#pragma unroll
+                    for (int v = 0; v < WMAX; ++v) {
+                        if (64 * v >= T) break;   // wave-uniform
+                        unsigned w = bw[u][v];
+                        while (w) {
+                            const int bb = __builtin_ctz(w);
+                            w &= w - 1;
+                            const int e = bb & 15;
+                            pl[pos++] = (u64)(unsigned)(32 * (lane + 64 * v) + 8 * (e >> 2) + 4 * (bb >> 4) + (e & 3));
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (qend == QW) stamp(11);
+            auto which = [&](int p, int &ql, int &s, int &e) {   // segment of entry p
+                ql = 0; s = 0; e = 0;
+#pragma unroll
+                for (int u = 0; u < QW; ++u)
+                    if (in[u] && p >= st[u]) { ql = u; s = st[u]; e = en[u]; }
+            };
+            // ---- distances: passes of 32 candidates.  Their rows are loaded whole (LPR lanes x 16 bytes per row: every
+            // load instruction reads complete rows instead of one 16-byte piece of 64 different rows), staged in LDS, and
+            // lanes 0..31 run the channel-ordered fma chain of one candidate each; the next pass's loads are in flight
+            // during the chains.
+            f32x4 g[NI];
+            int jc = 0, jn = 0;
+            float xc = 0.f, xn = 0.f;
+            auto issue = [&](int p0) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int r = min(i * RPI + lrow, 31);
+                    const int j = (int)(unsigned)pl[min(p0 + r, P - 1)];
+                    g[i] = *reinterpret_cast<const f32x4 *>(xtb + (long)j * CP + 4 * lpc);
+                }
+                jn = (int)(unsigned)pl[min(p0 + (lane & 31), P - 1)];
+                xn = xxb[jn];
+            };
+            auto commit = [&]() {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int r = i * RPI + lrow;
+                    if (r < 32) *reinterpret_cast<f32x4 *>(stg + r * CPQ + 4 * lpc) = g[i];
+                }
+                jc = jn;
+                xc = xn;
+            };
+            if (P > 0) {
+                issue(0);
+                commit();
+            }
+            if (qend == QW) stamp(12);
+            for (int p0 = 0; p0 < P; p0 += 32) {
+                __builtin_amdgcn_wave_barrier();
+                if (p0 + 32 < P) issue(p0 + 32);
+                const int p = p0 + lane;
+                if (lane < 32 && p < P) {
+                    int ql, s, e;
+                    which(p, ql, s, e);
+                    const float *qr = qrow + (qbase + ql) * CPQ;
+                    const float *row = stg + lane * CPQ;
+                    float dot = 0.f;
+                    constexpr int HB = CP / 4 >= 8 ? 8 : CP / 4;   // all LDS reads of half a row are issued before its fma chain
+#pragma unroll
+                    for (int c0 = 0; c0 < CP / 4; c0 += HB) {
+                        f32x4 qv[HB], cv[HB];
+#pragma unroll
+                        for (int c4 = 0; c4 < HB; ++c4) {
+                            qv[c4] = *reinterpret_cast<const f32x4 *>(qr + 4 * (c0 + c4));
+                            cv[c4] = *reinterpret_cast<const f32x4 *>(row + 4 * (c0 + c4));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int c4 = 0; c4 < HB; ++c4)
+#pragma unroll
+                            for (int ee = 0; ee < 4; ++ee) dot = __builtin_fmaf(qv[c4][ee], cv[c4][ee], dot);
+                    }
+                    const float tt = qr[CP] - 2.0f * dot;
+                    float d = tt + xc;
+                    if (fix_diag && jc == q0 + qbase + ql) d = 0.f;
+                    pl[p] = ((u64)f2o(d) << 32) | (unsigned)jc;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (p0 + 32 < P) commit();
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (qend == QW) stamp(13);
+            // ---- ranks and output
+            for (int p0 = 0; p0 < P; p0 += 64) {
+                const int p = p0 + lane;
+                if (p < P) {
+                    int ql, s, e;
+                    which(p, ql, s, e);
+                    const u64 key = pl[p];
+                    int r = 0;
+                    int t = s;
+                    if ((t & 1) && t < e) { r += pl[t] < key ? 1 : 0; ++t; }   // 16-byte reads from an even entry on
+#pragma unroll 4
+                    for (; t + 2 <= e; t += 2) {
+                        const u32x4 kk = *reinterpret_cast<const u32x4 *>(pl + t);
+                        const u64 k0 = ((u64)kk[1] << 32) | kk[0], k1 = ((u64)kk[3] << 32) | kk[2];
+                        r += (k0 < key ? 1 : 0) + (k1 < key ? 1 : 0);
+                    }
+                    if (t < e) r += pl[t] < key ? 1 : 0;
+                    if (r >= drop && r < KK) {
+                        const long o = ((long)b * N + q0 + qbase + ql) * k - drop + r;
+                        idx_out[o] = (int)(unsigned)(key & 0xFFFFFFFFull);
+                        if (dist_out) dist_out[o] = o2f((unsigned)(key >> 32));
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    stamp(14);
+    __syncthreads();
+
+    // ---------------------------------------------------------------- slow path: whole workgroup, one flagged query at a time
+    for (int q = 0; q < QB; ++q) {
+        if (!slowq[q]) continue;   // uniform (LDS value, written before the barrier above)
+        for (int j = tid; j < N; j += WAVES * 64) dl[j] = exact_d(q, j);
+        __syncthreads();
+        if (wave == 0) {
+            u64 last = 0;
+            const long ob = ((long)b * N + q0 + q) * k - drop;
+            for (int r = 0; r < KK; ++r) {
+                u64 best = ~0ull;
+                for (int j = lane; j < N; j += 64) {
+                    const u64 kj = ((u64)f2o(dl[j]) << 32) | (unsigned)j;
+                    if ((r == 0 || kj > last) && kj < best) best = kj;
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const u64 o = __shfl_xor(best, off);
+                    best = o < best ? o : best;
+                }
+                last = best;
+                if (lane == 0 && r >= drop) {
+                    idx_out[ob + r] = (int)(unsigned)(best & 0xFFFFFFFFull);
+                    if (dist_out) dist_out[ob + r] = o2f((unsigned)(best >> 32));
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct SplitPlan {
+    bool ok;
+    int KS, CP, Np;
+    bool pack;
+    size_t off_xx, off_xt, off_cand, off_qry, total;
+};
+
+SplitPlan plan(int B, int N, int c_knn) {
+    SplitPlan p{};
+    p.ok = N >= 1024 && N <= 8192 && c_knn >= 1 && c_knn <= 64;
+    p.pack = c_knn <= 4;
+    p.KS = p.pack ? 1 : (c_knn <= 16 ? 1 : (c_knn <= 32 ? 2 : 4));
+    p.CP = p.pack ? 4 : 16 * p.KS;
+    p.Np = (N + 63) & ~63;
+    const size_t T = p.Np / 32, opt = p.pack ? 1 : 2 * p.KS;
+    p.off_xx = 0;
+    p.off_xt = align256(sizeof(float) * (size_t)B * p.Np);
+    p.off_cand = p.off_xt + align256(sizeof(float) * (size_t)B * p.Np * p.CP);
+    p.off_qry = p.off_cand + align256((size_t)B * T * opt * 1024);
+    p.total = p.off_qry + align256((size_t)B * T * opt * 1024);
+    return p;
+}
+
+}  // namespace
+
+size_t fsg_knn_split_workspace_bytes(int B, int N, int c_knn) {
+    const SplitPlan p = plan(B, N, c_knn);
+    return p.ok ? p.total : 0;
+}
+
+// returns FSG_ERR_UNSUPPORTED when the shape is outside this kernel's envelope (caller falls back)
+int fsg_knn_split_launch(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k, int flags,
+                         int32_t *idx_out, float *dist_out, void *ws, size_t ws_bytes, hipStream_t st) {
+    const int drop = (flags & FSG_KNN_DROP_FIRST) ? 1 : 0;
+    const SplitPlan p = plan(B, N, c_knn);
+    if (!p.ok || k + drop > 64 || ws == nullptr || ws_bytes < p.total) return FSG_ERR_UNSUPPORTED;
+    unsigned char *w = static_cast<unsigned char *>(ws);
+    float *xx = reinterpret_cast<float *>(w + p.off_xx);
+    float *xt = reinterpret_cast<float *>(w + p.off_xt);
+    u32x4 *cand = reinterpret_cast<u32x4 *>(w + p.off_cand);
+    u32x4 *qry = reinterpret_cast<u32x4 *>(w + p.off_qry);
+    const dim3 pgrid(p.Np / 32, B), grid(p.Np / 64, B);
+    const int PC = N <= 4096 ? 1024 : 512;   // candidates a wave refines per batch (8 bytes of LDS each)
+    const size_t T = p.Np / 32, CPQ = p.CP + 4;
+    size_t usz = sizeof(float) * p.Np + 4 * ((QB * (T + 1) + 1) & ~(size_t)1);
+    if (usz < 4 * (size_t)WAVES * 32 * CPQ) usz = 4 * (size_t)WAVES * 32 * CPQ;
+    const size_t lds = ((usz + 15) & ~(size_t)15) + 8 * (size_t)WAVES * PC + sizeof(float) * QB * CPQ + sizeof(float) * QB +
+                       sizeof(int) * QB + sizeof(float) * 16;
+#define FSG_KNN_SPLIT(KSV, PK)                                                                                          \
+    do {                                                                                                               \
+        static bool granted = false;                                                                                   \
+        if (!granted) {                                                                                                \
+            if (hipFuncSetAttribute((const void *)knn_split_kernel<KSV, PK>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    160 * 1024) != hipSuccess) {                                                       \
+                fsg_set_error("fsg_knn_dense_ws_f32: cannot raise dynamic LDS");                                       \
+                return FSG_ERR_HIP;                                                                                    \
+            }                                                                                                          \
+            granted = true;                                                                                            \
+        }                                                                                                              \
+        hipLaunchKernelGGL((knn_split_prep_kernel<KSV, PK>), pgrid, dim3(256), 0, st, x, N, p.Np, (long)stride_b,       \
+                           (long)stride_c, c_knn, xx, xt, cand, qry);                                                  \
+        hipLaunchKernelGGL((knn_split_kernel<KSV, PK>), grid, dim3(WAVES * 64), lds, st, xx, xt, cand, qry, N, p.Np, k,  \
+                           flags, PC, idx_out, dist_out);                                                              \
+    } while (0)
+    if (lds > 160 * 1024) return FSG_ERR_UNSUPPORTED;
+    if (p.pack) FSG_KNN_SPLIT(1, true);
+    else if (p.KS == 1) FSG_KNN_SPLIT(1, false);
+    else if (p.KS == 2) FSG_KNN_SPLIT(2, false);
+    else FSG_KNN_SPLIT(4, false);
+#undef FSG_KNN_SPLIT
+    FSG_CHECK_LAUNCH("fsg_knn_dense_ws_f32/split");
+    return FSG_OK;
+}

@@ -152,7 +152,8 @@ def knn_graph(x, k, c_knn=None, fix_diag=True, drop_first=False, return_dist=Fal
     dist = torch.empty(B, N, k, dtype=torch.float32, device=x.device) if return_dist else None
     flags = (_lib.KNN_FIX_DIAG if fix_diag else 0) | (_lib.KNN_DROP_FIRST if drop_first else 0) | \
         (_lib.KNN_FORCE_ROWS if force_rows_kernel else 0) | _debug_flags
-    xx = torch.empty(B, N, dtype=torch.float32, device=x.device)
+    ws_bytes = _lib.lib.fsg_knn_dense_workspace_bytes(B, N, c_knn)
+    xx = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         if _debug_flags & _KNN_EXPERIMENT_FLAGS:   # superseded designs (tests / tools): libfsg_hip_experiments.so
             xl = _lib.experiments()
@@ -163,8 +164,8 @@ def knn_graph(x, k, c_knn=None, fix_diag=True, drop_first=False, return_dist=Fal
             if rc != 3:   # FSG_ERR_UNSUPPORTED: shape outside that kernel's envelope -> the production kernel below
                 raise RuntimeError(xl.fsg_last_error().decode())
             flags &= ~_KNN_EXPERIMENT_FLAGS
-        _lib.call("fsg_knn_dense_f32", _p(x), B, N, x.stride(0), x.stride(1), c_knn, k, flags, _p(idx), _p(dist), _p(xx),
-                  _stream())
+        _lib.call("fsg_knn_dense_ws_f32", _p(x), B, N, x.stride(0), x.stride(1), c_knn, k, flags, _p(idx), _p(dist), _p(xx),
+                  ws_bytes, _stream())
     return (idx, dist) if return_dist else idx
 
 

@@ -57,6 +57,18 @@ int fsg_knn_dense_f32(const float *x, int B, int N, int64_t stride_b, int64_t st
                       fsg_stream_t stream);
 
 /*
+ * The same graph build with a caller-owned workspace (what the nn.Module layer calls).  Inside 1024 <= N <= 16384,
+ * c_knn <= 64 the graph comes from the coarse-sweep + exact-refine kernel: split-bf16 products on
+ * v_mfma_f32_32x32x16_bf16 nominate ~1.2 k candidates per query under a rigorous error bound, and only the nominees get the
+ * arithmetic above (indices AND distance bits equal fsg_knn_dense_f32's).  Other shapes: fsg_knn_dense_f32 with the
+ * workspace as xx_scratch.  workspace may be NULL (then as fsg_knn_dense_f32 with xx_scratch = NULL).
+ */
+size_t fsg_knn_dense_workspace_bytes(int B, int N, int c_knn);
+int fsg_knn_dense_ws_f32(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn,
+                         int k, int flags, int32_t *idx_out, float *dist_out, void *workspace,
+                         size_t workspace_bytes, fsg_stream_t stream);
+
+/*
  * Edge features: replaces models/dgcnn.py:31-36 (create_neighbor_features: take_along_dim, repeat,
  * cat) and models/dgcnn_opensrc.py:43-66 (get_graph_feature).
  *   x (B,C,N) fp32, idx (B,N,k) int32 -> edge (B,2C,N,k): [x_j - x_i ; x_i]

@@ -57,10 +57,64 @@ def test_knn_mfma_kernel_equals_rows_kernel_at_full_size(fsg, device, B, C, Np, 
                                  force_rows_kernel=True)
     # two-phase kernel (production), its 512-candidate-chunk variant, wave-specialised pipeline (4096), first MFMA design (8),
     # threshold-filter design (16384)
-    for dbg in (0, 2048, 4096, 8, 16384):
+    # default entry (coarse-sweep + exact-refine kernel inside its envelope), two-phase kernel (2097152), its 512-candidate-chunk
+    # variant (2048), wave-specialised pipeline (4096), first MFMA design (8), threshold-filter design (16384)
+    for dbg in (0, 2097152, 2048, 4096, 8, 16384):
         a = fsg.functional.knn_graph(x, k, c_knn=c_knn, fix_diag=fix, drop_first=drop, return_dist=True, _debug_flags=dbg)
         assert torch.equal(a[0], r[0]), dbg
         assert torch.equal(a[1].view(torch.int32), r[1].view(torch.int32)), dbg
+
+
+def _split_inputs(kind, seed, B, C, Np):
+    g = np.random.default_rng(seed)
+    if kind == "uniform":
+        return g.uniform(-1, 1, (B, C, Np)).astype(np.float32)
+    if kind == "biased":       # what an EdgeConv emits: large common mean, small spread (cancellation in d = xx - 2 dot + xx)
+        return (1.9 + 0.5 * g.standard_normal((B, C, Np))).astype(np.float32)
+    if kind == "lowdim":       # features that are a smooth function of 3-D positions: neighbours far closer than the cloud radius
+        p = g.uniform(0, 1, (B, 3, Np))
+        w = g.standard_normal((C, 3))
+        return (np.tanh(np.einsum("cd,bdn->bcn", w, p)) + 1.0).astype(np.float32)
+    if kind == "lattice":      # every point twice on a coarse lattice: massive ties, lists overflow -> slow path
+        p = g.integers(0, 6, (B, C, Np // 2)).astype(np.float32)
+        return np.concatenate([p, p], 2)
+    if kind == "far":          # a tight cloud far from the origin: |x|^2 ~ 1e4 times the neighbour distances
+        return (100.0 + 0.01 * g.standard_normal((B, C, Np))).astype(np.float32)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("B,C,Np,k,c_knn,fix,drop,kind,flags", [
+    (2, 64, 2048, 20, None, True, False, "uniform", 0), (2, 64, 2048, 20, None, True, False, "biased", 0),
+    (2, 64, 2048, 20, None, True, False, "lowdim", 0), (2, 3, 2048, 20, None, True, True, "uniform", 0),
+    (2, 6, 2048, 20, 3, True, False, "uniform", 0), (2, 10, 1024, 16, None, False, False, "uniform", 0),
+    (2, 24, 1500, 20, None, True, True, "lowdim", 0), (1, 33, 4096, 63, None, True, True, "biased", 0),
+    (1, 64, 1024, 64, None, True, False, "lowdim", 0), (2, 3, 1024, 20, None, True, False, "lattice", 0),
+    (1, 16, 1100, 8, None, True, False, "far", 0), (1, 64, 2048, 20, None, True, False, "uniform", 4194304),
+    (1, 3, 1030, 40, None, True, True, "uniform", 4194304)])
+def test_knn_split_kernel_bit_exact_vs_c_oracle(fsg, device, B, C, Np, k, c_knn, fix, drop, kind, flags):
+    """fsg_knn_dense_ws_f32's coarse-sweep + exact-refine kernel (csrc/knn_split.hip: split-bf16 MFMA products only NOMINATE
+    candidates under a rigorous error bound; every ranked distance is the oracle's fp32 fma chain): indices and distance bits
+    equal the C oracle's on inputs that stress the bound (common mean, manifold features, far-from-origin clouds, ties);
+    flag 4194304 sends every query through the kernel's slow exact path."""
+    x = _split_inputs(kind, 77 + Np + C, B, C, Np)
+    idx, dist = fsg.functional.knn_graph(G(x, device), k, c_knn=c_knn, fix_diag=fix, drop_first=drop, return_dist=True,
+                                         _debug_flags=flags)
+    ridx, rdist = c_api.knn_dense(x, k, c_knn=c_knn, fix_diag=fix, drop_first=drop)
+    assert np.array_equal(N(idx), ridx)
+    assert np.array_equal(N(dist).view(np.uint32), rdist.view(np.uint32))  # same bits
+
+
+@pytest.mark.parametrize("B,C,Np,k,kind", [(8, 64, 2048, 20, "biased"), (8, 64, 2048, 20, "lowdim"), (4, 64, 8192, 40, "lowdim"),
+                                           (4, 3, 8192, 40, "uniform"), (32, 3, 2048, 40, "uniform"), (2, 3, 2048, 20, "far"),
+                                           (3, 48, 5000, 33, "biased")])
+def test_knn_split_kernel_equals_two_phase_kernel_at_full_size(fsg, device, B, C, Np, k, kind):
+    """BASELINE config 2 / 4 / 5 graph sizes: the default entry against the two-phase matrix-core kernel (flag 2097152), which
+    reproduces the C oracle's bits on every size the oracle reaches."""
+    x = G(_split_inputs(kind, 5 + Np, B, C, Np), device)
+    a = fsg.functional.knn_graph(x, k, return_dist=True)
+    r = fsg.functional.knn_graph(x, k, return_dist=True, _debug_flags=2097152)
+    assert torch.equal(a[0], r[0])
+    assert torch.equal(a[1].view(torch.int32), r[1].view(torch.int32))
 
 
 def test_knn_massive_ties_take_the_slow_exact_path(fsg, device):
