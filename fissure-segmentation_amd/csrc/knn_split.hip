@@ -277,7 +277,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
     // s~ of the tile's 32 candidates (rows 8 (e/4) + 4 h + e%4) against the 32 queries of block bk (column n)
     auto scores = [&](const Ops<KS, PACK> &c, const f32x16 &init, int bk) {
         f32x16 acc = init;
-        if (flags & 536870912) return acc;   // timing ablation: no matrix work
 #pragma unroll
         for (int s = 0; s < NOP; ++s) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.hi[s], qo[bk].hi[s], acc, 0, 0, 0);
@@ -308,40 +307,44 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
         if (ii >= TW) ii -= TW;
         return wave + WAVES * ii;
     };
+    // One sweep over the wave's tiles.  Operands come through a ring of three register sets, requested two tiles ahead.
+    // The consumer f of a chain's 16 x 64 scores runs one chain LATE: the vector work on chain c-1 is independent of the
+    // twelve MFMAs of chain c, so the scheduler can place it in the matrix instructions' issue gaps (a wave is in-order:
+    // consumed right after its own chain, the vector work and the matrix work of the two waves of a SIMD line up in phase
+    // and the matrix pipe idles during every consume -- measured: 1500 of 3100 cycles per tile).
     auto sweep = [&](auto &&f) {
         Ops<KS, PACK> ring[3];
-        f32x16 init[3];
-        const bool noload = (flags & 134217728) != 0;   // timing ablation: the first tile's operands for every tile
-        if (TW > 0) {
-            load_tile(ring[0], tile_of(0));
-            init[0] = load_init(tile_of(0));
-        }
-        if (TW > 1) load_tile(ring[1], tile_of(noload ? 0 : 1));
-        if (noload) load_tile(ring[2], tile_of(0));
-        int gi = 0, g = 0;   // tiles in the open minimum group, its index
+        if (TW > 0) load_tile(ring[0], tile_of(0));
+        if (TW > 1) load_tile(ring[1], tile_of(1));
+        int gi = 0, g = 0;          // tiles in the open minimum group, its index
+        f32x16 prev;                // scores of the previous chain (block 1 of the previous tile), not yet consumed
+#pragma unroll
+        for (int e = 0; e < 16; ++e) prev[e] = INFINITY;
+        int pt = TW > 0 ? tile_of(0) : 0, pg = 0;
+        bool pgend = false;
         for (int i0 = 0; i0 < TW; i0 += 3) {
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 const int i = i0 + u;
                 if (i < TW) {
                     const int t = tile_of(i);
-                    if (i + 2 < TW && !noload) load_tile(ring[(u + 2) % 3], tile_of(i + 2));
-                    if (i + 1 < TW) init[(u + 1) % 3] = load_init(tile_of(i + 1));   // a tile ahead: no LDS wait in front of the chain
-                    // the tile's matrix chain runs at raised priority: the two waves of a SIMD then take the matrix pipe in
-                    // turns instead of interleaving their chains (flag 1073741824: off, A/B timing)
+                    if (i + 2 < TW) load_tile(ring[(u + 2) % 3], tile_of(i + 2));
                     ++gi;
                     const bool gend = gi == G || i + 1 == TW;   // wave-uniform: the minimum group is complete
-#pragma unroll
-                    for (int bk = 0; bk < 2; ++bk) {
-                        if (!(flags & 1073741824)) __builtin_amdgcn_s_setprio(3);
-                        const f32x16 a = scores(ring[u], init[u], bk);
-                        if (!(flags & 1073741824)) __builtin_amdgcn_s_setprio(0);
-                        f(a, bk, t, g, gend);
-                    }
+                    const f32x16 init = load_init(t);
+                    const f32x16 a0 = scores(ring[u], init, 0);
+                    f(prev, 1, pt, pg, pgend);                  // block 1 of the previous tile (first tile: +inf scores)
+                    const f32x16 a1 = scores(ring[u], init, 1);
+                    f(a0, 0, t, g, gend);
+                    prev = a1;
+                    pt = t;
+                    pg = g;
+                    pgend = gend;
                     if (gend) { ++g; gi = 0; }
                 }
             }
         }
+        if (TW > 0) f(prev, 1, pt, pg, pgend);
     };
     stamp(1);
     __syncthreads();   // xs, red, qrow

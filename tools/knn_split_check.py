@@ -108,9 +108,7 @@ if __name__ == "__main__":
         torch.cuda.synchronize()
         lib.fsg_debug_knn_split_stats(st, 0)
         print(f"stats B={B} C={C} N={N} k={k} {kind:8s}: {st[1] / max(st[0], 1):.1f} listed per query, max {st[3]}, slow {st[2]} of {st[0]}", flush=True)
-        for nm, fl in (("setup", 67108864), ("setup+sweep1", 8388608), ("..+tau+sweep2", 16777216), ("all, no operand loads", 134217728),
-                       ("all, lockstep tile order", 268435456), ("all, no stagger", 1073741824), ("setup+sweep1, no MFMA", 8388608 | 536870912),
-                       ("setup+sweep1, no MFMA no loads", 8388608 | 536870912 | 134217728)):
+        for nm, fl in (("setup", 67108864), ("setup+sweep1", 8388608), ("..+tau+sweep2", 16777216)):
             print(f"   {nm}: {timeit(B, C, N, k, kind, fl):.1f} us", flush=True)
     for (B, C, N, k, kind) in [(8, 64, 2048, 20, "biased"), (8, 64, 2048, 20, "lowdim"), (8, 64, 2048, 20, "uniform"),
                                (8, 3, 2048, 20, "uniform"), (4, 64, 8192, 40, "lowdim"), (4, 3, 8192, 40, "uniform"),
