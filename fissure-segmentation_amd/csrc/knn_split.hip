@@ -88,7 +88,7 @@ __device__ __forceinline__ Split split2(float v) {
 template <int KS, bool PACK>
 __global__ __launch_bounds__(256) void knn_split_prep_kernel(const float *__restrict__ x, int N, int Np, long sb, long sc,
                                                              int c_knn, float *__restrict__ xx, float *__restrict__ xt,
-                                                             u32x4 *__restrict__ cand, u32x4 *__restrict__ qry) {
+                                                             u32x4 *__restrict__ cand) {
     constexpr int CP = PACK ? 4 : 16 * KS;
     __shared__ float slab[CP][33];
     const int tid = threadIdx.x, b = blockIdx.y, tile = blockIdx.x, j0 = tile * 32;
@@ -114,40 +114,31 @@ __global__ __launch_bounds__(256) void knn_split_prep_kernel(const float *__rest
     if (PACK) {
         if (tid >= 64 && tid < 128) {     // (the first wave carries the norm chain)
             const int lane = tid & 63, m = lane & 31, h = lane >> 5;
-            unsigned hi[4], lo[4], qhi[4], qlo[4];
+            unsigned hi[4], lo[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float v = slab[i][m];
-                const Split s = split2(v), q = split2(-2.0f * v);
-                hi[i] = s.hi; lo[i] = s.lo; qhi[i] = q.hi; qlo[i] = q.lo;
+                const Split s = split2(slab[i][m]);
+                hi[i] = s.hi; lo[i] = s.lo;
             }
-            u32x4 c, q;
-            if (h == 0) {
-                c = u32x4{hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16)};
-                q = u32x4{qhi[0] | (qhi[1] << 16), qhi[2] | (qhi[3] << 16), qlo[0] | (qlo[1] << 16), qlo[2] | (qlo[3] << 16)};
-            } else {
-                c = u32x4{lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), 0u, 0u};
-                q = u32x4{qhi[0] | (qhi[1] << 16), qhi[2] | (qhi[3] << 16), 0u, 0u};
-            }
-            const long o = ((long)b * T + tile) * 64 + lane;
-            cand[o] = c;
-            qry[o] = q;
+            // candidate image [hi | hi] / [lo | 0]; the query image of the same point is [hi | lo] / [hi | 0] (times -2):
+            // the main kernel rebuilds it from this block (lane m holds hi, lane 32 + m holds lo)
+            u32x4 c;
+            if (h == 0) c = u32x4{hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16)};
+            else c = u32x4{lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), 0u, 0u};
+            cand[((long)b * T + tile) * 64 + lane] = c;
         }
     } else {
         for (int e = tid; e < KS * 2 * 64; e += 256) {
             const int lane = e & 63, part = (e >> 6) & 1, s = e >> 7;
             const int m = lane & 31, h = lane >> 5;
-            unsigned cw[8], qw[8];
+            unsigned cw[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float v = slab[16 * s + 8 * h + i][m];
-                const Split sp = split2(v), sq = split2(-2.0f * v);
+                const Split sp = split2(slab[16 * s + 8 * h + i][m]);
                 cw[i] = part ? sp.lo : sp.hi;
-                qw[i] = part ? sq.lo : sq.hi;
             }
             const long o = ((((long)b * T + tile) * KS + s) * 2 + part) * 64 + lane;
             cand[o] = u32x4{cw[0] | (cw[1] << 16), cw[2] | (cw[3] << 16), cw[4] | (cw[5] << 16), cw[6] | (cw[7] << 16)};
-            qry[o] = u32x4{qw[0] | (qw[1] << 16), qw[2] | (qw[3] << 16), qw[4] | (qw[5] << 16), qw[6] | (qw[7] << 16)};
         }
     }
 }
@@ -176,8 +167,7 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 
 template <int KS, bool PACK>
 __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *__restrict__ xx, const float *__restrict__ xt,
-                                                                  const u32x4 *__restrict__ cand,
-                                                                  const u32x4 *__restrict__ qry, int N, int Np, int k,
+                                                                  const u32x4 *__restrict__ cand, int N, int Np, int k,
                                                                   int flags, int PC, int32_t *__restrict__ idx_out,
                                                                   float *__restrict__ dist_out) {
     constexpr int CP = PACK ? 4 : 16 * KS;
@@ -229,7 +219,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
     const float *xxb = xx + (long)b * Np;
     const float *xtb = xt + (long)b * Np * CP;
     const u32x4 *candb = cand + (long)b * T * OPT * 64 + lane;
-    const u32x4 *qryb = qry + (long)b * T * OPT * 64 + lane;
 
     // ---- setup: norms into LDS (+ their maximum), the workgroup's query rows, the query operands
     float mx = 0.f;
@@ -255,14 +244,34 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
     for (int bk = 0; bk < 2; ++bk)      // this thread's eight minimum slots: groups without a tile stay +inf
 #pragma unroll
         for (int g = 0; g < 4; ++g) mins[(32 * bk + n) * 64 + wave * 8 + h * 4 + g] = INFINITY;
+    // query operands: the candidate image of the workgroup's own two tiles times -2.  A bf16 doubles by one exponent step:
+    // (w ^ sign) + (1 << 7) per 16-bit half; a zero becomes 2^-126 (its products with the candidates' exact zeros in the
+    // padding channels stay zero, with real channels they are ~1e-38 |x|, nothing next to eps)
+    auto neg2 = [](u32x4 w) {
+        u32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = (w[e] ^ 0x80008000u) + 0x00800080u;
+        return r;
+    };
     Ops<KS, PACK> qo[2];
 #pragma unroll
     for (int bk = 0; bk < 2; ++bk) {
-        const u32x4 *p = qryb + (long)(q0 / 32 + bk) * OPT * 64;
+        const u32x4 *p = candb + (long)(q0 / 32 + bk) * OPT * 64;
+        if (PACK) {
+            // candidate block: lane (m, 0) = [hi | hi], lane (m, 1) = [lo | 0]; query block: (m, 0) = [hi | lo], (m, 1) = [hi | 0]
+            const u32x4 mine = p[0], other = p[(lane ^ 32) - lane];
+            u32x4 q;
+            if (h == 0) q = u32x4{mine[0], mine[1], other[0], other[1]};
+            else q = u32x4{other[0], other[1], 0u, 0u};
+            q = neg2(q);
+            if (h == 1) { q[2] = 0u; q[3] = 0u; }
+            qo[bk].hi[0] = __builtin_bit_cast(bf16x8, q);
+        } else {
 #pragma unroll
-        for (int s = 0; s < NOP; ++s) {
-            qo[bk].hi[s] = __builtin_bit_cast(bf16x8, p[(PACK ? 0 : 2 * s) * 64]);
-            if (!PACK) qo[bk].lo[s] = __builtin_bit_cast(bf16x8, p[(2 * s + 1) * 64]);
+            for (int s = 0; s < NOP; ++s) {
+                qo[bk].hi[s] = __builtin_bit_cast(bf16x8, neg2(p[(2 * s) * 64]));
+                qo[bk].lo[s] = __builtin_bit_cast(bf16x8, neg2(p[(2 * s + 1) * 64]));
+            }
         }
     }
 
@@ -697,7 +706,7 @@ struct SplitPlan {
     bool ok;
     int KS, CP, Np;
     bool pack;
-    size_t off_xx, off_xt, off_cand, off_qry, total;
+    size_t off_xx, off_xt, off_cand, total;
 };
 
 SplitPlan plan(int B, int N, int c_knn) {
@@ -711,8 +720,7 @@ SplitPlan plan(int B, int N, int c_knn) {
     p.off_xx = 0;
     p.off_xt = align256(sizeof(float) * (size_t)B * p.Np);
     p.off_cand = p.off_xt + align256(sizeof(float) * (size_t)B * p.Np * p.CP);
-    p.off_qry = p.off_cand + align256((size_t)B * T * opt * 1024);
-    p.total = p.off_qry + align256((size_t)B * T * opt * 1024);
+    p.total = p.off_cand + align256((size_t)B * T * opt * 1024);
     return p;
 }
 
@@ -733,7 +741,6 @@ int fsg_knn_split_launch(const float *x, int B, int N, int64_t stride_b, int64_t
     float *xx = reinterpret_cast<float *>(w + p.off_xx);
     float *xt = reinterpret_cast<float *>(w + p.off_xt);
     u32x4 *cand = reinterpret_cast<u32x4 *>(w + p.off_cand);
-    u32x4 *qry = reinterpret_cast<u32x4 *>(w + p.off_qry);
     const dim3 pgrid(p.Np / 32, B), grid(p.Np / 64, B);
     const int PC = N <= 4096 ? 1024 : 512;   // candidates a wave refines per batch (8 bytes of LDS each)
     const size_t T = p.Np / 32, CPQ = p.CP + 4;
@@ -753,8 +760,8 @@ int fsg_knn_split_launch(const float *x, int B, int N, int64_t stride_b, int64_t
             granted = true;                                                                                            \
         }                                                                                                              \
         hipLaunchKernelGGL((knn_split_prep_kernel<KSV, PK>), pgrid, dim3(256), 0, st, x, N, p.Np, (long)stride_b,       \
-                           (long)stride_c, c_knn, xx, xt, cand, qry);                                                  \
-        hipLaunchKernelGGL((knn_split_kernel<KSV, PK>), grid, dim3(WAVES * 64), lds, st, xx, xt, cand, qry, N, p.Np, k,  \
+                           (long)stride_c, c_knn, xx, xt, cand);                                                  \
+        hipLaunchKernelGGL((knn_split_kernel<KSV, PK>), grid, dim3(WAVES * 64), lds, st, xx, xt, cand, N, p.Np, k,  \
                            flags, PC, idx_out, dist_out);                                                              \
     } while (0)
     if (lds > 160 * 1024) return FSG_ERR_UNSUPPORTED;
