@@ -9,7 +9,8 @@ TAG = sys.argv[1] if len(sys.argv) > 1 else "r1"
 rows = list(csv.DictReader([l for l in open(os.path.join(ROOT, "profiles", f"{TAG}_bench_c2_kernel_stats.csv")) if not l.startswith("#")]))
 B, N, k = 8, 2048, 20
 E = B * N * k
-items = [("knn_rows_mfma_kernel<16,", "kNN graph, 64 channels: distance block (2 B N^2 C flop) + exact top-k", 2.0 * B * N * N * 64),
+items = [("knn_split_kernel<4,", "kNN graph, 64 channels (coarse sweeps + exact refine; the prep kernel's time is not in this row): "
+          "algorithmic 2 B N^2 C flop of the exact fp32 distance block", 2.0 * B * N * N * 64),
          ("ec2_fwd_kernel<64", "EdgeConv layer-2 contraction per edge, forward (2 E 64 64)", 2.0 * E * 64 * 64),
          ("ec2_bwd_kernel<64", "EdgeConv layer-2 backward: y2 recompute + dz1 + dW2 (3 x 2 E 64 64)", 6.0 * E * 64 * 64),
          ("Cijk_Alik_Bljk_S_B_Bias_HA_S_SAV_UserArgs_MT256x256x32", "vendor GEMM, head 192 -> 1024 over 16 384 points, forward",

@@ -25,8 +25,11 @@ for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA
            "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT" \
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc_knn/p$i -- python3 $R/tools/prof_knn_phaseA.py > $out/pmc_knn_p$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc_knn/p$i -- python3 $R/tools/knn_split_prof.py 8 64 2048 20 > $out/pmc_knn_p$i.log 2>&1
 done
 cd $R
-python3 tools/summarise_knn_pmc.py $out/pmc_knn > $out/knn_sq_counters.txt
+python3 tools/summarise_knn_pmc.py $out/pmc_knn knn_split > $out/knn_sq_counters.txt
+python3 tools/knn_split_stamps.py 8 64 2048 20 > $out/knn_phase_stamps.txt 2>/dev/null
+python3 tools/knn_split_stamps.py 4 64 8192 40 >> $out/knn_phase_stamps.txt 2>/dev/null
+python3 tools/knn_split_check.py --time-only > $out/knn_split_timing.txt 2>/dev/null
 grep -h ms_per_step $out/stats.log | cut -c1-200

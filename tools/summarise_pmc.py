@@ -41,11 +41,11 @@ def main():
                       "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
     group = {}
     for k in kernels:   # forward graph build + neighbour gather: per-step launch counts
-        if k.startswith("knn_rows_mfma_kernel<1,"):
+        if k.startswith("knn_split_kernel<1, true") or k.startswith("knn_split_prep_kernel<1, true"):
             group[k] = 1
-        elif k.startswith("knn_rows_mfma_kernel<16,"):
+        elif k.startswith("knn_split_kernel<4,") or k.startswith("knn_split_prep_kernel<4,"):
             group[k] = 2
-        elif k in ("knn_sqnorm2_kernel", "ec1_stats_select_kernel", "ec1_apply_kernel"):
+        elif k in ("ec1_stats_select_kernel", "ec1_apply_kernel"):
             group[k] = 3
         elif k.startswith("ec2_fwd_kernel"):
             group[k] = 1
