@@ -4,13 +4,17 @@
 // cores only nominate candidates, every distance that is ranked or returned is the oracle's fp32 fma chain.
 //
 //   prep    one pass over the cloud: squared norms (the oracle's chain), a point-major fp32 copy (rows for the refine) and
-//           the points split into two bf16 pieces x = hi + lo + r, |r| <= 2^-16 |x| (round-to-nearest-even done in integer
-//           arithmetic, so the bound does not depend on a conversion instruction), stored in the register image of
-//           v_mfma_f32_32x32x16_bf16 operands (one 1-KiB block per 32 points, k-step and piece: a wave loads an operand
-//           with one fully coalesced 16-byte load per lane).  The query image carries -2x.
+//           the coarse image of the points in the REGISTER LAYOUT of a 32x32x16 MFMA operand (one 1-KiB block per 32 points
+//           and k-step: a wave loads an operand with one fully coalesced 16-byte load per lane).  Two forms:
+//           * above 4 channels: ONE fp16 image of the points centred on a sampled mean and scaled by a power of two (both the
+//             same for every workgroup of a cloud); points outside the fp16 range are marked and send their cloud down the
+//             exact slow path;
+//           * up to 4 channels (and flag 1073741824): two bf16 pieces x = hi + lo + r, |r| <= 2^-16 |x| (round-to-nearest-
+//             even in integer arithmetic) of the points as they are, three products -- which share ONE k-step at <= 4 channels.
+//           A query operand is the same image times -2 (one exponent step, done in the main kernel).
 //   sweep 1 a workgroup owns 64 queries (two 32-column blocks, resident as B operands); its 8 waves take the candidate
-//           tiles (32 rows, A operand) round-robin.  s~(i,j) = xx_j - 2 (hi_i.hi_j + hi_i.lo_j + lo_i.hi_j) comes out of
-//           three bf16 MFMAs per k-step with xx_j as the accumulator's initial value.  Lane (n, h) holds 16 candidates of
+//           tiles (32 rows, A operand) round-robin.  s~(i,j) = |x_j|^2 - 2 x_i.x_j in coarse arithmetic comes out of one fp16
+//           (three bf16) MFMAs per k-step with the squared norm as the accumulator's initial value.  Lane (n, h) holds 16 candidates of
 //           ONE query per tile, so the running minimum of a tile group is a per-lane register: 64 group minima per query.
 //   tau     K-th smallest of the 64 group minima (distinct candidates, so at least K candidates have s~ <= tau);
 //           with |s~ - F| <= eps_i for every candidate (F = the oracle's distance minus the query's own squared norm, see
@@ -23,7 +27,8 @@
 //   slow    a query whose lists overflow (massive ties, fewer than K finite candidates) is redone by the whole workgroup
 //           from the oracle's distances of ALL candidates: exact, slow, rare.
 //
-// Error bound (n_i = |x_i|, R = max_j |x_j|, both rounded up):
+// Error bound of the bf16 form (n_i = |x_i|, R = max_j |x_j|, both rounded up; the fp16 form's terms are listed where eps is
+// computed, in the centred and scaled units):
 //   dropped product terms lo.lo + r.(..)   <= 3.1 * 2^-16 n_i R, times the factor 2          -> 1.0e-4 n_i R
 //   fp32 accumulation of 193 terms in the matrix core, any order, truncation allowed          -> 2.6e-5 (R^2 + 2.1 n_i R)
 //   the oracle's own fp32 chains against real arithmetic (dot, both norms, two roundings)     -> 9.0e-6 (n_i + R)^2
@@ -52,6 +57,7 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
 
@@ -83,14 +89,18 @@ __device__ __forceinline__ Split split2(float v) {
 
 // ---------------------------------------------------------------------------------------------------------------- prep
 // grid (Np / 32, B), 256 threads: 32 points = one operand tile.
-// KS = k-steps of 16 channels; PACK (c_knn <= 4): all three products share ONE k-step:
+// KS = k-steps of 16 channels.  HALF: ONE fp16 image of the centred, scaled points (one product per k-step).  Otherwise two
+// bf16 pieces of the points as they are (three products); PACK (c_knn <= 4) then packs all three into ONE k-step:
 //   k-slots 0-3 hi.qhi, 4-7 hi.qlo, 8-11 lo.qhi, 12-15 zero.
-template <int KS, bool PACK>
+template <int KS, bool PACK, bool HALF>
 __global__ __launch_bounds__(256) void knn_split_prep_kernel(const float *__restrict__ x, int N, int Np, long sb, long sc,
                                                              int c_knn, float *__restrict__ xx, float *__restrict__ xt,
-                                                             u32x4 *__restrict__ cand) {
+                                                             u32x4 *__restrict__ cand, float *__restrict__ xs,
+                                                             float *__restrict__ cscale) {
     constexpr int CP = PACK ? 4 : 16 * KS;
     __shared__ float slab[CP][33];
+    __shared__ float psum[4][64], mu[64], wred[4];
+    __shared__ int outl[32];
     const int tid = threadIdx.x, b = blockIdx.y, tile = blockIdx.x, j0 = tile * 32;
     const float *xb = x + (long)b * sb;
     {
@@ -99,16 +109,86 @@ __global__ __launch_bounds__(256) void knn_split_prep_kernel(const float *__rest
         for (int c = tid >> 5; c < CP; c += 8)
             slab[c][pt] = (c < c_knn && j0 + pt < N) ? xb[c * sc + j0 + pt] : 0.f;
     }
-    __syncthreads();
+    float sigma = 1.f;
+    if (HALF) {
+        // Centre and scale of the cloud for the fp16 image, from a fixed SAMPLE (four runs of 16 consecutive points at 0, N/4,
+        // N/2, 3N/4) that every workgroup of the cloud evaluates identically: any centre / scale is correct (the error bound
+        // is written in the centred, scaled norms; points far outside the sample's range are marked, see below), a
+        // representative one makes the bound tight.
+        const int c = tid & 63, g = tid >> 6;
+        float sv[16];
+        const int pos = min((int)(((long)g * N / 4) & ~15L), N - 16);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sv[i] = c < c_knn ? xb[c * sc + pos + i] : 0.f;
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a += sv[i];
+        psum[g][c] = a;
+        __syncthreads();
+        if (tid < 64) mu[tid] = (psum[0][tid] + psum[1][tid] + psum[2][tid] + psum[3][tid]) * (1.0f / 64.0f);
+        __syncthreads();
+        float dv = 0.f;
+        const float m = mu[c];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dv = fmaxf(dv, fabsf(sv[i] - m));
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) dv = fmaxf(dv, __shfl_xor(dv, off));
+        if ((tid & 63) == 0) wred[tid >> 6] = dv;
+        __syncthreads();
+        const float maxdev = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+        // power of two that maps the sample's largest deviation into [2^9, 2^10): fp16 keeps 11 bits down to 2^-14
+        int ex = (int)((__float_as_uint(maxdev) >> 23) & 255u) - 127;
+        int e2 = 9 - ex;
+        e2 = max(-100, min(100, e2));
+        sigma = (maxdev > 0.f && maxdev < 3.0e38f) ? __uint_as_float((unsigned)(e2 + 127) << 23) : 1.f;
+        if (tile == 0 && tid == 0) cscale[b] = sigma;
+    } else {
+        __syncthreads();
+    }
     if (tid < 32) {
         float a = 0.f;
         for (int c = 0; c < c_knn; ++c) a = __builtin_fmaf(slab[c][tid], slab[c][tid], a);
         xx[(long)b * Np + j0 + tid] = (j0 + tid < N) ? a : INFINITY;
+        if (HALF) {
+            // centred, scaled squared norm (the accumulator's initial value in the sweeps); a point with a coordinate beyond
+            // 2^14 (twice that is still a finite fp16) or a non-finite one is an OUTLIER: NaN here, zeros in the image --
+            // the main kernel sends every query of a cloud with an outlier through its exact slow path
+            float c2 = 0.f;
+            bool bad = false;
+            for (int c = 0; c < c_knn; ++c) {
+                const float v = (slab[c][tid] - mu[c]) * sigma;
+                bad |= !(fabsf(v) < 16384.0f);
+                c2 = __builtin_fmaf(v, v, c2);
+            }
+            bad &= j0 + tid < N;
+            outl[tid] = bad ? 1 : 0;
+            xs[(long)b * Np + j0 + tid] = (j0 + tid < N) ? (bad ? __uint_as_float(0x7FC00000u) : c2) : INFINITY;
+        }
     }
     for (int e = tid; e < 32 * (CP / 4); e += 256) {
         const int pt = e / (CP / 4), c4 = e % (CP / 4);
         f32x4 v = {slab[4 * c4][pt], slab[4 * c4 + 1][pt], slab[4 * c4 + 2][pt], slab[4 * c4 + 3][pt]};
         *reinterpret_cast<f32x4 *>(xt + ((long)b * Np + j0 + pt) * CP + 4 * c4) = v;
+    }
+    if (HALF) {
+        __syncthreads();   // outl
+        const long T = Np / 32;
+        for (int e = tid; e < KS * 64; e += 256) {
+            const int lane = e & 63, s = e >> 6;
+            const int m = lane & 31, h = lane >> 5;
+            unsigned cw[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = 16 * s + 8 * h + i;
+                float v = 0.f;
+                if (c < c_knn && !outl[m] && j0 + m < N) v = (slab[c < CP ? c : 0][m] - mu[c & 63]) * sigma;
+                const _Float16 hv = (_Float16)v;    // round to nearest even
+                cw[i] = (unsigned)__builtin_bit_cast(unsigned short, hv);
+            }
+            cand[(((long)b * T + tile) * KS + s) * 64 + lane] =
+                u32x4{cw[0] | (cw[1] << 16), cw[2] | (cw[3] << 16), cw[4] | (cw[5] << 16), cw[6] | (cw[7] << 16)};
+        }
+        return;
     }
     const long T = Np / 32;
     if (PACK) {
@@ -144,9 +224,9 @@ __global__ __launch_bounds__(256) void knn_split_prep_kernel(const float *__rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------- main
-template <int KS, bool PACK>
+template <int NOPS, bool TWO>
 struct Ops {
-    bf16x8 hi[PACK ? 1 : KS], lo[PACK ? 1 : KS];
+    u32x4 hi[NOPS], lo[TWO ? NOPS : 1];
 };
 
 // m = 2 m + (a <= thr): sixteen of these leave bit e = (a[e] <= thr) when fed e = 15 .. 0.  Plain C on purpose: an inline-asm
@@ -165,15 +245,19 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     return v;
 }
 
-template <int KS, bool PACK>
+template <int KS, bool PACK, bool HALF>
 __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *__restrict__ xx, const float *__restrict__ xt,
-                                                                  const u32x4 *__restrict__ cand, int N, int Np, int k,
+                                                                  const u32x4 *__restrict__ cand,
+                                                                  const float *__restrict__ xsg,
+                                                                  const float *__restrict__ cscale, int N, int Np, int k,
                                                                   int flags, int PC, int32_t *__restrict__ idx_out,
                                                                   float *__restrict__ dist_out) {
     constexpr int CP = PACK ? 4 : 16 * KS;
     constexpr int CPQ = CP + 4;
-    constexpr int NOP = PACK ? 1 : KS;     // operand blocks per piece and tile
-    constexpr int OPT = PACK ? 1 : 2 * KS; // 1-KiB operand blocks per tile
+    constexpr bool PK3 = PACK && !HALF;          // the packed three-product k-step (bf16 pieces, <= 4 channels)
+    constexpr int NOP = PK3 ? 1 : KS;            // operand blocks per piece and tile
+    constexpr int OPT = HALF ? KS : (PACK ? 1 : 2 * KS);   // 1-KiB operand blocks per tile
+    typedef Ops<NOP, !HALF && !PACK> OpsT;
     constexpr int QW = QB / WAVES;         // queries a wave refines
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int T = Np / 32;                       // candidate tiles
@@ -189,7 +273,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
     float *qrow = reinterpret_cast<float *>(plist + WAVES * PC);              // [QB][CPQ]: query row, then its squared norm
     float *thrL = qrow + QB * CPQ;                                            // [QB]
     int *slowq = reinterpret_cast<int *>(thrL + QB);                          // [QB]
-    float *red = reinterpret_cast<float *>(slowq + QB);                       // [16]
+    float *red = reinterpret_cast<float *>(slowq + QB);                       // [24]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
@@ -220,17 +304,36 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
     const float *xtb = xt + (long)b * Np * CP;
     const u32x4 *candb = cand + (long)b * T * OPT * 64 + lane;
 
-    // ---- setup: norms into LDS (+ their maximum), the workgroup's query rows, the query operands
-    float mx = 0.f;
+    // ---- setup: the norms the sweeps start their accumulators from into LDS (HALF: of the centred, scaled points; otherwise
+    // the oracle's), their maximum, the maximum of the oracle's norms; the workgroup's query rows, the query operands
+    const float *xsb = HALF ? xsg + (long)b * Np : xxb;
+    float mx = 0.f, mo = 0.f;
+    bool outlier = false;
     for (int j = tid * 4; j < Np; j += WAVES * 64 * 4) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(xxb + j);
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(xsb + j);
         *reinterpret_cast<f32x4 *>(xs + j) = v;
+        f32x4 vo = v;
+        if (HALF) vo = *reinterpret_cast<const f32x4 *>(xxb + j);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) mx = (j + e < N) ? fmaxf(mx, v[e]) : mx;
+        for (int e = 0; e < 4; ++e) {
+            if (j + e < N) {
+                outlier |= v[e] != v[e];            // NaN: the prep kernel's outlier mark
+                mx = fmaxf(mx, v[e]);
+                mo = fmaxf(mo, vo[e]);
+            }
+        }
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-    if (lane == 0) red[wave] = mx;
+    for (int off = 32; off >= 1; off >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+        mo = fmaxf(mo, __shfl_xor(mo, off));
+    }
+    const bool wave_outlier = __ballot(outlier) != 0;
+    if (lane == 0) {
+        red[wave] = mx;
+        red[8 + wave] = mo;
+        red[16 + wave] = wave_outlier ? 1.f : 0.f;
+    }
     for (int e = tid; e < QB * (CP / 4); e += WAVES * 64) {
         const int pt = e / (CP / 4), c4 = e % (CP / 4);
         *reinterpret_cast<f32x4 *>(qrow + pt * CPQ + 4 * c4) =
@@ -244,20 +347,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
     for (int bk = 0; bk < 2; ++bk)      // this thread's eight minimum slots: groups without a tile stay +inf
 #pragma unroll
         for (int g = 0; g < 4; ++g) mins[(32 * bk + n) * 64 + wave * 8 + h * 4 + g] = INFINITY;
-    // query operands: the candidate image of the workgroup's own two tiles times -2.  A bf16 doubles by one exponent step:
-    // (w ^ sign) + (1 << 7) per 16-bit half; a zero becomes 2^-126 (its products with the candidates' exact zeros in the
-    // padding channels stay zero, with real channels they are ~1e-38 |x|, nothing next to eps)
+    // query operands: the candidate image of the workgroup's own two tiles times -2.  A bf16 / fp16 doubles by one exponent
+    // step: (w ^ sign) + (1 << 7 | 1 << 10) per 16-bit half; a zero becomes the smallest normal number (bf16: ~1e-38, nothing;
+    // fp16: 2^-14, inside the absolute error term of eps; products with the exact zeros of padding channels stay zero)
     auto neg2 = [](u32x4 w) {
         u32x4 r;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = (w[e] ^ 0x80008000u) + 0x00800080u;
+        for (int e = 0; e < 4; ++e) r[e] = (w[e] ^ 0x80008000u) + (HALF ? 0x04000400u : 0x00800080u);
         return r;
     };
-    Ops<KS, PACK> qo[2];
+    OpsT qo[2];
 #pragma unroll
     for (int bk = 0; bk < 2; ++bk) {
         const u32x4 *p = candb + (long)(q0 / 32 + bk) * OPT * 64;
-        if (PACK) {
+        if (HALF) {
+#pragma unroll
+            for (int s = 0; s < NOP; ++s) qo[bk].hi[s] = neg2(p[s * 64]);
+        } else if (PACK) {
             // candidate block: lane (m, 0) = [hi | hi], lane (m, 1) = [lo | 0]; query block: (m, 0) = [hi | lo], (m, 1) = [hi | 0]
             const u32x4 mine = p[0], other = p[(lane ^ 32) - lane];
             u32x4 q;
@@ -265,33 +371,39 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
             else q = u32x4{other[0], other[1], 0u, 0u};
             q = neg2(q);
             if (h == 1) { q[2] = 0u; q[3] = 0u; }
-            qo[bk].hi[0] = __builtin_bit_cast(bf16x8, q);
+            qo[bk].hi[0] = q;
         } else {
 #pragma unroll
             for (int s = 0; s < NOP; ++s) {
-                qo[bk].hi[s] = __builtin_bit_cast(bf16x8, neg2(p[(2 * s) * 64]));
-                qo[bk].lo[s] = __builtin_bit_cast(bf16x8, neg2(p[(2 * s + 1) * 64]));
+                qo[bk].hi[s] = neg2(p[(2 * s) * 64]);
+                qo[bk].lo[s] = neg2(p[(2 * s + 1) * 64]);
             }
         }
     }
 
-    auto load_tile = [&](Ops<KS, PACK> &c, int t) {
+    auto load_tile = [&](OpsT &c, int t) {
         const u32x4 *p = candb + (long)t * OPT * 64;
 #pragma unroll
         for (int s = 0; s < NOP; ++s) {
-            c.hi[s] = __builtin_bit_cast(bf16x8, p[(PACK ? 0 : 2 * s) * 64]);
-            if (!PACK) c.lo[s] = __builtin_bit_cast(bf16x8, p[(2 * s + 1) * 64]);
+            c.hi[s] = p[(HALF ? s : (PACK ? 0 : 2 * s)) * 64];
+            if (!HALF && !PACK) c.lo[s] = p[(2 * s + 1) * 64];
         }
     };
     // s~ of the tile's 32 candidates (rows 8 (e/4) + 4 h + e%4) against the 32 queries of block bk (column n)
-    auto scores = [&](const Ops<KS, PACK> &c, const f32x16 &init, int bk) {
+    auto scores = [&](const OpsT &c, const f32x16 &init, int bk) {
         f32x16 acc = init;
 #pragma unroll
         for (int s = 0; s < NOP; ++s) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.hi[s], qo[bk].hi[s], acc, 0, 0, 0);
-            if (!PACK) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.hi[s], qo[bk].lo[s], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.lo[s], qo[bk].hi[s], acc, 0, 0, 0);
+            if (HALF) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, c.hi[s]),
+                                                             __builtin_bit_cast(f16x8, qo[bk].hi[s]), acc, 0, 0, 0);
+            } else {
+                const bf16x8 ch = __builtin_bit_cast(bf16x8, c.hi[s]), qh = __builtin_bit_cast(bf16x8, qo[bk].hi[s]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch, qh, acc, 0, 0, 0);
+                if (!PACK) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch, __builtin_bit_cast(bf16x8, qo[bk].lo[s]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c.lo[s]), qh, acc, 0, 0, 0);
+                }
             }
         }
         return acc;
@@ -322,7 +434,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
     // consumed right after its own chain, the vector work and the matrix work of the two waves of a SIMD line up in phase
     // and the matrix pipe idles during every consume -- measured: 1500 of 3100 cycles per tile).
     auto sweep = [&](auto &&f) {
-        Ops<KS, PACK> ring[3];
+        OpsT ring[3];
         if (TW > 0) load_tile(ring[0], tile_of(0));
         if (TW > 1) load_tile(ring[1], tile_of(1));
         int gi = 0, g = 0;          // tiles in the open minimum group, its index
@@ -383,10 +495,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
 
     // ---------------------------------------------------------------- tau and the acceptance bound per query
     {
-        float R2 = red[0];
+        float R2 = red[0], Ro2 = red[8], ao = red[16];
 #pragma unroll
-        for (int w = 1; w < WAVES; ++w) R2 = fmaxf(R2, red[w]);
-        const float R = sqrtf(R2) * 1.0001f;
+        for (int w = 1; w < WAVES; ++w) {
+            R2 = fmaxf(R2, red[w]);
+            Ro2 = fmaxf(Ro2, red[8 + w]);
+            ao = fmaxf(ao, red[16 + w]);
+        }
+        const bool any_outlier = ao != 0.f;
+        const float R = sqrtf(R2) * 1.0001f, Ro = sqrtf(Ro2) * 1.0001f;
+        const float sg = HALF ? cscale[b] : 1.f;
         // eight lanes per query, eight group minima per lane: the K-th smallest of the 64 by bisection on the key bits with
         // the counts summed over the eight lanes on the DPP network (no scalar round trips: the ballot version of this
         // search spent 2000 cycles per query on VALU -> SALU dependencies)
@@ -418,12 +536,29 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
         float thr;
         if (q0 + q >= N) {
             thr = -INFINITY;                                   // no such query
-        } else if (tau >= 0xFF800000u || (flags & 4194304)) {  // fewer than K finite minima / flag: force the slow path
+        } else if ((flags & 4194304) || any_outlier) {   // flag / a marked outlier in the cloud: straight to the slow path
+            thr = -INFINITY;
+            if ((lane & 7) == 0) slowq[q] = 1;
+        } else if (tau >= 0xFF800000u) {                 // fewer than K finite minima: every finite candidate is a nominee
             thr = 3.4028234e38f;
         } else {
             const float td = o2f(tau);
             const float ni = sqrtf(xq) * 1.0001f;
-            const float eps = (1.0e-4f * ni * R + 2.6e-5f * (R * R + 2.1f * ni * R) + 9.2e-6f * (ni + R) * (ni + R)) * 1.001f;
+            float eps;
+            if (HALF) {
+                // centred, scaled units (ni, R from xs; the oracle's norms no, Ro in original units, times the scale):
+                //   fp16 rounding of both operands, factor 2           2 (2^-10 + 2^-22) ni R            -> 1.96e-3 ni R
+                //   flushed / spurious values below 2^-14 (a = 2^-14)  2 (8 a (ni + R) + 64 a^2)         -> 9.8e-4 (ni + R) + 5e-7
+                //   fp32 accumulation of 65 terms in the matrix core   66 * 2^-23 (R^2 + 2.01 ni R)      -> 7.9e-6 (R^2 + 2.01 ni R)
+                //   centred norm chain, centring in fp32               3.8e-6 R^2 + 1.2e-7 (ni + R)^2
+                //   the oracle's own fp32 chains against real arithmetic                                  -> 9.2e-6 (sg (no + Ro))^2
+                const float no = sqrtf(qrow[q * CPQ + CP]) * 1.0001f;
+                const float so = sg * (no + Ro);
+                eps = (1.96e-3f * ni * R + 9.8e-4f * (ni + R) + 5e-7f + 7.9e-6f * (R * R + 2.01f * ni * R) + 3.8e-6f * R * R +
+                       1.2e-7f * (ni + R) * (ni + R) + 9.2e-6f * so * so) * 1.001f;
+            } else {
+                eps = (1.0e-4f * ni * R + 2.6e-5f * (R * R + 2.1f * ni * R) + 9.2e-6f * (ni + R) * (ni + R)) * 1.001f;
+            }
             thr = (td - xq) + 2.01f * eps + (fabsf(td) + xq) * 2.4e-7f;
             if (!(thr < 3.4028234e38f)) thr = 3.4028234e38f;
         }
@@ -706,9 +841,10 @@ struct SplitPlan {
     bool ok;
     int KS, CP, Np;
     bool pack;
-    size_t off_xx, off_xt, off_cand, total;
+    size_t off_xx, off_xt, off_cand, off_xs, off_scale, total;
 };
 
+// the workspace is sized for the larger of the two operand images (two bf16 pieces; the fp16 image is half of it)
 SplitPlan plan(int B, int N, int c_knn) {
     SplitPlan p{};
     p.ok = N >= 1024 && N <= 8192 && c_knn >= 1 && c_knn <= 64;
@@ -720,7 +856,9 @@ SplitPlan plan(int B, int N, int c_knn) {
     p.off_xx = 0;
     p.off_xt = align256(sizeof(float) * (size_t)B * p.Np);
     p.off_cand = p.off_xt + align256(sizeof(float) * (size_t)B * p.Np * p.CP);
-    p.total = p.off_cand + align256((size_t)B * T * opt * 1024);
+    p.off_xs = p.off_cand + align256((size_t)B * T * opt * 1024);
+    p.off_scale = p.off_xs + align256(sizeof(float) * (size_t)B * p.Np);
+    p.total = p.off_scale + align256(sizeof(float) * (size_t)B);
     return p;
 }
 
@@ -741,34 +879,45 @@ int fsg_knn_split_launch(const float *x, int B, int N, int64_t stride_b, int64_t
     float *xx = reinterpret_cast<float *>(w + p.off_xx);
     float *xt = reinterpret_cast<float *>(w + p.off_xt);
     u32x4 *cand = reinterpret_cast<u32x4 *>(w + p.off_cand);
+    float *xs = reinterpret_cast<float *>(w + p.off_xs);
+    float *cscale = reinterpret_cast<float *>(w + p.off_scale);
     const dim3 pgrid(p.Np / 32, B), grid(p.Np / 64, B);
     const int PC = N <= 4096 ? 1024 : 512;   // candidates a wave refines per batch (8 bytes of LDS each)
     const size_t T = p.Np / 32, CPQ = p.CP + 4;
     size_t usz = sizeof(float) * p.Np + 4 * ((QB * (T + 1) + 1) & ~(size_t)1);
     if (usz < 4 * (size_t)WAVES * 32 * CPQ) usz = 4 * (size_t)WAVES * 32 * CPQ;
     const size_t lds = ((usz + 15) & ~(size_t)15) + 8 * (size_t)WAVES * PC + sizeof(float) * QB * CPQ + sizeof(float) * QB +
-                       sizeof(int) * QB + sizeof(float) * 16;
-#define FSG_KNN_SPLIT(KSV, PK)                                                                                          \
+                       sizeof(int) * QB + sizeof(float) * 24;
+#define FSG_KNN_SPLIT(KSV, PK, HF)                                                                                      \
     do {                                                                                                               \
         static bool granted = false;                                                                                   \
         if (!granted) {                                                                                                \
-            if (hipFuncSetAttribute((const void *)knn_split_kernel<KSV, PK>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    160 * 1024) != hipSuccess) {                                                       \
+            if (hipFuncSetAttribute((const void *)knn_split_kernel<KSV, PK, HF>,                                       \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {           \
                 fsg_set_error("fsg_knn_dense_ws_f32: cannot raise dynamic LDS");                                       \
                 return FSG_ERR_HIP;                                                                                    \
             }                                                                                                          \
             granted = true;                                                                                            \
         }                                                                                                              \
-        hipLaunchKernelGGL((knn_split_prep_kernel<KSV, PK>), pgrid, dim3(256), 0, st, x, N, p.Np, (long)stride_b,       \
-                           (long)stride_c, c_knn, xx, xt, cand);                                                  \
-        hipLaunchKernelGGL((knn_split_kernel<KSV, PK>), grid, dim3(WAVES * 64), lds, st, xx, xt, cand, N, p.Np, k,  \
-                           flags, PC, idx_out, dist_out);                                                              \
+        hipLaunchKernelGGL((knn_split_prep_kernel<KSV, PK, HF>), pgrid, dim3(256), 0, st, x, N, p.Np, (long)stride_b,   \
+                           (long)stride_c, c_knn, xx, xt, cand, xs, cscale);                                           \
+        hipLaunchKernelGGL((knn_split_kernel<KSV, PK, HF>), grid, dim3(WAVES * 64), lds, st, xx, xt, cand, xs, cscale,  \
+                           N, p.Np, k, flags, PC, idx_out, dist_out);                                                  \
     } while (0)
     if (lds > 160 * 1024) return FSG_ERR_UNSUPPORTED;
-    if (p.pack) FSG_KNN_SPLIT(1, true);
-    else if (p.KS == 1) FSG_KNN_SPLIT(1, false);
-    else if (p.KS == 2) FSG_KNN_SPLIT(2, false);
-    else FSG_KNN_SPLIT(4, false);
+    // default above 4 channels: ONE fp16 product on the centred, scaled points; flag 1073741824: three bf16 products on the
+    // points as they are
+    // (the first form of this kernel: A/B timing, cross-check of the centred path)
+    if ((flags & 1073741824) || p.pack) {   // up to 4 channels the three bf16 products share ONE k-step: nothing to gain
+        if (p.pack) FSG_KNN_SPLIT(1, true, false);
+        else if (p.KS == 1) FSG_KNN_SPLIT(1, false, false);
+        else if (p.KS == 2) FSG_KNN_SPLIT(2, false, false);
+        else FSG_KNN_SPLIT(4, false, false);
+    } else {
+        if (p.KS == 1) FSG_KNN_SPLIT(1, false, true);
+        else if (p.KS == 2) FSG_KNN_SPLIT(2, false, true);
+        else FSG_KNN_SPLIT(4, false, true);
+    }
 #undef FSG_KNN_SPLIT
     FSG_CHECK_LAUNCH("fsg_knn_dense_ws_f32/split");
     return FSG_OK;

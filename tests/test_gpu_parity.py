@@ -80,6 +80,15 @@ def _split_inputs(kind, seed, B, C, Np):
         return np.concatenate([p, p], 2)
     if kind == "far":          # a tight cloud far from the origin: |x|^2 ~ 1e4 times the neighbour distances
         return (100.0 + 0.01 * g.standard_normal((B, C, Np))).astype(np.float32)
+    if kind == "outlier":      # one point far outside the range the fp16 image was scaled for: marked, the cloud goes the slow path
+        x = g.uniform(-1, 1, (B, C, Np)).astype(np.float32)
+        x[0, :, Np // 3] = 3.0e5
+        return x
+    if kind == "tiny":         # coordinates far below fp16's range before the power-of-two scaling
+        return (1e-9 * g.uniform(-1, 1, (B, C, Np))).astype(np.float32)
+    if kind == "sorted":       # spatially sorted cloud: the sampled centre sits in one corner
+        x = g.uniform(-1, 1, (B, C, Np)).astype(np.float32)
+        return np.take_along_axis(x, np.argsort(x[:, :1], axis=2).repeat(C, 1), axis=2)
     raise ValueError(kind)
 
 
@@ -90,12 +99,17 @@ def _split_inputs(kind, seed, B, C, Np):
     (2, 24, 1500, 20, None, True, True, "lowdim", 0), (1, 33, 4096, 63, None, True, True, "biased", 0),
     (1, 64, 1024, 64, None, True, False, "lowdim", 0), (2, 3, 1024, 20, None, True, False, "lattice", 0),
     (1, 16, 1100, 8, None, True, False, "far", 0), (1, 64, 2048, 20, None, True, False, "uniform", 4194304),
-    (1, 3, 1030, 40, None, True, True, "uniform", 4194304)])
+    (1, 3, 1030, 40, None, True, True, "uniform", 4194304), (2, 16, 1024, 20, None, True, False, "outlier", 0),
+    (2, 16, 1024, 20, None, True, False, "tiny", 0), (2, 40, 2048, 20, None, True, True, "sorted", 0),
+    (2, 64, 2048, 20, None, True, False, "biased", 1073741824), (2, 24, 1500, 20, None, True, True, "lowdim", 1073741824),
+    (1, 64, 1024, 64, None, True, False, "lowdim", 1073741824)])
 def test_knn_split_kernel_bit_exact_vs_c_oracle(fsg, device, B, C, Np, k, c_knn, fix, drop, kind, flags):
-    """fsg_knn_dense_ws_f32's coarse-sweep + exact-refine kernel (csrc/knn_split.hip: split-bf16 MFMA products only NOMINATE
+    """fsg_knn_dense_ws_f32's coarse-sweep + exact-refine kernel (csrc/knn_split.hip: fp16 MFMA products on the centred, scaled
+    points -- or three bf16 products on the points as they are: flag 1073741824, and always up to 4 channels -- only NOMINATE
     candidates under a rigorous error bound; every ranked distance is the oracle's fp32 fma chain): indices and distance bits
-    equal the C oracle's on inputs that stress the bound (common mean, manifold features, far-from-origin clouds, ties);
-    flag 4194304 sends every query through the kernel's slow exact path."""
+    equal the C oracle's on inputs that stress the bound (common mean, manifold features, far-from-origin clouds, ties, an
+    outlier beyond the fp16 range, values below it, a spatially sorted cloud); flag 4194304 sends every query through the
+    kernel's slow exact path."""
     x = _split_inputs(kind, 77 + Np + C, B, C, Np)
     idx, dist = fsg.functional.knn_graph(G(x, device), k, c_knn=c_knn, fix_diag=fix, drop_first=drop, return_dist=True,
                                          _debug_flags=flags)

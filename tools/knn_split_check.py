@@ -30,6 +30,11 @@ def feats(seed, B, C, N, kind):
         x = torch.cat([p, p], 2)
     elif kind == "const":
         x = torch.ones(B, C, N)
+    elif kind == "outlier":     # one point far outside the sampled range: the fp16 image marks it, the cloud takes the slow path
+        x = torch.rand(B, C, N, generator=g) * 2 - 1
+        x[0, :, N // 3] = 3.0e5
+    elif kind == "tiny":        # everything far below fp16's normal range before scaling
+        x = (torch.rand(B, C, N, generator=g) * 2 - 1) * 1e-9
     return x.contiguous()
 
 
@@ -96,6 +101,12 @@ if __name__ == "__main__":
         ok &= check(2, 3, 1024, 20, "dups")
         ok &= check(1, 16, 1024, 8, "const")
         ok &= check(2, 64, 2048, 20, "uniform", flags=4194304)   # everything through the slow path
+        ok &= check(2, 16, 1024, 20, "outlier", oracle=True)
+        ok &= check(2, 16, 1024, 20, "tiny", oracle=True)
+        for fl in (1073741824,):                                 # the three-product bf16 form
+            ok &= check(2, 64, 2048, 20, "biased", flags=fl)
+            ok &= check(2, 3, 2048, 20, "uniform", flags=fl, oracle=True)
+            ok &= check(1, 33, 4096, 63, "biased", drop=True, flags=fl)
         print("ALL EQUAL" if ok else "MISMATCH", flush=True)
     import ctypes
     lib = fsg._lib.lib
@@ -113,6 +124,6 @@ if __name__ == "__main__":
     for (B, C, N, k, kind) in [(8, 64, 2048, 20, "biased"), (8, 64, 2048, 20, "lowdim"), (8, 64, 2048, 20, "uniform"),
                                (8, 3, 2048, 20, "uniform"), (4, 64, 8192, 40, "lowdim"), (4, 3, 8192, 40, "uniform"),
                                (32, 3, 2048, 40, "uniform"), (8, 3, 4096, 20, "uniform")]:
-        tn, to = timeit(B, C, N, k, kind, 0), timeit(B, C, N, k, kind, OLD)
-        print(f"time B={B} C={C} N={N} k={k} {kind:8s}: split {tn:8.1f} us   two-phase {to:8.1f} us", flush=True)
+        tn, tb, to = timeit(B, C, N, k, kind, 0), timeit(B, C, N, k, kind, 1073741824), timeit(B, C, N, k, kind, OLD)
+        print(f"time B={B} C={C} N={N} k={k} {kind:8s}: split fp16 {tn:8.1f} us   split 3 x bf16 {tb:8.1f} us   two-phase {to:8.1f} us", flush=True)
     sys.exit(0 if ok else 1)
