@@ -87,6 +87,30 @@ __device__ __forceinline__ Split split2(float v) {
     return s;
 }
 
+// wave-wide sum / maximum of a float on the DPP network (row_shr 1,2,4,8, then the row totals broadcast down): lane 63 holds
+// the result, returned to every lane through a scalar read
+__device__ __forceinline__ float wave_sum_f(float v) {
+#define FSG_DPP_F(x, ctrl, rm, bc) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, rm, 0xf, bc))
+    v += FSG_DPP_F(v, 0x111, 0xf, true);
+    v += FSG_DPP_F(v, 0x112, 0xf, true);
+    v += FSG_DPP_F(v, 0x114, 0xf, true);
+    v += FSG_DPP_F(v, 0x118, 0xf, true);
+    v += FSG_DPP_F(v, 0x142, 0xa, false);
+    v += FSG_DPP_F(v, 0x143, 0xc, false);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// maximum of NON-NEGATIVE floats (a masked-out DPP source reads as +0, the identity here)
+__device__ __forceinline__ float wave_max_nonneg_f(float v) {
+    v = fmaxf(v, FSG_DPP_F(v, 0x111, 0xf, true));
+    v = fmaxf(v, FSG_DPP_F(v, 0x112, 0xf, true));
+    v = fmaxf(v, FSG_DPP_F(v, 0x114, 0xf, true));
+    v = fmaxf(v, FSG_DPP_F(v, 0x118, 0xf, true));
+    v = fmaxf(v, FSG_DPP_F(v, 0x142, 0xa, false));
+    v = fmaxf(v, FSG_DPP_F(v, 0x143, 0xc, false));
+#undef FSG_DPP_F
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // ---------------------------------------------------------------------------------------------------------------- prep
 // grid (Np / 32, B), 256 threads: 32 points = one operand tile.
 // KS = k-steps of 16 channels.  HALF: ONE fp16 image of the centred, scaled points (one product per k-step).  Otherwise two
@@ -99,8 +123,7 @@ __global__ __launch_bounds__(256) void knn_split_prep_kernel(const float *__rest
                                                              float *__restrict__ cscale) {
     constexpr int CP = PACK ? 4 : 16 * KS;
     __shared__ float slab[CP][33];
-    __shared__ float psum[4][64], mu[64], wred[4];
-    __shared__ int outl[32];
+    __shared__ float mu[64], wred[4];
     const int tid = threadIdx.x, b = blockIdx.y, tile = blockIdx.x, j0 = tile * 32;
     const float *xb = x + (long)b * sb;
     {
@@ -115,25 +138,21 @@ __global__ __launch_bounds__(256) void knn_split_prep_kernel(const float *__rest
         // N/2, 3N/4) that every workgroup of the cloud evaluates identically: any centre / scale is correct (the error bound
         // is written in the centred, scaled norms; points far outside the sample's range are marked, see below), a
         // representative one makes the bound tight.
-        const int c = tid & 63, g = tid >> 6;
+        // lane = sample point (coalesced: a wave-load reads four 64-byte runs of one channel), wave w takes channels w + 4 r
+        const int sp = tid & 63, w = tid >> 6;
+        const int pos = min((int)(((long)(sp >> 4) * N / 4) & ~15L), N - 16) + (sp & 15);
         float sv[16];
-        const int pos = min((int)(((long)g * N / 4) & ~15L), N - 16);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sv[i] = c < c_knn ? xb[c * sc + pos + i] : 0.f;
-        float a = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) a += sv[i];
-        psum[g][c] = a;
-        __syncthreads();
-        if (tid < 64) mu[tid] = (psum[0][tid] + psum[1][tid] + psum[2][tid] + psum[3][tid]) * (1.0f / 64.0f);
-        __syncthreads();
+        for (int r = 0; r < 16; ++r) sv[r] = (w + 4 * r) < c_knn ? xb[(long)(w + 4 * r) * sc + pos] : 0.f;
         float dv = 0.f;
-        const float m = mu[c];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dv = fmaxf(dv, fabsf(sv[i] - m));
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) dv = fmaxf(dv, __shfl_xor(dv, off));
-        if ((tid & 63) == 0) wred[tid >> 6] = dv;
+        for (int r = 0; r < 16; ++r) {
+            const float m = wave_sum_f(sv[r]) * (1.0f / 64.0f);
+            if (sp == 0) mu[w + 4 * r] = m;
+            dv = fmaxf(dv, fabsf(sv[r] - m));
+        }
+        dv = wave_max_nonneg_f(dv);
+        if (sp == 0) wred[w] = dv;
         __syncthreads();
         const float maxdev = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
         // power of two that maps the sample's largest deviation into [2^9, 2^10): fp16 keeps 11 bits down to 2^-14
@@ -146,22 +165,34 @@ __global__ __launch_bounds__(256) void knn_split_prep_kernel(const float *__rest
         __syncthreads();
     }
     if (tid < 32) {
-        float a = 0.f;
-        for (int c = 0; c < c_knn; ++c) a = __builtin_fmaf(slab[c][tid], slab[c][tid], a);
+        // the oracle's squared norm (channel-ordered fma chain from +0) and, HALF, the centred scaled one (the accumulator's
+        // initial value in the sweeps); eight LDS reads in flight per step.  A point with a centred coordinate beyond 2^14
+        // (twice that is still a finite fp16) or a non-finite one is an OUTLIER: NaN norm -- the main kernel sends every
+        // query of a cloud with an outlier through its exact slow path and never looks at a coarse score of that cloud
+        float a = 0.f, c2 = 0.f;
+        bool bad = false;
+        constexpr int CB = CP < 8 ? CP : 8;
+#pragma unroll
+        for (int c0 = 0; c0 < CP; c0 += CB) {
+            float v[CB], m[CB];
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                v[u] = slab[c0 + u][tid];           // channels >= c_knn hold 0: fma(0, 0, a) = a exactly
+                m[u] = HALF ? mu[c0 + u] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                a = __builtin_fmaf(v[u], v[u], a);
+                if (HALF) {
+                    const float vs = (c0 + u < c_knn) ? (v[u] - m[u]) * sigma : 0.f;
+                    bad |= !(fabsf(vs) < 16384.0f);
+                    c2 = __builtin_fmaf(vs, vs, c2);
+                }
+            }
+        }
         xx[(long)b * Np + j0 + tid] = (j0 + tid < N) ? a : INFINITY;
         if (HALF) {
-            // centred, scaled squared norm (the accumulator's initial value in the sweeps); a point with a coordinate beyond
-            // 2^14 (twice that is still a finite fp16) or a non-finite one is an OUTLIER: NaN here, zeros in the image --
-            // the main kernel sends every query of a cloud with an outlier through its exact slow path
-            float c2 = 0.f;
-            bool bad = false;
-            for (int c = 0; c < c_knn; ++c) {
-                const float v = (slab[c][tid] - mu[c]) * sigma;
-                bad |= !(fabsf(v) < 16384.0f);
-                c2 = __builtin_fmaf(v, v, c2);
-            }
             bad &= j0 + tid < N;
-            outl[tid] = bad ? 1 : 0;
             xs[(long)b * Np + j0 + tid] = (j0 + tid < N) ? (bad ? __uint_as_float(0x7FC00000u) : c2) : INFINITY;
         }
     }
@@ -171,7 +202,7 @@ __global__ __launch_bounds__(256) void knn_split_prep_kernel(const float *__rest
         *reinterpret_cast<f32x4 *>(xt + ((long)b * Np + j0 + pt) * CP + 4 * c4) = v;
     }
     if (HALF) {
-        __syncthreads();   // outl
+        // (an outlier's row is NOT zeroed: its cloud never uses a coarse score -- every query of it takes the slow path)
         const long T = Np / 32;
         for (int e = tid; e < KS * 64; e += 256) {
             const int lane = e & 63, s = e >> 6;
@@ -181,7 +212,7 @@ __global__ __launch_bounds__(256) void knn_split_prep_kernel(const float *__rest
             for (int i = 0; i < 8; ++i) {
                 const int c = 16 * s + 8 * h + i;
                 float v = 0.f;
-                if (c < c_knn && !outl[m] && j0 + m < N) v = (slab[c < CP ? c : 0][m] - mu[c & 63]) * sigma;
+                if (c < c_knn && j0 + m < N) v = (slab[c < CP ? c : 0][m] - mu[c & 63]) * sigma;
                 const _Float16 hv = (_Float16)v;    // round to nearest even
                 cw[i] = (unsigned)__builtin_bit_cast(unsigned short, hv);
             }
