@@ -15,8 +15,8 @@
 //   sweep 1 a workgroup owns 64 queries (two 32-column blocks, resident as B operands); its 8 waves take the candidate
 //           tiles (32 rows, A operand) round-robin.  s~(i,j) = |x_j|^2 - 2 x_i.x_j in coarse arithmetic comes out of one fp16
 //           (three bf16) MFMAs per k-step with the squared norm as the accumulator's initial value.  Lane (n, h) holds 16 candidates of
-//           ONE query per tile, so the running minimum of a tile group is a per-lane register: 64 group minima per query.
-//   tau     K-th smallest of the 64 group minima (distinct candidates, so at least K candidates have s~ <= tau);
+//           ONE query per tile, so the running minimum of a tile group is a per-lane register: 128 group minima per query.
+//   tau     K-th smallest of the 128 group minima (distinct candidates, so at least K candidates have s~ <= tau);
 //           with |s~ - F| <= eps_i for every candidate (F = the oracle's distance minus the query's own squared norm, see
 //           the bound below) the K-th smallest oracle distance is <= tau + eps_i and every true neighbour has
 //           s~ <= tau + 2 eps_i.
@@ -63,6 +63,8 @@ typedef unsigned long long u64;
 
 constexpr int QB = 64;        // queries per workgroup
 constexpr int WAVES = 8;
+constexpr int MSL = 4;         // group-minimum slots per lane and query block in sweep 1
+constexpr int NMIN = 2 * WAVES * MSL;   // group minima per query (128): tau = the K-th smallest of them
 
 __device__ __forceinline__ unsigned f2o(float d) {
     const unsigned u = __float_as_uint(d);
@@ -299,7 +301,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
     float *mins = reinterpret_cast<float *>(bm);                              // [QB][64] group minima (sweep 1), same storage
     float *stage = reinterpret_cast<float *>(smem);                           // [WAVES][32][CPQ] candidate rows (refine)
     float *dl = reinterpret_cast<float *>(smem);                              // slow path: [N] distances
-    const size_t usz = max((size_t)4 * Np + 4 * (((size_t)QB * RSW + 1) & ~(size_t)1), (size_t)4 * WAVES * 32 * CPQ);
+    const size_t usz = max((size_t)4 * Np + max((size_t)4 * (((size_t)QB * RSW + 1) & ~(size_t)1), (size_t)4 * QB * NMIN),
+                           (size_t)4 * WAVES * 32 * CPQ);
     u64 *plist = reinterpret_cast<u64 *>(smem + ((usz + 15) & ~(size_t)15)); // [WAVES][PC] candidates, then keys, of a batch
     float *qrow = reinterpret_cast<float *>(plist + WAVES * PC);              // [QB][CPQ]: query row, then its squared norm
     float *thrL = qrow + QB * CPQ;                                            // [QB]
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
     const int KK = k + drop;
     const bool fix_diag = (flags & FSG_KNN_FIX_DIAG) != 0;
     const int TW = (T - wave + WAVES - 1) / WAVES;   // tiles of this wave (round-robin: tile = wave + 8 i)
-    const int G = ((T + WAVES - 1) / WAVES + 3) / 4; // tiles per minimum group (the same for every wave)
+    const int G = ((T + WAVES - 1) / WAVES + MSL - 1) / MSL;   // tiles per minimum group (the same for every wave)
     const float *xxb = xx + (long)b * Np;
     const float *xtb = xt + (long)b * Np * CP;
     const u32x4 *candb = cand + (long)b * T * OPT * 64 + lane;
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
 #pragma unroll
     for (int bk = 0; bk < 2; ++bk)      // this thread's eight minimum slots: groups without a tile stay +inf
 #pragma unroll
-        for (int g = 0; g < 4; ++g) mins[(32 * bk + n) * 64 + wave * 8 + h * 4 + g] = INFINITY;
+        for (int g = 0; g < MSL; ++g) mins[(32 * bk + n) * NMIN + wave * 2 * MSL + h * MSL + g] = INFINITY;
     // query operands: the candidate image of the workgroup's own two tiles times -2.  A bf16 / fp16 doubles by one exponent
     // step: (w ^ sign) + (1 << 7 | 1 << 10) per 16-bit half; a zero becomes the smallest normal number (bf16: ~1e-38, nothing;
     // fp16: 2^-14, inside the absolute error term of eps; products with the exact zeros of padding channels stay zero)
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
     // ---------------------------------------------------------------- sweep 1: group minima
     {
         float run[2] = {INFINITY, INFINITY};
-        float *mp[2] = {mins + n * 64 + wave * 8 + h * 4, mins + (32 + n) * 64 + wave * 8 + h * 4};
+        float *mp[2] = {mins + n * NMIN + wave * 2 * MSL + h * MSL, mins + (32 + n) * NMIN + wave * 2 * MSL + h * MSL};
         sweep([&](const f32x16 &a, int bk, int t, int g, bool gend) {
             (void)t;
             float r = run[bk];
@@ -536,20 +539,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
         const bool any_outlier = ao != 0.f;
         const float R = sqrtf(R2) * 1.0001f, Ro = sqrtf(Ro2) * 1.0001f;
         const float sg = HALF ? cscale[b] : 1.f;
-        // eight lanes per query, eight group minima per lane: the K-th smallest of the 64 by bisection on the key bits with
+        // eight lanes per query, sixteen group minima per lane: the K-th smallest of the 128 by bisection on the key bits with
         // the counts summed over the eight lanes on the DPP network (no scalar round trips: the ballot version of this
         // search spent 2000 cycles per query on VALU -> SALU dependencies)
         const int q = wave * QW + (lane >> 3);
         const float xq = (q0 + q < N) ? xs[q0 + q] : 0.f;
-        const f32x4 va = *reinterpret_cast<const f32x4 *>(mins + q * 64 + 8 * (lane & 7));
-        const f32x4 vb = *reinterpret_cast<const f32x4 *>(mins + q * 64 + 8 * (lane & 7) + 4);
-        unsigned key[8];
+        constexpr int KPL = NMIN / 8;    // minima per lane of the eight that share a query
+        unsigned key[KPL];
         // the search runs on distances (minimum + the query's norm): rounding tau up by 2^-11 of a DISTANCE is harmless,
         // 2^-11 of s~ = d - |x_i|^2 would not be for clouds far from the origin
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            key[e] = f2o(va[e] + xq);
-            key[4 + e] = f2o(vb[e] + xq);
+        for (int e4 = 0; e4 < KPL / 4; ++e4) {
+            const f32x4 va = *reinterpret_cast<const f32x4 *>(mins + q * NMIN + KPL * (lane & 7) + 4 * e4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) key[4 * e4 + e] = f2o(va[e] + xq);
         }
         unsigned prefix = 0u;
 #pragma unroll 2
@@ -557,7 +560,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
             const unsigned t = prefix | ((1u << bit) - 1u);
             int c = 0;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) c += key[e] <= t ? 1 : 0;
+            for (int e = 0; e < KPL; ++e) c += key[e] <= t ? 1 : 0;
             c += __builtin_amdgcn_update_dpp(0, c, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
             c += __builtin_amdgcn_update_dpp(0, c, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
             c += __builtin_amdgcn_update_dpp(0, c, 0x141, 0xf, 0xf, true);   // row_half_mirror: the other quad of the eight
@@ -915,7 +918,9 @@ int fsg_knn_split_launch(const float *x, int B, int N, int64_t stride_b, int64_t
     const dim3 pgrid(p.Np / 32, B), grid(p.Np / 64, B);
     const int PC = N <= 4096 ? 1024 : 512;   // candidates a wave refines per batch (8 bytes of LDS each)
     const size_t T = p.Np / 32, CPQ = p.CP + 4;
-    size_t usz = sizeof(float) * p.Np + 4 * ((QB * (T + 1) + 1) & ~(size_t)1);
+    size_t bmb = 4 * ((QB * (T + 1) + 1) & ~(size_t)1);
+    if (bmb < (size_t)4 * QB * NMIN) bmb = (size_t)4 * QB * NMIN;
+    size_t usz = sizeof(float) * p.Np + bmb;
     if (usz < 4 * (size_t)WAVES * 32 * CPQ) usz = 4 * (size_t)WAVES * 32 * CPQ;
     const size_t lds = ((usz + 15) & ~(size_t)15) + 8 * (size_t)WAVES * PC + sizeof(float) * QB * CPQ + sizeof(float) * QB +
                        sizeof(int) * QB + sizeof(float) * 24;
