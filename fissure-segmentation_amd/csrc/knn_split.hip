@@ -1,5 +1,5 @@
 // Dense kNN graph build, "coarse sweep + exact refine" kernel behind fsg_knn_dense_ws_f32
-// (1024 <= N <= 8192, c_knn <= 64, k + drop <= 64).  Replaces utils/general_utils.py:43-53,315-327 like the two-phase
+// (1024 <= N <= 8192, c_knn <= 128 (above 64 channels up to N = 4096), k + drop <= 64).  Replaces utils/general_utils.py:43-53,315-327 like the two-phase
 // kernel of knn_rows_mfma.hip and returns the SAME bits (indices and distances of oracle/fsg_oracle.c): the matrix
 // cores only nominate candidates, every distance that is ranked or returned is the oracle's fp32 fma chain.
 //
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void knn_split_prep_kernel(const float *__rest
                                                              float *__restrict__ cscale) {
     constexpr int CP = PACK ? 4 : 16 * KS;
     __shared__ float slab[CP][33];
-    __shared__ float mu[64], wred[4];
+    __shared__ float mu[CP < 64 ? 64 : CP], wred[4];
     const int tid = threadIdx.x, b = blockIdx.y, tile = blockIdx.x, j0 = tile * 32;
     const float *xb = x + (long)b * sb;
     {
@@ -143,12 +143,13 @@ __global__ __launch_bounds__(256) void knn_split_prep_kernel(const float *__rest
         // lane = sample point (coalesced: a wave-load reads four 64-byte runs of one channel), wave w takes channels w + 4 r
         const int sp = tid & 63, w = tid >> 6;
         const int pos = min((int)(((long)(sp >> 4) * N / 4) & ~15L), N - 16) + (sp & 15);
-        float sv[16];
+        constexpr int NR = CP <= 64 ? 16 : CP / 4;   // channels per wave
+        float sv[NR];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sv[r] = (w + 4 * r) < c_knn ? xb[(long)(w + 4 * r) * sc + pos] : 0.f;
+        for (int r = 0; r < NR; ++r) sv[r] = (w + 4 * r) < c_knn ? xb[(long)(w + 4 * r) * sc + pos] : 0.f;
         float dv = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < NR; ++r) {
             const float m = wave_sum_f(sv[r]) * (1.0f / 64.0f);
             if (sp == 0) mu[w + 4 * r] = m;
             dv = fmaxf(dv, fabsf(sv[r] - m));
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void knn_split_prep_kernel(const float *__rest
             for (int i = 0; i < 8; ++i) {
                 const int c = 16 * s + 8 * h + i;
                 float v = 0.f;
-                if (c < c_knn && j0 + m < N) v = (slab[c < CP ? c : 0][m] - mu[c & 63]) * sigma;
+                if (c < c_knn && j0 + m < N) v = (slab[c < CP ? c : 0][m] - mu[c]) * sigma;
                 const _Float16 hv = (_Float16)v;    // round to nearest even
                 cw[i] = (unsigned)__builtin_bit_cast(unsigned short, hv);
             }
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
     constexpr int OPT = HALF ? KS : (PACK ? 1 : 2 * KS);   // 1-KiB operand blocks per tile
     typedef Ops<NOP, !HALF && !PACK> OpsT;
     constexpr int QW = QB / WAVES;         // queries a wave refines
+    constexpr int PR = CP > 64 ? 16 : 32;  // candidate rows per refine pass (the LDS stage holds PR rows per wave)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int T = Np / 32;                       // candidate tiles
     const int RSW = T + 1;                       // bitmap row stride in 32-bit words (one word per tile + 1: no bank conflicts)
@@ -299,10 +301,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
     float *xs = reinterpret_cast<float *>(smem);                              // [Np] squared norms (sweeps only)
     unsigned *bm = reinterpret_cast<unsigned *>(xs + Np);                     // [QB][RSW] survivor bitmaps (sweep 2)
     float *mins = reinterpret_cast<float *>(bm);                              // [QB][64] group minima (sweep 1), same storage
-    float *stage = reinterpret_cast<float *>(smem);                           // [WAVES][32][CPQ] candidate rows (refine)
+    float *stage = reinterpret_cast<float *>(smem);                           // [WAVES][PR][CPQ] candidate rows (refine)
     float *dl = reinterpret_cast<float *>(smem);                              // slow path: [N] distances
     const size_t usz = max((size_t)4 * Np + max((size_t)4 * (((size_t)QB * RSW + 1) & ~(size_t)1), (size_t)4 * QB * NMIN),
-                           (size_t)4 * WAVES * 32 * CPQ);
+                           (size_t)4 * WAVES * PR * CPQ);
     u64 *plist = reinterpret_cast<u64 *>(smem + ((usz + 15) & ~(size_t)15)); // [WAVES][PC] candidates, then keys, of a batch
     float *qrow = reinterpret_cast<float *>(plist + WAVES * PC);              // [QB][CPQ]: query row, then its squared norm
     float *thrL = qrow + QB * CPQ;                                            // [QB]
@@ -627,15 +629,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
     auto exact_d = [&](int q, int j) {
         const float *row = xtb + (long)j * CP;
         const float *qr = qrow + q * CPQ;
-        f32x4 v[CP / 4];
-#pragma unroll
-        for (int c4 = 0; c4 < CP / 4; ++c4) v[c4] = *reinterpret_cast<const f32x4 *>(row + 4 * c4);
+        constexpr int CH = CP / 4 >= 8 ? 8 : CP / 4;   // 16-byte pieces in flight
         float dot = 0.f;
 #pragma unroll
-        for (int c4 = 0; c4 < CP / 4; ++c4) {
-            const f32x4 qv = *reinterpret_cast<const f32x4 *>(qr + 4 * c4);
+        for (int c0 = 0; c0 < CP / 4; c0 += CH) {
+            f32x4 v[CH];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dot = __builtin_fmaf(qv[e], v[c4][e], dot);
+            for (int c4 = 0; c4 < CH; ++c4) v[c4] = *reinterpret_cast<const f32x4 *>(row + 4 * (c0 + c4));
+#pragma unroll
+            for (int c4 = 0; c4 < CH; ++c4) {
+                const f32x4 qv = *reinterpret_cast<const f32x4 *>(qr + 4 * (c0 + c4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dot = __builtin_fmaf(qv[e], v[c4][e], dot);
+            }
         }
         const float tt = qr[CP] - 2.0f * dot;
         float d = tt + xxb[j];
@@ -644,7 +650,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
     };
     {
         u64 *pl = plist + wave * PC;
-        float *stg = stage + wave * 32 * CPQ;
+        float *stg = stage + wave * PR * CPQ;
         const int qbase = wave * QW;
         // ---- this wave's bitmap rows into registers (the stage overwrites the bitmaps), survivor counts of all its queries
         constexpr int WMAX = 4;                      // bitmap words per lane and query: T <= 256
@@ -690,7 +696,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
 
         constexpr int LPR = CP / 4;                  // lanes (16-byte pieces) per candidate row
         constexpr int RPI = 64 / LPR;                // rows per load instruction
-        constexpr int NI = RPI >= 32 ? 1 : 32 / RPI; // load instructions per pass of 32 rows
+        constexpr int NI = RPI >= PR ? 1 : PR / RPI; // load instructions per pass of PR rows
         const int lrow = lane / LPR, lpc = lane % LPR;
         int qnext = 0;
         while (qnext < QW) {      // wave-uniform: a batch = as many of the next queries as fit PC candidates
@@ -752,18 +758,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
             auto issue = [&](int p0) {
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
-                    const int r = min(i * RPI + lrow, 31);
+                    const int r = min(i * RPI + lrow, PR - 1);
                     const int j = (int)(unsigned)pl[min(p0 + r, P - 1)];
                     g[i] = *reinterpret_cast<const f32x4 *>(xtb + (long)j * CP + 4 * lpc);
                 }
-                jn = (int)(unsigned)pl[min(p0 + (lane & 31), P - 1)];
+                jn = (int)(unsigned)pl[min(p0 + (lane & (PR - 1)), P - 1)];
                 xn = xxb[jn];
             };
             auto commit = [&]() {
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     const int r = i * RPI + lrow;
-                    if (r < 32) *reinterpret_cast<f32x4 *>(stg + r * CPQ + 4 * lpc) = g[i];
+                    if (r < PR) *reinterpret_cast<f32x4 *>(stg + r * CPQ + 4 * lpc) = g[i];
                 }
                 jc = jn;
                 xc = xn;
@@ -773,11 +779,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
                 commit();
             }
             if (qend == QW) stamp(12);
-            for (int p0 = 0; p0 < P; p0 += 32) {
+            for (int p0 = 0; p0 < P; p0 += PR) {
                 __builtin_amdgcn_wave_barrier();
-                if (p0 + 32 < P) issue(p0 + 32);
+                if (p0 + PR < P) issue(p0 + PR);
                 const int p = p0 + lane;
-                if (lane < 32 && p < P) {
+                if (lane < PR && p < P) {
                     int ql, s, e;
                     which(p, ql, s, e);
                     const float *qr = qrow + (qbase + ql) * CPQ;
@@ -804,7 +810,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
                     pl[p] = ((u64)f2o(d) << 32) | (unsigned)jc;
                 }
                 __builtin_amdgcn_wave_barrier();
-                if (p0 + 32 < P) commit();
+                if (p0 + PR < P) commit();
             }
             __builtin_amdgcn_wave_barrier();
             if (qend == QW) stamp(13);
@@ -881,12 +887,12 @@ struct SplitPlan {
 // the workspace is sized for the larger of the two operand images (two bf16 pieces; the fp16 image is half of it)
 SplitPlan plan(int B, int N, int c_knn) {
     SplitPlan p{};
-    p.ok = N >= 1024 && N <= 8192 && c_knn >= 1 && c_knn <= 64;
+    p.ok = N >= 1024 && N <= 8192 && c_knn >= 1 && c_knn <= 128;
     p.pack = c_knn <= 4;
-    p.KS = p.pack ? 1 : (c_knn <= 16 ? 1 : (c_knn <= 32 ? 2 : 4));
+    p.KS = p.pack ? 1 : (c_knn <= 16 ? 1 : (c_knn <= 32 ? 2 : (c_knn <= 64 ? 4 : 8)));
     p.CP = p.pack ? 4 : 16 * p.KS;
     p.Np = (N + 63) & ~63;
-    const size_t T = p.Np / 32, opt = p.pack ? 1 : 2 * p.KS;
+    const size_t T = p.Np / 32, opt = p.pack ? 1 : (p.KS == 8 ? 8 : 2 * p.KS);   // 8 k-steps: fp16 image only
     p.off_xx = 0;
     p.off_xt = align256(sizeof(float) * (size_t)B * p.Np);
     p.off_cand = p.off_xt + align256(sizeof(float) * (size_t)B * p.Np * p.CP);
@@ -916,14 +922,19 @@ int fsg_knn_split_launch(const float *x, int B, int N, int64_t stride_b, int64_t
     float *xs = reinterpret_cast<float *>(w + p.off_xs);
     float *cscale = reinterpret_cast<float *>(w + p.off_scale);
     const dim3 pgrid(p.Np / 32, B), grid(p.Np / 64, B);
-    const int PC = N <= 4096 ? 1024 : 512;   // candidates a wave refines per batch (8 bytes of LDS each)
-    const size_t T = p.Np / 32, CPQ = p.CP + 4;
+    const size_t T = p.Np / 32, CPQ = p.CP + 4, PR = p.CP > 64 ? 16 : 32;
     size_t bmb = 4 * ((QB * (T + 1) + 1) & ~(size_t)1);
     if (bmb < (size_t)4 * QB * NMIN) bmb = (size_t)4 * QB * NMIN;
     size_t usz = sizeof(float) * p.Np + bmb;
-    if (usz < 4 * (size_t)WAVES * 32 * CPQ) usz = 4 * (size_t)WAVES * 32 * CPQ;
-    const size_t lds = ((usz + 15) & ~(size_t)15) + 8 * (size_t)WAVES * PC + sizeof(float) * QB * CPQ + sizeof(float) * QB +
-                       sizeof(int) * QB + sizeof(float) * 24;
+    if (usz < 4 * (size_t)WAVES * PR * CPQ) usz = 4 * (size_t)WAVES * PR * CPQ;
+    const size_t fixed = ((usz + 15) & ~(size_t)15) + sizeof(float) * QB * CPQ + sizeof(float) * QB + sizeof(int) * QB +
+                         sizeof(float) * 24;
+    // candidates a wave refines per batch (8 bytes of LDS each): as many as the 160 KiB allow
+    int PC = 1024;
+    while (PC >= 256 && fixed + 8 * (size_t)WAVES * PC > 160 * 1024) PC /= 2;
+    if (PC < 256) return FSG_ERR_UNSUPPORTED;
+    const size_t lds = fixed + 8 * (size_t)WAVES * PC;
+    if (p.KS == 8 && (flags & 1073741824)) return FSG_ERR_UNSUPPORTED;   // 128 channels: fp16 image only
 #define FSG_KNN_SPLIT(KSV, PK, HF)                                                                                      \
     do {                                                                                                               \
         static bool granted = false;                                                                                   \
@@ -952,7 +963,8 @@ int fsg_knn_split_launch(const float *x, int B, int N, int64_t stride_b, int64_t
     } else {
         if (p.KS == 1) FSG_KNN_SPLIT(1, false, true);
         else if (p.KS == 2) FSG_KNN_SPLIT(2, false, true);
-        else FSG_KNN_SPLIT(4, false, true);
+        else if (p.KS == 4) FSG_KNN_SPLIT(4, false, true);
+        else FSG_KNN_SPLIT(8, false, true);
     }
 #undef FSG_KNN_SPLIT
     FSG_CHECK_LAUNCH("fsg_knn_dense_ws_f32/split");

@@ -102,7 +102,8 @@ def _split_inputs(kind, seed, B, C, Np):
     (1, 3, 1030, 40, None, True, True, "uniform", 4194304), (2, 16, 1024, 20, None, True, False, "outlier", 0),
     (2, 16, 1024, 20, None, True, False, "tiny", 0), (2, 40, 2048, 20, None, True, True, "sorted", 0),
     (2, 64, 2048, 20, None, True, False, "biased", 1073741824), (2, 24, 1500, 20, None, True, True, "lowdim", 1073741824),
-    (1, 64, 1024, 64, None, True, False, "lowdim", 1073741824)])
+    (1, 64, 1024, 64, None, True, False, "lowdim", 1073741824), (2, 128, 2048, 20, None, True, False, "lowdim", 0),
+    (1, 100, 1500, 33, None, True, True, "biased", 0), (1, 128, 1024, 20, None, True, False, "uniform", 4194304)])
 def test_knn_split_kernel_bit_exact_vs_c_oracle(fsg, device, B, C, Np, k, c_knn, fix, drop, kind, flags):
     """fsg_knn_dense_ws_f32's coarse-sweep + exact-refine kernel (csrc/knn_split.hip: fp16 MFMA products on the centred, scaled
     points -- or three bf16 products on the points as they are: flag 1073741824, and always up to 4 channels -- only NOMINATE
@@ -120,7 +121,7 @@ def test_knn_split_kernel_bit_exact_vs_c_oracle(fsg, device, B, C, Np, k, c_knn,
 
 @pytest.mark.parametrize("B,C,Np,k,kind", [(8, 64, 2048, 20, "biased"), (8, 64, 2048, 20, "lowdim"), (4, 64, 8192, 40, "lowdim"),
                                            (4, 3, 8192, 40, "uniform"), (32, 3, 2048, 40, "uniform"), (2, 3, 2048, 20, "far"),
-                                           (3, 48, 5000, 33, "biased")])
+                                           (3, 48, 5000, 33, "biased"), (8, 128, 4096, 20, "lowdim")])
 def test_knn_split_kernel_equals_two_phase_kernel_at_full_size(fsg, device, B, C, Np, k, kind):
     """BASELINE config 2 / 4 / 5 graph sizes: the default entry against the two-phase matrix-core kernel (flag 2097152), which
     reproduces the C oracle's bits on every size the oracle reaches."""

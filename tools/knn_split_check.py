@@ -99,6 +99,9 @@ if __name__ == "__main__":
         ok &= check(2, 3, 8192, 40, "uniform")
         ok &= check(1, 33, 4096, 63, "biased", drop=True)
         ok &= check(2, 3, 1024, 20, "dups")
+        ok &= check(2, 128, 2048, 20, "lowdim", oracle=True)     # 8 k-steps: the PC-AE encoder's last graph
+        ok &= check(2, 100, 4096, 33, "biased", drop=True)
+        ok &= check(1, 128, 1024, 20, "uniform", flags=4194304)
         ok &= check(1, 16, 1024, 8, "const")
         ok &= check(2, 64, 2048, 20, "uniform", flags=4194304)   # everything through the slow path
         ok &= check(2, 16, 1024, 20, "outlier", oracle=True)
@@ -123,7 +126,8 @@ if __name__ == "__main__":
             print(f"   {nm}: {timeit(B, C, N, k, kind, fl):.1f} us", flush=True)
     for (B, C, N, k, kind) in [(8, 64, 2048, 20, "biased"), (8, 64, 2048, 20, "lowdim"), (8, 64, 2048, 20, "uniform"),
                                (8, 3, 2048, 20, "uniform"), (4, 64, 8192, 40, "lowdim"), (4, 3, 8192, 40, "uniform"),
-                               (32, 3, 2048, 40, "uniform"), (8, 3, 4096, 20, "uniform")]:
+                               (32, 3, 2048, 40, "uniform"), (8, 3, 4096, 20, "uniform"), (8, 64, 4096, 20, "lowdim"),
+                               (8, 128, 4096, 20, "lowdim")]:
         tn, tb, to = timeit(B, C, N, k, kind, 0), timeit(B, C, N, k, kind, 1073741824), timeit(B, C, N, k, kind, OLD)
         print(f"time B={B} C={C} N={N} k={k} {kind:8s}: split fp16 {tn:8.1f} us   split 3 x bf16 {tb:8.1f} us   two-phase {to:8.1f} us", flush=True)
     sys.exit(0 if ok else 1)
