@@ -119,6 +119,34 @@ def test_knn_split_kernel_bit_exact_vs_c_oracle(fsg, device, B, C, Np, k, c_knn,
     assert np.array_equal(N(dist).view(np.uint32), rdist.view(np.uint32))  # same bits
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_knn_split_kernel_random_affine_clouds_vs_c_oracle(fsg, device, seed):
+    """The error bound of the coarse sweeps is a claim about ARBITRARY inputs: random per-channel scales over six decades, random
+    offsets up to 30 spreads away from the origin, constant channels, duplicated points, clustered clouds and anisotropic
+    features, random channel counts / k / flags -- indices and distance bits must equal the C oracle's every time."""
+    g = np.random.default_rng(9000 + seed)
+    B, Np = 2, int(g.choice([1024, 1280, 1536]))
+    C = int(g.choice([3, 5, 16, 24, 40, 64, 96]))
+    k = int(g.choice([8, 20, 40]))
+    x = g.standard_normal((B, C, Np))
+    if seed % 3 == 0:      # clusters: most neighbours are much closer than the cloud is wide
+        centres = 5.0 * g.standard_normal((B, C, 8))
+        x = centres[:, :, g.integers(0, 8, Np)] + 0.05 * x
+    scale = 10.0 ** g.uniform(-3, 3, (1, C, 1)) if seed % 2 else 10.0 ** g.uniform(-3, 3)
+    shift = g.uniform(-30, 30, (1, C, 1)) * (seed % 4 != 0)
+    x = (x + shift) * scale
+    if C > 4:
+        x[:, g.integers(0, C)] = 1.5                      # a constant channel
+    dup = g.integers(0, Np, 40)
+    x[:, :, dup[:20]] = x[:, :, dup[20:]]                  # duplicated points: exact ties
+    x = x.astype(np.float32)
+    fix, drop = bool(seed % 2), bool((seed // 2) % 2)
+    idx, dist = fsg.functional.knn_graph(G(x, device), k, fix_diag=fix, drop_first=drop, return_dist=True)
+    ridx, rdist = c_api.knn_dense(x, k, fix_diag=fix, drop_first=drop)
+    assert np.array_equal(N(idx), ridx)
+    assert np.array_equal(N(dist).view(np.uint32), rdist.view(np.uint32))
+
+
 @pytest.mark.parametrize("B,C,Np,k,kind", [(8, 64, 2048, 20, "biased"), (8, 64, 2048, 20, "lowdim"), (4, 64, 8192, 40, "lowdim"),
                                            (4, 3, 8192, 40, "uniform"), (32, 3, 2048, 40, "uniform"), (2, 3, 2048, 20, "far"),
                                            (3, 48, 5000, 33, "biased"), (8, 128, 4096, 20, "lowdim")])
