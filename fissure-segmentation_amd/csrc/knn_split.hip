@@ -293,7 +293,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
     constexpr int OPT = HALF ? KS : (PACK ? 1 : 2 * KS);   // 1-KiB operand blocks per tile
     typedef Ops<NOP, !HALF && !PACK> OpsT;
     constexpr int QW = QB / WAVES;         // queries a wave refines
-    constexpr int PR = CP > 64 ? 16 : 32;  // candidate rows per refine pass (the LDS stage holds PR rows per wave)
+    constexpr int PR = CP > 64 ? 16 : 48;  // candidate rows per refine pass (the LDS stage holds PR rows per wave)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int T = Np / 32;                       // candidate tiles
     const int RSW = T + 1;                       // bitmap row stride in 32-bit words (one word per tile + 1: no bank conflicts)
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
 
         constexpr int LPR = CP / 4;                  // lanes (16-byte pieces) per candidate row
         constexpr int RPI = 64 / LPR;                // rows per load instruction
-        constexpr int NI = RPI >= PR ? 1 : PR / RPI; // load instructions per pass of PR rows
+        constexpr int NI = RPI >= PR ? 1 : (PR + RPI - 1) / RPI; // load instructions per pass of PR rows
         const int lrow = lane / LPR, lpc = lane % LPR;
         int qnext = 0;
         while (qnext < QW) {      // wave-uniform: a batch = as many of the next queries as fit PC candidates
@@ -748,9 +748,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
                 for (int u = 0; u < QW; ++u)
                     if (in[u] && p >= st[u]) { ql = u; s = st[u]; e = en[u]; }
             };
-            // ---- distances: passes of 32 candidates.  Their rows are loaded whole (LPR lanes x 16 bytes per row: every
+            // ---- distances: passes of PR candidates.  Their rows are loaded whole (LPR lanes x 16 bytes per row: every
             // load instruction reads complete rows instead of one 16-byte piece of 64 different rows), staged in LDS, and
-            // lanes 0..31 run the channel-ordered fma chain of one candidate each; the next pass's loads are in flight
+            // lanes 0..PR-1 run the channel-ordered fma chain of one candidate each; the next pass's loads are in flight
             // during the chains.
             f32x4 g[NI];
             int jc = 0, jn = 0;
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
                     const int j = (int)(unsigned)pl[min(p0 + r, P - 1)];
                     g[i] = *reinterpret_cast<const f32x4 *>(xtb + (long)j * CP + 4 * lpc);
                 }
-                jn = (int)(unsigned)pl[min(p0 + (lane & (PR - 1)), P - 1)];
+                jn = (int)(unsigned)pl[min(p0 + min(lane, PR - 1), P - 1)];
                 xn = xxb[jn];
             };
             auto commit = [&]() {
@@ -922,7 +922,7 @@ int fsg_knn_split_launch(const float *x, int B, int N, int64_t stride_b, int64_t
     float *xs = reinterpret_cast<float *>(w + p.off_xs);
     float *cscale = reinterpret_cast<float *>(w + p.off_scale);
     const dim3 pgrid(p.Np / 32, B), grid(p.Np / 64, B);
-    const size_t T = p.Np / 32, CPQ = p.CP + 4, PR = p.CP > 64 ? 16 : 32;
+    const size_t T = p.Np / 32, CPQ = p.CP + 4, PR = p.CP > 64 ? 16 : 48;
     size_t bmb = 4 * ((QB * (T + 1) + 1) & ~(size_t)1);
     if (bmb < (size_t)4 * QB * NMIN) bmb = (size_t)4 * QB * NMIN;
     size_t usz = sizeof(float) * p.Np + bmb;
@@ -930,7 +930,7 @@ int fsg_knn_split_launch(const float *x, int B, int N, int64_t stride_b, int64_t
     const size_t fixed = ((usz + 15) & ~(size_t)15) + sizeof(float) * QB * CPQ + sizeof(float) * QB + sizeof(int) * QB +
                          sizeof(float) * 24;
     // candidates a wave refines per batch (8 bytes of LDS each): as many as the 160 KiB allow
-    int PC = 1024;
+    int PC = 512;
     while (PC >= 256 && fixed + 8 * (size_t)WAVES * PC > 160 * 1024) PC /= 2;
     if (PC < 256) return FSG_ERR_UNSUPPORTED;
     const size_t lds = fixed + 8 * (size_t)WAVES * PC;
