@@ -556,18 +556,24 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
 #pragma unroll
             for (int e = 0; e < 4; ++e) key[4 * e4 + e] = f2o(va[e] + xq);
         }
+        // two key bits per step: the counts for the three thresholds ..01|1s, ..10|1s, ..11|1s travel through the DPP
+        // reduction packed in one register (each <= 64); the number of thresholds still below K is the bit pair
         unsigned prefix = 0u;
 #pragma unroll 2
-        for (int bit = 31; bit >= 12; --bit) {
-            const unsigned t = prefix | ((1u << bit) - 1u);
+        for (int bit = 30; bit >= 12; bit -= 2) {
+            const unsigned low = (1u << bit) - 1u;
+            const unsigned t1 = prefix | low, t2 = prefix | (1u << bit) | low, t3 = prefix | (2u << bit) | low;
             int c = 0;
 #pragma unroll
-            for (int e = 0; e < KPL; ++e) c += key[e] <= t ? 1 : 0;
+            for (int e = 0; e < KPL; ++e)
+                c += (key[e] <= t1 ? 1 : 0) + (key[e] <= t2 ? 256 : 0) + (key[e] <= t3 ? 65536 : 0);
             c += __builtin_amdgcn_update_dpp(0, c, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
             c += __builtin_amdgcn_update_dpp(0, c, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
             c += __builtin_amdgcn_update_dpp(0, c, 0x141, 0xf, 0xf, true);   // row_half_mirror: the other quad of the eight
-            if (c < KK) prefix |= 1u << bit;
+            const unsigned two = ((c & 255) < KK ? 1u : 0u) + (((c >> 8) & 255) < KK ? 1u : 0u) + ((c >> 16) < KK ? 1u : 0u);
+            prefix |= two << bit;
         }
+        stamp(15);
         const unsigned tau = prefix | 0xFFFu;
         float thr;
         if (q0 + q >= N) {

@@ -33,4 +33,5 @@ d = np.diff(t, axis=2)
 print(f"B={B} C={C} N={N} k={k} extra flags {extra}: thousands of shader cycles per phase, mean / max over {nwg} workgroups x 8 waves")
 for i, nm in enumerate(names):
     print(f"  {nm:24s} {d[:, :, i].mean() / 1000:8.2f} k   max {d[:, :, i].max() / 1000:8.2f} k")
+print(f"  {'tau: up to the end of its bisection loop':24s} {(t[:, :, 15] - t[:, :, 4]).mean() / 1000:8.2f} k")
 print(f"  {'whole kernel':24s} {(t[:, :, 14] - t[:, :, 0]).mean() / 1000:8.2f} k")
