@@ -1310,8 +1310,11 @@ class _PTAttn(torch.autograd.Function):
             setattr(gstruct, name, gt.data_ptr())
             grads.append(gt)
             off += sz
-        dqkv = torch.zeros(n, 3 * c, dtype=torch.float32, device=dev)
-        dp = torch.zeros_like(p) if ctx.needs_input_grad[0] else None
+        # dk / dv / dp are accumulated with atomics: ONE zero fill for both buffers (two fill launches per layer and step before)
+        need_dp = ctx.needs_input_grad[0]
+        zbuf = torch.zeros(n * 3 * c + (n * 3 if need_dp else 0), dtype=torch.float32, device=dev)
+        dqkv = zbuf[:n * 3 * c].view(n, 3 * c)
+        dp = zbuf[n * 3 * c:].view(n, 3) if need_dp else None
         ws = torch.empty(_lib.lib.fsg_pt_attn_workspace_bytes(n, ns, c) // 8 + 1, dtype=torch.float64, device=dev)
         g = _f32c(g)
         with torch.cuda.device(dev):

@@ -33,6 +33,25 @@ def test_bad_arguments_are_reported_not_thrown():
         _lib.call("fsg_knn_dense_f32", None, 1, 16, 48, 16, 3, 4, 0, None, None, None, None)
     with pytest.raises(RuntimeError, match="k="):
         _lib.call("fsg_knn_dense_f32", 1, 1, 16, 48, 16, 3, 65, 0, 1, None, None, None)
+    with pytest.raises(RuntimeError, match="NULL pointer"):
+        _lib.call("fsg_knn_dense_ws_f32", None, 1, 2048, 3 * 2048, 2048, 3, 20, 0, None, None, None, 0, None)
+    with pytest.raises(RuntimeError, match="workspace"):   # a workspace smaller than the (B,N) squared norms
+        _lib.call("fsg_knn_dense_ws_f32", 1, 1, 2048, 3 * 2048, 2048, 3, 20, 0, 1, None, 1, 16, None)
+
+
+def test_knn_workspace_query():
+    """fsg_knn_dense_workspace_bytes: never less than the (B,N) fp32 squared norms the two-phase kernel needs; inside the
+    coarse-sweep kernel's envelope also the point-major copy and the operand image (pure host arithmetic: no GPU needed)"""
+    from fissure_segmentation_amd import _lib
+    ws = _lib.lib.fsg_knn_dense_workspace_bytes
+    assert ws(0, 2048, 3) == 0 and ws(8, 0, 3) == 0
+    assert ws(8, 256, 3) == 8 * 256 * 4                     # below the envelope: the norms only
+    assert ws(8, 2048, 200) == 8 * 2048 * 4                 # above 128 channels
+    for B, N, C in ((8, 2048, 3), (8, 2048, 64), (4, 8192, 64), (8, 4096, 128), (2, 1500, 24)):
+        Np = (N + 63) // 64 * 64
+        cp = 4 if C <= 4 else 16 * (1 if C <= 16 else 2 if C <= 32 else 4 if C <= 64 else 8)
+        assert ws(B, N, C) >= B * Np * 4 * (1 + cp), (B, N, C)   # norms + point-major fp32 copy at least
+        assert ws(B, N, C) < 3 * B * Np * 4 * (2 + cp) + 4096, (B, N, C)
 
 
 def test_no_cpu_fallback():
