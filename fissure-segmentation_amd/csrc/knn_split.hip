@@ -1,7 +1,8 @@
 // Dense kNN graph build, "coarse sweep + exact refine" kernel behind fsg_knn_dense_ws_f32
-// (1024 <= N <= 8192, c_knn <= 128 (above 64 channels up to N = 4096), k + drop <= 64).  Replaces utils/general_utils.py:43-53,315-327 like the two-phase
-// kernel of knn_rows_mfma.hip and returns the SAME bits (indices and distances of oracle/fsg_oracle.c): the matrix
-// cores only nominate candidates, every distance that is ranked or returned is the oracle's fp32 fma chain.
+// (1024 <= N <= 8192, c_knn <= 128 -- above 64 channels N <= 4096 --, k + drop <= 64).  Replaces
+// utils/general_utils.py:43-53,315-327 like the two-phase kernel of knn_rows_mfma.hip and returns the SAME bits (indices and
+// distances of oracle/fsg_oracle.c): the matrix cores only NOMINATE candidates, every distance that is ranked or returned is
+// the oracle's fp32 fma chain.
 //
 //   prep    one pass over the cloud: squared norms (the oracle's chain), a point-major fp32 copy (rows for the refine) and
 //           the coarse image of the points in the REGISTER LAYOUT of a 32x32x16 MFMA operand (one 1-KiB block per 32 points
@@ -14,24 +15,31 @@
 //           A query operand is the same image times -2 (one exponent step, done in the main kernel).
 //   sweep 1 a workgroup owns 64 queries (two 32-column blocks, resident as B operands); its 8 waves take the candidate
 //           tiles (32 rows, A operand) round-robin.  s~(i,j) = |x_j|^2 - 2 x_i.x_j in coarse arithmetic comes out of one fp16
-//           (three bf16) MFMAs per k-step with the squared norm as the accumulator's initial value.  Lane (n, h) holds 16 candidates of
-//           ONE query per tile, so the running minimum of a tile group is a per-lane register: 128 group minima per query.
-//   tau     K-th smallest of the 128 group minima (distinct candidates, so at least K candidates have s~ <= tau);
-//           with |s~ - F| <= eps_i for every candidate (F = the oracle's distance minus the query's own squared norm, see
-//           the bound below) the K-th smallest oracle distance is <= tau + eps_i and every true neighbour has
-//           s~ <= tau + 2 eps_i.
-//   sweep 2 the same MFMAs again (bit-identical values); a lane appends the candidates with s~ <= tau + 2 eps to its
-//           OWN list in LDS (no atomics: one list per query, wave and lane half), ~1.2 K per query in total.
-//   refine  one wave per query: the oracle's distance d = (xx_i - 2 dot) + xx_j, dot = channel-ordered fmaf chain from +0,
-//           for every listed candidate (rows from the point-major copy), (d, j) keys ranked by counting, ranks < K written.
-//   slow    a query whose lists overflow (massive ties, fewer than K finite candidates) is redone by the whole workgroup
-//           from the oracle's distances of ALL candidates: exact, slow, rare.
+//           (three bf16) MFMAs per k-step with the squared norm as the accumulator's initial value.  Lane (n, h) holds 16
+//           candidates of ONE query per tile, so the running minimum of a tile group is a per-lane register: NMIN = 64 group
+//           minima per query.
+//   tau     K-th smallest of the group minima (disjoint candidate groups, so at least K candidates have s~ <= tau); with
+//           |s~ - F| <= eps_i for every candidate (F = the oracle's distance, in the image's units, minus a per-query
+//           constant) the K-th smallest oracle distance is <= tau + eps_i and every true neighbour has s~ <= tau + 2 eps_i.
+//   sweep 2 the same MFMAs again (bit-identical values); s~ <= tau + 2 eps becomes one bit per candidate in a per-query
+//           bitmap in LDS -- branch-free; ~1.2 K bits set per query.
+//   refine  a wave owns 8 queries: bitmap rows -> registers, counts (popcount + DPP scan), decode into one candidate list;
+//           candidate rows are loaded WHOLE from the point-major copy into an LDS stage (48 rows per pass), one lane per
+//           candidate runs the oracle's distance d = (xx_i - 2 dot) + xx_j, dot = channel-ordered fmaf chain from +0; the
+//           (d, j) keys are ranked by counting inside the query's segment and ranks < K are written.
+//   slow    a query whose candidate list overflows (massive ties) -- and every query of a cloud with a marked outlier -- is
+//           redone by the whole workgroup from the oracle's distances of ALL candidates: exact, slow, rare.
 //
 // Error bound of the bf16 form (n_i = |x_i|, R = max_j |x_j|, both rounded up; the fp16 form's terms are listed where eps is
 // computed, in the centred and scaled units):
 //   dropped product terms lo.lo + r.(..)   <= 3.1 * 2^-16 n_i R, times the factor 2          -> 1.0e-4 n_i R
 //   fp32 accumulation of 193 terms in the matrix core, any order, truncation allowed          -> 2.6e-5 (R^2 + 2.1 n_i R)
-//   the oracle's own fp32 chains against real arithmetic (dot, both norms, two roundings)     -> 9.0e-6 (n_i + R)^2
+//   the oracle's own fp32 chains against real arithmetic (dot, both norms, two roundings)     -> 9.2e-6 (n_i + R)^2
+//
+// Debug / measurement flags (bits of `flags`; tools/knn_split_check.py, tools/knn_split_stamps.py): 65536 plain workgroup
+// placement; 4194304 every query through the slow path; 1073741824 the bf16 form above 4 channels; 33554432 statistics
+// (fsg_debug_knn_split_stats); 268435456 cycle stamps (fsg_debug_knn_split_stamps); 67108864 / 8388608 / 16777216 return
+// after the setup / sweep 1 / sweep 2 (timing ablations: the outputs are NOT written).
 #include "fsg_common.h"
 
 // debug statistics (flag 33554432): [0] queries refined, [1] their listed candidates, [2] queries on the slow path,
@@ -64,7 +72,7 @@ typedef unsigned long long u64;
 constexpr int QB = 64;        // queries per workgroup
 constexpr int WAVES = 8;
 constexpr int MSL = 4;         // group-minimum slots per lane and query block in sweep 1
-constexpr int NMIN = 2 * WAVES * MSL;   // group minima per query (128): tau = the K-th smallest of them
+constexpr int NMIN = 2 * WAVES * MSL;   // group minima per query (64): tau = the K-th smallest of them
 
 __device__ __forceinline__ unsigned f2o(float d) {
     const unsigned u = __float_as_uint(d);
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
     // U region: the squared norms and the bitmaps during the sweeps, the row stage of the refine afterwards
     float *xs = reinterpret_cast<float *>(smem);                              // [Np] squared norms (sweeps only)
     unsigned *bm = reinterpret_cast<unsigned *>(xs + Np);                     // [QB][RSW] survivor bitmaps (sweep 2)
-    float *mins = reinterpret_cast<float *>(bm);                              // [QB][64] group minima (sweep 1), same storage
+    float *mins = reinterpret_cast<float *>(bm);                              // [QB][NMIN] group minima (sweep 1), same storage
     float *stage = reinterpret_cast<float *>(smem);                           // [WAVES][PR][CPQ] candidate rows (refine)
     float *dl = reinterpret_cast<float *>(smem);                              // slow path: [N] distances
     const size_t usz = max((size_t)4 * Np + max((size_t)4 * (((size_t)QB * RSW + 1) & ~(size_t)1), (size_t)4 * QB * NMIN),
@@ -541,7 +549,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
         const bool any_outlier = ao != 0.f;
         const float R = sqrtf(R2) * 1.0001f, Ro = sqrtf(Ro2) * 1.0001f;
         const float sg = HALF ? cscale[b] : 1.f;
-        // eight lanes per query, sixteen group minima per lane: the K-th smallest of the 128 by bisection on the key bits with
+        // eight lanes per query, eight group minima per lane: the K-th smallest of the 64 by bisection on the key bits with
         // the counts summed over the eight lanes on the DPP network (no scalar round trips: the ballot version of this
         // search spent 2000 cycles per query on VALU -> SALU dependencies)
         const int q = wave * QW + (lane >> 3);
