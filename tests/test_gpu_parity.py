@@ -84,6 +84,10 @@ def _split_inputs(kind, seed, B, C, Np):
         x = g.uniform(-1, 1, (B, C, Np)).astype(np.float32)
         x[0, :, Np // 3] = 3.0e5
         return x
+    if kind == "outlier0":     # the outlier sits INSIDE the centre / scale sample: everything else collapses below fp16's range
+        x = g.uniform(-1, 1, (B, C, Np)).astype(np.float32)
+        x[:, :, 3] = -7.0e6
+        return x
     if kind == "tiny":         # coordinates far below fp16's range before the power-of-two scaling
         return (1e-9 * g.uniform(-1, 1, (B, C, Np))).astype(np.float32)
     if kind == "sorted":       # spatially sorted cloud: the sampled centre sits in one corner
@@ -100,7 +104,7 @@ def _split_inputs(kind, seed, B, C, Np):
     (1, 64, 1024, 64, None, True, False, "lowdim", 0), (2, 3, 1024, 20, None, True, False, "lattice", 0),
     (1, 16, 1100, 8, None, True, False, "far", 0), (1, 64, 2048, 20, None, True, False, "uniform", 4194304),
     (1, 3, 1030, 40, None, True, True, "uniform", 4194304), (2, 16, 1024, 20, None, True, False, "outlier", 0),
-    (2, 16, 1024, 20, None, True, False, "tiny", 0), (2, 40, 2048, 20, None, True, True, "sorted", 0),
+    (2, 16, 1024, 20, None, True, False, "tiny", 0), (1, 24, 1024, 20, None, True, False, "outlier0", 0), (2, 40, 2048, 20, None, True, True, "sorted", 0),
     (2, 64, 2048, 20, None, True, False, "biased", 1073741824), (2, 24, 1500, 20, None, True, True, "lowdim", 1073741824),
     (1, 64, 1024, 64, None, True, False, "lowdim", 1073741824), (2, 128, 2048, 20, None, True, False, "lowdim", 0),
     (1, 100, 1500, 33, None, True, True, "biased", 0), (1, 128, 1024, 20, None, True, False, "uniform", 4194304)])
