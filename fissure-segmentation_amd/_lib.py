@@ -25,6 +25,7 @@ SIGNATURES = {
     "fsg_edge_gather_fwd_f32": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
     "fsg_edge_gather_bwd_f32": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
     "fsg_knn_gather_fused_f32": ([_P, _I, _I, _I, _I, _I, _P, _P, _P, _P], _I),
+    "fsg_knn_gather_fused_ws_f32": ([_P, _I, _I, _I, _I, _I, _P, _P, _P, ctypes.c_size_t, _P], _I),
     "fsg_edge_gather_fwd_bf16": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
     "fsg_edge_gather_bwd_bf16": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
     "fsg_graph_reverse_csr_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),

@@ -133,3 +133,15 @@ extern "C" int fsg_knn_gather_fused_f32(const float *x, int B, int C, int N, int
     if (rc != FSG_OK) return rc;
     return fsg_edge_gather_fwd_f32(x, idx_out, edge, B, C, N, k, stream);
 }
+
+// The same call with the workspace of fsg_knn_dense_workspace_bytes(B, N, c_knn): the graph comes from fsg_knn_dense_ws_f32
+// (coarse-sweep + exact-refine kernel inside its envelope: same indices).
+extern "C" int fsg_knn_gather_fused_ws_f32(const float *x, int B, int C, int N, int k, int c_knn, int32_t *idx_out,
+                                           float *edge, void *workspace, size_t workspace_bytes, fsg_stream_t stream) {
+    FSG_REQUIRE(x && idx_out && edge && workspace, "fsg_knn_gather_fused_ws_f32: NULL pointer");
+    FSG_REQUIRE(c_knn > 0 && c_knn <= C, "fsg_knn_gather_fused_ws_f32: c_knn=%d outside 1..C=%d", c_knn, C);
+    int rc = fsg_knn_dense_ws_f32(x, B, N, (int64_t)C * N, (int64_t)N, c_knn, k, FSG_KNN_FIX_DIAG, idx_out, nullptr, workspace,
+                                  workspace_bytes, stream);
+    if (rc != FSG_OK) return rc;
+    return fsg_edge_gather_fwd_f32(x, idx_out, edge, B, C, N, k, stream);
+}

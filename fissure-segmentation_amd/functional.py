@@ -209,10 +209,11 @@ def knn_edge_features(x, k, knn_only_over_coords=False):
     B, C, N = xc.shape
     idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
     edge = torch.empty(B, 2 * C, N, k, dtype=torch.float32, device=x.device)
-    xx = torch.empty(B, N, dtype=torch.float32, device=x.device)
+    c_knn = 3 if knn_only_over_coords else C
+    ws_bytes = _lib.lib.fsg_knn_dense_workspace_bytes(B, N, c_knn)
+    ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.call("fsg_knn_gather_fused_f32", _p(xc), B, C, N, k, 3 if knn_only_over_coords else C, _p(idx), _p(edge), _p(xx),
-                  _stream())
+        _lib.call("fsg_knn_gather_fused_ws_f32", _p(xc), B, C, N, k, c_knn, _p(idx), _p(edge), _p(ws), ws_bytes, _stream())
     return edge, idx
 
 

@@ -83,6 +83,9 @@ int fsg_edge_gather_bwd_f32(const float *grad_edge, const int32_t *idx, float *g
  * xx_scratch (B,N) fp32.  (Reference-semantic op: the training path uses the fused fsg_edgeconv* entries instead.) */
 int fsg_knn_gather_fused_f32(const float *x, int B, int C, int N, int k, int c_knn, int32_t *idx_out, float *edge,
                              float *xx_scratch, fsg_stream_t stream);
+/* ... with the workspace of fsg_knn_dense_workspace_bytes(B, N, c_knn): the graph then comes from fsg_knn_dense_ws_f32 */
+int fsg_knn_gather_fused_ws_f32(const float *x, int B, int C, int N, int k, int c_knn, int32_t *idx_out, float *edge,
+                                void *workspace, size_t workspace_bytes, fsg_stream_t stream);
 /* bf16 storage of the same op (BASELINE configs 3-5; SURVEY 8d counts the edge tensor at 2 bytes per element):
  * x, edge and grad_edge are bf16 (raw 16-bit patterns), the difference is formed in fp32 and rounded once;
  * grad_x is accumulated and returned in FP32 (B,C,N). */

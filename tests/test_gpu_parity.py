@@ -2162,13 +2162,22 @@ def test_dgcnnseg_bf16_mode_vs_fp32_oracle(fsg, device, monkeypatch, how):
 
 @pytest.mark.parametrize("B,C,Np,k,coords", [(2, 5, 300, 12, False), (1, 64, 1024, 20, False), (2, 15, 257, 8, True)])
 def test_knn_gather_fused_entry_point(fsg, device, B, C, Np, k, coords):
-    """fsg_knn_gather_fused_f32 = the reference's create_neighbor_features with a dynamic graph (models/dgcnn.py:15-36):
+    """fsg_knn_gather_fused_ws_f32 = the reference's create_neighbor_features with a dynamic graph (models/dgcnn.py:15-36):
     graph bit-exact vs the C oracle, edge tensor exact vs the oracle's edge features on that graph"""
     x = cloud(3000 + C, B, C, Np)
     edge, idx = fsg.functional.knn_edge_features(G(x, device), k, knn_only_over_coords=coords)
     idx_o, _ = c_api.knn_dense(x, k, c_knn=3 if coords else None, fix_diag=True)
     assert np.array_equal(N(idx), idx_o)
     assert np.array_equal(N(edge), c_api.edge_features(x, idx_o))
+    # the entry point with the (B,N) scratch (two-phase kernel for every shape): same graph, same edge tensor
+    from fissure_segmentation_amd import _lib
+    xg = G(x, device)
+    idx2 = torch.empty(B, Np, k, dtype=torch.int32, device=device)
+    edge2 = torch.empty(B, 2 * C, Np, k, dtype=torch.float32, device=device)
+    xx = torch.empty(B, Np, dtype=torch.float32, device=device)
+    _lib.call("fsg_knn_gather_fused_f32", xg.data_ptr(), B, C, Np, k, 3 if coords else C, idx2.data_ptr(), edge2.data_ptr(),
+              xx.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(idx2, idx) and torch.equal(edge2, edge)
 
 
 def test_dgcnnreg_vs_reference_golden(fsg, device):
