@@ -271,10 +271,21 @@ struct Ops {
     u32x4 hi[NOPS], lo[TWO ? NOPS : 1];
 };
 
-// m = 2 m + (a <= thr): sixteen of these leave bit e = (a[e] <= thr) when fed e = 15 .. 0.  Plain C on purpose: an inline-asm
-// consumer of MFMA results is invisible to the compiler's hazard recognizer (no wait states between the matrix
-// instruction and the read: stale accumulators, measured as lost neighbours).
-__device__ __forceinline__ unsigned push_le(unsigned m, float a, float thr) { return m + m + (a <= thr ? 1u : 0u); }
+// m = 2 m + (a < thr): sixteen of these leave bit e = (a[e] < thr) when fed e = 15 .. 0.  Two instructions and no scalar
+// register in between: the SIGN of a - thr (exact for finite a != thr, +0 for a == thr, NaN with a clear sign bit for inf - inf)
+// is shifted in with v_alignbit.  (A compare writes a scalar mask; the select that follows costs a wait state and the
+// compiler's shift / or glue: 3.5 instructions per score.  An inline-asm version of that form also LOST neighbours: an asm
+// consumer of MFMA results is invisible to the hazard recognizer -- no wait states after the matrix instruction.)
+__device__ __forceinline__ unsigned push_lt(unsigned m, float a, float thr) {
+    return __builtin_amdgcn_alignbit(m, __float_as_uint(a - thr), 31);
+}
+// the smallest float above thr: a <= thr  <=>  a < above(thr) for every finite thr (FLT_MAX -> +inf; -inf stays)
+__device__ __forceinline__ float above(float thr) {
+    const unsigned u = __float_as_uint(thr);
+    if (thr == -INFINITY || thr != thr) return thr;
+    if (thr == 0.f) return __uint_as_float(1u);
+    return __uint_as_float(thr > 0.f ? u + 1u : u - 1u);
+}
 
 // inclusive prefix sum over the 64 lanes on the DPP network (as knn_rows_mfma.hip)
 __device__ __forceinline__ int wave_incl_scan(int v) {
@@ -555,32 +566,32 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
         const int q = wave * QW + (lane >> 3);
         const float xq = (q0 + q < N) ? xs[q0 + q] : 0.f;
         constexpr int KPL = NMIN / 8;    // minima per lane of the eight that share a query
+        // The search runs on distances (minimum + the query's norm): rounding tau up by 2^-11 of a DISTANCE is harmless, 2^-11
+        // of s~ = d - |x_i|^2 would not be for clouds far from the origin.  Keys = order-preserving integer images of the
+        // floats, HALVED so that the difference of two keys fits 32 bits with its sign: (key <= t) is then the sign bit of
+        // key - (t + 1), shifted into a mask with v_alignbit -- two instructions per key and step and no scalar register in
+        // between (compare + select + glue: 3.5 and a wait state; the search is VALU-issue-bound).
         unsigned key[KPL];
-        // the search runs on distances (minimum + the query's norm): rounding tau up by 2^-11 of a DISTANCE is harmless,
-        // 2^-11 of s~ = d - |x_i|^2 would not be for clouds far from the origin
 #pragma unroll
         for (int e4 = 0; e4 < KPL / 4; ++e4) {
             const f32x4 va = *reinterpret_cast<const f32x4 *>(mins + q * NMIN + KPL * (lane & 7) + 4 * e4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) key[4 * e4 + e] = f2o(va[e] + xq);
+            for (int e = 0; e < 4; ++e) key[4 * e4 + e] = f2o(va[e] + xq) >> 1;
         }
-        // two key bits per step: the counts for the three thresholds ..01|1s, ..10|1s, ..11|1s travel through the DPP
-        // reduction packed in one register (each <= 64); the number of thresholds still below K is the bit pair
         unsigned prefix = 0u;
-#pragma unroll 2
-        for (int bit = 30; bit >= 12; bit -= 2) {
-            const unsigned low = (1u << bit) - 1u;
-            const unsigned t1 = prefix | low, t2 = prefix | (1u << bit) | low, t3 = prefix | (2u << bit) | low;
-            int c = 0;
+#pragma unroll 4
+        for (int bit = 30; bit >= 11; --bit) {
+            const unsigned t1 = (prefix | ((1u << bit) - 1u)) + 1u;
+            unsigned m = 0u;
 #pragma unroll
-            for (int e = 0; e < KPL; ++e)
-                c += (key[e] <= t1 ? 1 : 0) + (key[e] <= t2 ? 256 : 0) + (key[e] <= t3 ? 65536 : 0);
+            for (int e = 0; e < KPL; ++e) m = __builtin_amdgcn_alignbit(m, key[e] - t1, 31);
+            int c = __popc(m);
             c += __builtin_amdgcn_update_dpp(0, c, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
             c += __builtin_amdgcn_update_dpp(0, c, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
             c += __builtin_amdgcn_update_dpp(0, c, 0x141, 0xf, 0xf, true);   // row_half_mirror: the other quad of the eight
-            const unsigned two = ((c & 255) < KK ? 1u : 0u) + (((c >> 8) & 255) < KK ? 1u : 0u) + ((c >> 16) < KK ? 1u : 0u);
-            prefix |= two << bit;
+            if (c < KK) prefix |= 1u << bit;
         }
+        prefix = (prefix << 1) | 1u;     // back to 32-bit keys, rounded up
         stamp(15);
         const unsigned tau = prefix | 0xFFFu;
         float thr;
@@ -621,7 +632,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
     // ---------------------------------------------------------------- sweep 2: survivor bitmaps, branch-free
     // bit 16 h + e of word t of row q <-> candidate 32 t + 8 (e / 4) + 4 h + e % 4
     {
-        const float thr[2] = {thrL[n], thrL[32 + n]};
+        const float thr[2] = {above(thrL[n]), above(thrL[32 + n])};   // a <= thr as a strict comparison
         unsigned short *bp[2] = {reinterpret_cast<unsigned short *>(bm + n * RSW) + h,
                                  reinterpret_cast<unsigned short *>(bm + (32 + n) * RSW) + h};
         sweep([&](const f32x16 &a, int bk, int t, int g, bool gend) {
@@ -629,7 +640,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
             (void)gend;
             unsigned m = 0;
 #pragma unroll
-            for (int e = 15; e >= 0; --e) m = push_le(m, a[e], thr[bk]);
+            for (int e = 15; e >= 0; --e) m = push_lt(m, a[e], thr[bk]);
             bp[bk][2 * t] = (unsigned short)m;
         });
     }
