@@ -329,6 +329,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
     float *thrL = qrow + QB * CPQ;                                            // [QB]
     int *slowq = reinterpret_cast<int *>(thrL + QB);                          // [QB]
     float *red = reinterpret_cast<float *>(slowq + QB);                       // [24]
+    int *segL = reinterpret_cast<int *>(red + 24);                            // [WAVES][QW][2] segment bounds of a batch
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
@@ -747,7 +748,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
             }
             const int P = base;
             qnext = qend;
-            // ---- decode: bit 16 h + e of word t <-> candidate 32 t + 8 (e / 4) + 4 h + e % 4
+            // ---- decode: bit 16 h + e of word t <-> candidate 32 t + 8 (e / 4) + 4 h + e % 4.  An entry's low word is
+            // (query's index in the wave << 16) | candidate: inside a query's segment the tag is constant, so it does not
+            // change the order of the keys (distance bits << 32 | low word) and spares the search for the segment of an entry
 #pragma unroll
             for (int u = 0; u < QW; ++u) {
                 if (in[u] && tot[u] > 0) {
@@ -760,19 +763,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
                             const int bb = __builtin_ctz(w);
                             w &= w - 1;
                             const int e = bb & 15;
-                            pl[pos++] = (u64)(unsigned)(32 * (lane + 64 * v) + 8 * (e >> 2) + 4 * (bb >> 4) + (e & 3));
+                            pl[pos++] = (u64)((unsigned)(u << 16) | (unsigned)(32 * (lane + 64 * v) + 8 * (e >> 2) + 4 * (bb >> 4) + (e & 3)));
                         }
                     }
                 }
             }
             __builtin_amdgcn_wave_barrier();
             if (qend == QW) stamp(11);
-            auto which = [&](int p, int &ql, int &s, int &e) {   // segment of entry p
-                ql = 0; s = 0; e = 0;
 #pragma unroll
-                for (int u = 0; u < QW; ++u)
-                    if (in[u] && p >= st[u]) { ql = u; s = st[u]; e = en[u]; }
-            };
+            for (int u = 0; u < QW; ++u)
+                if (lane == u) { segL[(wave * QW + u) * 2] = st[u]; segL[(wave * QW + u) * 2 + 1] = en[u]; }
             // ---- distances: passes of PR candidates.  Their rows are loaded whole (LPR lanes x 16 bytes per row: every
             // load instruction reads complete rows instead of one 16-byte piece of 64 different rows), staged in LDS, and
             // lanes 0..PR-1 run the channel-ordered fma chain of one candidate each; the next pass's loads are in flight
@@ -784,11 +784,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     const int r = min(i * RPI + lrow, PR - 1);
-                    const int j = (int)(unsigned)pl[min(p0 + r, P - 1)];
+                    const int j = (int)((unsigned)pl[min(p0 + r, P - 1)] & 0xFFFFu);
                     g[i] = *reinterpret_cast<const f32x4 *>(xtb + (long)j * CP + 4 * lpc);
                 }
-                jn = (int)(unsigned)pl[min(p0 + min(lane, PR - 1), P - 1)];
-                xn = xxb[jn];
+                jn = (int)(unsigned)pl[min(p0 + min(lane, PR - 1), P - 1)];   // tagged entry
+                xn = xxb[jn & 0xFFFF];
             };
             auto commit = [&]() {
 #pragma unroll
@@ -809,8 +809,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
                 if (p0 + PR < P) issue(p0 + PR);
                 const int p = p0 + lane;
                 if (lane < PR && p < P) {
-                    int ql, s, e;
-                    which(p, ql, s, e);
+                    const int ql = (jc >> 16) & (QW - 1);
                     const float *qr = qrow + (qbase + ql) * CPQ;
                     const float *row = stg + lane * CPQ;
                     float dot = 0.f;
@@ -831,7 +830,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
                     }
                     const float tt = qr[CP] - 2.0f * dot;
                     float d = tt + xc;
-                    if (fix_diag && jc == q0 + qbase + ql) d = 0.f;
+                    if (fix_diag && (jc & 0xFFFF) == q0 + qbase + ql) d = 0.f;
                     pl[p] = ((u64)f2o(d) << 32) | (unsigned)jc;
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -843,9 +842,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
             for (int p0 = 0; p0 < P; p0 += 64) {
                 const int p = p0 + lane;
                 if (p < P) {
-                    int ql, s, e;
-                    which(p, ql, s, e);
                     const u64 key = pl[p];
+                    const int ql = (int)((unsigned)key >> 16) & (QW - 1);
+                    const int s = segL[(wave * QW + ql) * 2], e = segL[(wave * QW + ql) * 2 + 1];
                     int r = 0;
                     int t = s;
                     if ((t & 1) && t < e) { r += pl[t] < key ? 1 : 0; ++t; }   // 16-byte reads from an even entry on
@@ -858,7 +857,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
                     if (t < e) r += pl[t] < key ? 1 : 0;
                     if (r >= drop && r < KK) {
                         const long o = ((long)b * N + q0 + qbase + ql) * k - drop + r;
-                        idx_out[o] = (int)(unsigned)(key & 0xFFFFFFFFull);
+                        idx_out[o] = (int)((unsigned)key & 0xFFFFu);
                         if (dist_out) dist_out[o] = o2f((unsigned)(key >> 32));
                     }
                 }
@@ -953,7 +952,7 @@ int fsg_knn_split_launch(const float *x, int B, int N, int64_t stride_b, int64_t
     size_t usz = sizeof(float) * p.Np + bmb;
     if (usz < 4 * (size_t)WAVES * PR * CPQ) usz = 4 * (size_t)WAVES * PR * CPQ;
     const size_t fixed = ((usz + 15) & ~(size_t)15) + sizeof(float) * QB * CPQ + sizeof(float) * QB + sizeof(int) * QB +
-                         sizeof(float) * 24;
+                         sizeof(float) * 24 + sizeof(int) * WAVES * (QB / WAVES) * 2;
     // candidates a wave refines per batch (8 bytes of LDS each): as many as the 160 KiB allow
     int PC = 512;
     while (PC >= 256 && fixed + 8 * (size_t)WAVES * PC > 160 * 1024) PC /= 2;
