@@ -421,8 +421,8 @@ def main():
             # selection ("VALU/LDS-bound, not HBM-bound") -> roofline.bound = "mfma".  The result is the exact
             # fp32 graph (indices and distance bits of the fp32 oracle), so `achieved` prices the algorithmic 2 B N^2 C flop
             # against the fp32 matrix peak -- the rate an exact-fp32 distance block is bounded by.  Since round 2 the kernel
-            # (csrc/knn_split.hip) evaluates the block three times cheaper-than-fp32 (split-bf16 products on
-            # v_mfma_f32_32x32x16_bf16, two sweeps) and the fp32 chain only for the ~1.2 k nominated candidates per point;
+            # (csrc/knn_split.hip) evaluates the block twice in coarse arithmetic (fp16 products on
+            # v_mfma_f32_32x32x16_f16, two sweeps) and the fp32 chain only for the ~1.3 k nominated candidates per point;
             # `mfma_issued` states what it really issues.
             per_step = len(knn_calls) // n_timed                 # graph builds per step (3 for DGCNN-seg, 4 for the PC-AE)
             chans = {"c5": (3, 64, 64, 128)}.get(args.workload, EDGE_LAYERS_C)
@@ -447,12 +447,13 @@ def main():
                         "frac": round(tf / MFMA_FP32_PEAK_TFLOPS, 4),
                         "traffic": knn_traffic,
                         "kernel": f"fsg_knn_dense_ws_f32 on {chans[li]} channels (knn_split_prep_kernel + knn_split_kernel): two "
-                                  "coarse sweeps on v_mfma_f32_32x32x16_bf16 (x = hi + lo bf16 pieces, 3 products) nominate "
-                                  "~1.2 k candidates per point under a rigorous error bound; exact fp32 fma chains + ranking "
-                                  "for the nominees (bit-identical to the fp32 oracle)",
-                        "mfma_issued": {"instruction": "v_mfma_f32_32x32x16_bf16", "flops_per_launch": 2 * 3 * flops,
-                                        "bf16_dense_peak_tflops": 2500.0,
-                                        "frac_of_bf16_peak": round(2 * 3 * flops / (avg_ms * 1e-3) / 1e12 / 2500.0, 4)},
+                                  "coarse sweeps on v_mfma_f32_32x32x16_f16 (ONE product on the points centred on a sampled "
+                                  "mean and scaled by a power of two) nominate ~1.3 k candidates per point under a rigorous "
+                                  "error bound; exact fp32 fma chains + ranking for the nominees (bit-identical to the fp32 "
+                                  "oracle)",
+                        "mfma_issued": {"instruction": "v_mfma_f32_32x32x16_f16", "flops_per_launch": 2 * flops,
+                                        "f16_dense_peak_tflops": 2500.0,
+                                        "frac_of_f16_peak": round(2 * flops / (avg_ms * 1e-3) / 1e12 / 2500.0, 4)},
                         "flops_per_launch": flops, "avg_us": round(1e3 * avg_ms, 1), "launches_per_step": per_step,
                         "candidates_per_s": round(B * N * N / (avg_ms * 1e-3), 1),
                         "timed_as": timed_as}
