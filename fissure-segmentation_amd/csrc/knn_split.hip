@@ -355,7 +355,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
     const int KK = k + drop;
     const bool fix_diag = (flags & FSG_KNN_FIX_DIAG) != 0;
     const int TW = (T - wave + WAVES - 1) / WAVES;   // tiles of this wave (round-robin: tile = wave + 8 i)
-    const int G = ((T + WAVES - 1) / WAVES + MSL - 1) / MSL;   // tiles per minimum group (the same for every wave)
     const float *xxb = xx + (long)b * Np;
     const float *xtb = xt + (long)b * Np * CP;
     const u32x4 *candb = cand + (long)b * T * OPT * 64 + lane;
@@ -493,7 +492,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
         OpsT ring[3];
         if (TW > 0) load_tile(ring[0], tile_of(0));
         if (TW > 1) load_tile(ring[1], tile_of(1));
-        int gi = 0, g = 0;          // tiles in the open minimum group, its index
+        // the wave's TW tiles are spread over its MSL minimum groups as evenly as possible (a group ends whenever the running
+        // sum of MSL per tile passes TW): every slot is used from TW = MSL on, so every query has its NMIN finite minima even
+        // when the tile count is not a multiple of the waves
+        int gacc = 0, g = 0;
         f32x16 prev;                // scores of the previous chain (block 1 of the previous tile), not yet consumed
 #pragma unroll
         for (int e = 0; e < 16; ++e) prev[e] = INFINITY;
@@ -506,8 +508,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
                 if (i < TW) {
                     const int t = tile_of(i);
                     if (i + 2 < TW) load_tile(ring[(u + 2) % 3], tile_of(i + 2));
-                    ++gi;
-                    const bool gend = gi == G || i + 1 == TW;   // wave-uniform: the minimum group is complete
+                    gacc += MSL;
+                    const bool gend = gacc >= TW;               // wave-uniform: the minimum group is complete
                     const f32x16 init = load_init(t);
                     const f32x16 a0 = scores(ring[u], init, 0);
                     f(prev, 1, pt, pg, pgend);                  // block 1 of the previous tile (first tile: +inf scores)
@@ -517,7 +519,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
                     pt = t;
                     pg = g;
                     pgend = gend;
-                    if (gend) { ++g; gi = 0; }
+                    if (gend) { ++g; gacc -= TW; }
                 }
             }
         }

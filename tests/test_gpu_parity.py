@@ -103,7 +103,7 @@ def _split_inputs(kind, seed, B, C, Np):
     (2, 24, 1500, 20, None, True, True, "lowdim", 0), (1, 33, 4096, 63, None, True, True, "biased", 0),
     (1, 64, 1024, 64, None, True, False, "lowdim", 0), (2, 3, 1024, 20, None, True, False, "lattice", 0),
     (1, 16, 1100, 8, None, True, False, "far", 0), (1, 64, 2048, 20, None, True, False, "uniform", 4194304),
-    (1, 3, 1030, 40, None, True, True, "uniform", 4194304), (2, 16, 1024, 20, None, True, False, "outlier", 0),
+    (1, 3, 1030, 40, None, True, True, "uniform", 4194304), (2, 8, 1100, 60, None, True, True, "uniform", 0), (2, 16, 1024, 20, None, True, False, "outlier", 0),
     (2, 16, 1024, 20, None, True, False, "tiny", 0), (1, 24, 1024, 20, None, True, False, "outlier0", 0), (2, 40, 2048, 20, None, True, True, "sorted", 0),
     (2, 64, 2048, 20, None, True, False, "biased", 1073741824), (2, 24, 1500, 20, None, True, True, "lowdim", 1073741824),
     (1, 64, 1024, 64, None, True, False, "lowdim", 1073741824), (2, 128, 2048, 20, None, True, False, "lowdim", 0),

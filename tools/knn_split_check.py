@@ -115,7 +115,8 @@ if __name__ == "__main__":
     lib = fsg._lib.lib
     lib.fsg_debug_knn_split_stats.argtypes = [ctypes.c_void_p, ctypes.c_int]
     st = (ctypes.c_ulonglong * 4)()
-    for (B, C, N, k, kind) in [(8, 64, 2048, 20, "lowdim"), (8, 3, 2048, 20, "uniform"), (4, 64, 8192, 40, "lowdim")]:
+    for (B, C, N, k, kind) in [(8, 64, 2048, 20, "lowdim"), (8, 3, 2048, 20, "uniform"), (4, 64, 8192, 40, "lowdim"),
+                               (4, 8, 1100, 60, "uniform")]:
         x = feats(7, B, C, N, kind).to(dev)
         lib.fsg_debug_knn_split_stats(st, 1)
         F.knn_graph(x, k, _debug_flags=33554432)
