@@ -176,6 +176,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if device.type != "cuda":
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    ranks_seen = 1
+    if world > 1:
+        # the process group the gradients will cross: RCCL (torch's "nccl" backend on ROCm) unless a rehearsal names another
+        # one explicitly, and every rank reachable -- a ones-tensor summed over the group must come back as `world`
+        backend = dist.get_backend()
+        if backend != "nccl" and not os.environ.get("FSG_DIST_BACKEND"):
+            raise SystemExit(f"world_size {world} on GPUs needs the nccl (RCCL) backend, got {backend!r}; "
+                             "set FSG_DIST_BACKEND to rehearse over another one")
+        probe = torch.ones(1, device=device)
+        dist.all_reduce(probe, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        ranks_seen = int(round(float(probe.item())))
+        if ranks_seen != world:
+            raise SystemExit(f"all-reduce of ones returned {ranks_seen}, expected {world}: the process group is incomplete")
     B, N, k, desc = WORKLOADS[args.workload]
     classes = 4
     # bf16 exists where a hand-written dense contraction exists: the two-layer EdgeConv of DGCNN-seg (configs 2 / 4).  The
@@ -233,7 +247,9 @@ def main():
 
     def sync_grads():
         if flat_sync:
-            dist.all_reduce(opt.flat.grad, op=dist.ReduceOp.SUM)
+            # synchronous call on the CURRENT (replay) stream: RCCL enqueues the collective stream-ordered after graph 1 and
+            # before graph 2, the host does not wait for it
+            dist.all_reduce(opt.flat.grad, op=dist.ReduceOp.SUM, async_op=False)
         else:
             averager.finish()
 
@@ -290,6 +306,9 @@ def main():
                 _dump_memmap(os.environ["FSG_DUMP_MEMMAP"] + f".rank{rank}.json", net, opt)
 
             def graph_step():
+                if flat_sync:     # graph 1 -> in-place all-reduce of flat.grad on the replay stream -> graph 2
+                    D.flat_sync_step(g1.replay, opt.flat.grad, g2.replay)
+                    return static_loss
                 g1.replay()
                 if world > 1:
                     sync_grads()
@@ -512,6 +531,7 @@ def main():
                           "launch": launch, "optimizer": "torch.optim.Adam(fused)" if args.torch_adam else
                           "Adam over one flat parameter buffer (optim.FlatAdam: fsg_adam_flat_f32, one launch)",
                           "parallelism": f"dp{world}",
+                          "dist_backend": None if world == 1 else dist.get_backend(), "ranks_seen": ranks_seen,
                           "grad_sync": None if world == 1 else
                           ("one in-place all-reduce of FlatAdam's flat gradient buffer between the fwd/bwd graph and the "
                            "optimizer graph" if flat_sync else "bucketed averager (cat, all-reduce, copy back)")},

@@ -26,7 +26,7 @@ def install_reference_aliases():
         "models.pointtransformer.pointops": ".models.pointtransformer.pointops",
         "models.pointtransformer.seg_model": ".models.pointtransformer.seg_model",
         "losses.chamfer_loss": ".losses.chamfer_loss", "losses.nnu_loss": ".losses.nnu_loss",
-        "losses.access_losses": ".losses.access_losses",
+        "losses.access_losses": ".losses.access_losses", "losses.mesh_loss": ".losses.mesh_loss",
     }
     for ref_name, ours in pairs.items():
         sys.modules[ref_name] = importlib.import_module(ours, __name__)

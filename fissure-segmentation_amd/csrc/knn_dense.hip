@@ -159,7 +159,7 @@ extern "C" int fsg_knn_dense_f32(const float *x, int B, int N, int64_t stride_b,
     FSG_REQUIRE(N <= 32768, "fsg_knn_dense_f32: N=%d > 32768 unsupported", N);
     if (B == 0) return FSG_OK;
     hipStream_t st = (hipStream_t)stream;
-    // The superseded designs (first matrix-core kernel, flag 8; wave-specialised pipeline, 4096; threshold filter, 16384) are
+    // The superseded design kept as a cross-check (first matrix-core kernel, flag 8; 4096 / 16384 were the removed pipeline / filter) is
     // test / benchmark infrastructure and live in libfsg_hip_experiments.so (csrc/knn_experiments.hip), not in the product.
     FSG_REQUIRE(!(flags & (FSG_KNN_FORCE_MFMA | 4096 | 16384)),
                 "fsg_knn_dense_f32: flags %d select an experimental kernel: call fsg_knn_experiment_f32 of "

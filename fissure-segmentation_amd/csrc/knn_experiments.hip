@@ -1,18 +1,15 @@
-// libfsg_hip_experiments.so -- the superseded kNN designs, kept as independent cross-checks of the production kernel
-// (tests/test_gpu_parity.py compares all of them bit for bit at the BASELINE sizes) and as benchmark baselines
-// (tools/bench_kernels.py).  TEST INFRASTRUCTURE: not part of libfsg_hip.so, not declared in include/fsg_hip.h.
+// libfsg_hip_experiments.so -- ONE superseded kNN design, kept as an independent cross-check of the production kernels
+// (tests/test_gpu_parity.py compares it bit for bit at the BASELINE sizes) and as a benchmark baseline
+// (tools/bench_kernels.py).  TEST INFRASTRUCTURE: not part of libfsg_hip.so, not declared in include/fsg_hip.h, loaded only by
+// the tests that ask for it (`_lib.experiments()`).
 //   flag 8      knn_mfma.hip    first matrix-core design (per-lane filter + sorting network)
-//   flag 4096   knn_pipe.hip    wave-specialised pipeline (MFMA producer waves + selection consumer waves)
-//   flag 16384  knn_filter.hip  threshold filter on the accumulators from tau = +inf
+// (round 3 removed the wave-specialised pipeline knn_pipe.hip and the threshold filter knn_filter.hip from the tree; their
+// measurements are in DESIGN.md "What did not work", their code in the history up to round 2.)
 // Same arguments and results as fsg_knn_dense_f32 (include/fsg_hip.h).
 #include "fsg_common.h"
 
-int fsg_knn_pipe_launch(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k, int flags,
-                        int32_t *idx_out, float *dist_out, float *xx_scratch, hipStream_t st);    // knn_pipe.hip
 int fsg_knn_mfma_launch(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k, int flags,
                         int32_t *idx_out, float *dist_out, float *xx_scratch, hipStream_t st);    // knn_mfma.hip
-int fsg_knn_filter_launch(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k, int flags,
-                          int32_t *idx_out, float *dist_out, float *xx_scratch, hipStream_t st);  // knn_filter.hip
 
 extern "C" int fsg_knn_experiment_f32(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k,
                                       int flags, int32_t *idx_out, float *dist_out, float *xx_scratch, fsg_stream_t stream) {
@@ -23,8 +20,6 @@ extern "C" int fsg_knn_experiment_f32(const float *x, int B, int N, int64_t stri
     hipStream_t st = (hipStream_t)stream;
     int rc = FSG_ERR_UNSUPPORTED;
     if (flags & FSG_KNN_FORCE_MFMA) rc = fsg_knn_mfma_launch(x, B, N, stride_b, stride_c, c_knn, k, flags, idx_out, dist_out, xx_scratch, st);
-    else if (flags & 16384) rc = fsg_knn_filter_launch(x, B, N, stride_b, stride_c, c_knn, k, flags, idx_out, dist_out, xx_scratch, st);
-    else if (flags & 4096) rc = fsg_knn_pipe_launch(x, B, N, stride_b, stride_c, c_knn, k, flags, idx_out, dist_out, xx_scratch, st);
     if (rc == FSG_ERR_UNSUPPORTED) fsg_set_error("fsg_knn_experiment_f32: flags %d / shape outside the experimental kernels' envelope", flags);
     return rc;
 }

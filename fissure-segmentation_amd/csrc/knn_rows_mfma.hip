@@ -782,7 +782,7 @@ int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int
     const bool half = small_k && (flags & 2048);
     // 16 waves per workgroup wherever the registers allow (both phases are latency-bound); flag 8192: the 8-wave variants
     const bool w8 = (flags & 8192) != 0;
-    // streamed selection (STREAM = true, 512-candidate chunks, 16 waves), flag 131072.  Exact (same parity suite) but
+    // streamed selection (STREAM = true, 512-candidate chunks, 16 waves), formerly flag 131072.  Exact (same parity suite) but
     // MEASURED SLOWER than the two-phase kernel and therefore opt-in: B=8 N=2048 k=20 C=64 101 vs 88 us, C=3 70 vs 52 us;
     // B=4 N=8192 k=40 C=64 567 vs 542 us (tools/knn_ablate_phases.py, eager timing incl. the squared-norm launch).  What the
     // instrumented build (-DFSG_KNN_STATS, tools/knn_stream_stats.py) shows: the filter works as designed -- 57 survivors
@@ -791,13 +791,8 @@ int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int
     // latency, the two barriers and the rank-by-counting merge (which dominates the selection either way) are all exposed,
     // and 512-candidate chunks are 14 us slower than 1024-candidate ones for the same reason.  Two co-resident 8-wave
     // workgroups per CU (flag 262144: 256-candidate first chunk, 50 KB of LDS, 101 VGPRs) change nothing: 101 us.
-    if ((flags & 131072) && !(flags & (8192 | 2048)) && c_knn <= 64) {
-        if (c_knn <= 4) { if (small_k) FSG_KNN_RMQS(1, 16, 128, 512, 32, false, true); else FSG_KNN_RMQS(1, 16, 128, 512, 64, false, true); }
-        else if (c_knn <= 16) { if (small_k) FSG_KNN_RMQS(4, 16, 128, 512, 32, false, true); else FSG_KNN_RMQS(4, 16, 128, 512, 64, false, true); }
-        else { if (small_k) FSG_KNN_RMQS(16, 16, 128, 512, 32, true, true); else FSG_KNN_RMQS(16, 16, 128, 512, 64, true, true); }
-        FSG_CHECK_LAUNCH("fsg_knn_dense_f32/rows_mfma_stream");
-        return FSG_OK;
-    }
+    // (round 3: the streamed instantiations are no longer built into the library -- the STREAM template paths above are kept as
+    // the record of the design; re-enable by dispatching FSG_KNN_RMQS(..., true) on a flag here)
     if (c_knn <= 4) { if (!w8) FSG_KNN_RM(1, 16, 128, 1024, 64); else FSG_KNN_RM(1, 8, 128, 1024, 64); }
     else if (c_knn <= 16) { if (!w8) FSG_KNN_RM(4, 16, 128, 1024, 64); else FSG_KNN_RM(4, 8, 128, 1024, 64); }
     else if (c_knn <= 64) {

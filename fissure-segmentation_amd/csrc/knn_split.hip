@@ -1,5 +1,5 @@
 // Dense kNN graph build, "coarse sweep + exact refine" kernel behind fsg_knn_dense_ws_f32
-// (1024 <= N <= 8192, c_knn <= 128 -- above 64 channels N <= 4096 --, k + drop <= 64).  Replaces
+// (1024 <= N <= 8192, c_knn <= 128 -- above 64 channels N <= 4096, enforced by plan() --, k + drop <= 64).  Replaces
 // utils/general_utils.py:43-53,315-327 like the two-phase kernel of knn_rows_mfma.hip and returns the SAME bits (indices and
 // distances of oracle/fsg_oracle.c): the matrix cores only NOMINATE candidates, every distance that is ranked or returned is
 // the oracle's fp32 fma chain.
@@ -610,15 +610,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_split_kernel(const float *_
             const float ni = sqrtf(xq) * 1.0001f;
             float eps;
             if (HALF) {
-                // centred, scaled units (ni, R from xs; the oracle's norms no, Ro in original units, times the scale):
+                // centred, scaled units (ni, R from xs; the oracle's norms no, Ro in original units, times the scale); CH = the
+                // channel count the constants are derived for (64 up to four k-steps, 128 for the eight-step instantiation):
                 //   fp16 rounding of both operands, factor 2           2 (2^-10 + 2^-22) ni R            -> 1.96e-3 ni R
-                //   flushed / spurious values below 2^-14 (a = 2^-14)  2 (8 a (ni + R) + 64 a^2)         -> 9.8e-4 (ni + R) + 5e-7
-                //   fp32 accumulation of 65 terms in the matrix core   66 * 2^-23 (R^2 + 2.01 ni R)      -> 7.9e-6 (R^2 + 2.01 ni R)
-                //   centred norm chain, centring in fp32               3.8e-6 R^2 + 1.2e-7 (ni + R)^2
+                //   flushed / spurious values below 2^-14 (a = 2^-14)  2 (sqrt(CH) a (ni + R) + CH a^2)  -> 9.8e-4 (ni + R) + 5e-7 at CH = 64
+                //   fp32 accumulation of CH + 1 terms in the matrix core   (CH + 2) 2^-23 (R^2 + 2.01 ni R) -> 7.9e-6 (..) at CH = 64
+                //   centred norm chain, centring in fp32               CH 2^-24 R^2 + 1.2e-7 (ni + R)^2  -> 3.8e-6 R^2 at CH = 64
                 //   the oracle's own fp32 chains against real arithmetic                                  -> 9.2e-6 (sg (no + Ro))^2
+                constexpr float CH = KS == 8 ? 128.f : 64.f;
+                constexpr float A14 = 6.103515625e-05f;                                   // 2^-14
+                constexpr float kFlush1 = (KS == 8 ? 11.3138f : 8.f) * 2.f * A14 * 1.004f;  // 2 sqrt(CH) a, rounded up
+                constexpr float kFlush0 = 2.f * CH * A14 * A14 * 1.05f;
+                constexpr float kAcc = (CH + 2.f) * 1.1920929e-07f * 1.004f;              // (CH + 2) 2^-23
+                constexpr float kNorm = CH * 5.9604645e-08f * 1.004f;                     // CH 2^-24
                 const float no = sqrtf(qrow[q * CPQ + CP]) * 1.0001f;
                 const float so = sg * (no + Ro);
-                eps = (1.96e-3f * ni * R + 9.8e-4f * (ni + R) + 5e-7f + 7.9e-6f * (R * R + 2.01f * ni * R) + 3.8e-6f * R * R +
+                eps = (1.96e-3f * ni * R + kFlush1 * (ni + R) + kFlush0 + kAcc * (R * R + 2.01f * ni * R) + kNorm * R * R +
                        1.2e-7f * (ni + R) * (ni + R) + 9.2e-6f * so * so) * 1.001f;
             } else {
                 eps = (1.0e-4f * ni * R + 2.6e-5f * (R * R + 2.1f * ni * R) + 9.2e-6f * (ni + R) * (ni + R)) * 1.001f;
@@ -913,7 +920,7 @@ struct SplitPlan {
 // the workspace is sized for the larger of the two operand images (two bf16 pieces; the fp16 image is half of it)
 SplitPlan plan(int B, int N, int c_knn) {
     SplitPlan p{};
-    p.ok = N >= 1024 && N <= 8192 && c_knn >= 1 && c_knn <= 128;
+    p.ok = N >= 1024 && N <= (c_knn > 64 ? 4096 : 8192) && c_knn >= 1 && c_knn <= 128;
     p.pack = c_knn <= 4;
     p.KS = p.pack ? 1 : (c_knn <= 16 ? 1 : (c_knn <= 32 ? 2 : (c_knn <= 64 ? 4 : 8)));
     p.CP = p.pack ? 4 : 16 * p.KS;

@@ -4,11 +4,18 @@ RCCL all-reduces over xGMI (torch.distributed backend "nccl" == RCCL on ROCm; "g
 The reference is single-process; this is the build's addition for BASELINE config 4.
 Every cloud is independent (kNN, FPS and attention never cross clouds), BatchNorm statistics stay
 per replica like stock DDP, so the only exchange is the gradient average.  The payload is small
-(DGCNNSeg: 631 428 fp32 = 2.5 MB) and latency-bound, so it is sent as TWO flat buckets: the point-wise
-head (whose gradients are complete first during backward) goes out on a side stream while the EdgeConv
-backward is still running, the remaining EdgeConv gradients follow at the end of backward.  On xGMI's
-fully connected topology RCCL moves each bucket over all 7 links at once; a bucket count above two
-only adds launch latency.
+(DGCNNSeg: 631 428 fp32 = 2.5 MB) and latency-bound.
+
+Default scheme (bench.py, hipGraph replay): graph 1 = forward + loss + backward + `FlatAdam.gather_grads()`
+(one cat into the optimizer's flat gradient buffer, allocated before any capture) -> ONE in-place
+`dist.all_reduce(opt.flat.grad)` on the replay stream (synchronous call, stream-ordered on the GPU) ->
+graph 2 = scale by 1/world + fused Adam over the flat parameter buffer.  Nothing is copied back.
+On xGMI's fully connected topology RCCL moves the bucket over all 7 links at once; more buckets only add
+launch latency.
+
+`BucketedGradAverager` is the eager-mode alternative (`bench.py --grad-sync bucketed --eager`): TWO flat
+buckets, the point-wise head (whose gradients are complete first during backward) goes out on a side stream
+while the EdgeConv backward is still running, the EdgeConv gradients follow at the end of backward.
 """
 import os
 
@@ -55,6 +62,21 @@ def broadcast_parameters(model, src=0):
     for t in tensors:
         t.copy_(flat[off:off + t.numel()].view_as(t))
         off += t.numel()
+
+
+def flat_sync_step(run_fwd_bwd, flat_grad, run_update, collective=None):
+    """One data-parallel step of the flat scheme, in the only order that is correct: `run_fwd_bwd()` (graph 1: forward, loss,
+    backward, gather into `flat_grad`) -> ONE in-place SUM all-reduce of `flat_grad`, issued synchronously (async_op=False) on
+    the current stream, so the device executes it after everything `run_fwd_bwd` enqueued and before anything `run_update`
+    enqueues -> `run_update()` (graph 2: scale by 1/world + Adam).  No handle escapes, nothing runs on a side stream: there is
+    no window in which the update could read an un-reduced buffer.  `collective` replaces dist.all_reduce in tests."""
+    out = run_fwd_bwd()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        work = (collective or dist.all_reduce)(flat_grad, op=dist.ReduceOp.SUM, async_op=False)
+        if work is not None:          # a backend that hands a handle back even for a synchronous call
+            work.wait()
+    run_update()
+    return out
 
 
 class BucketedGradAverager:

@@ -132,7 +132,7 @@ def deterministic():
 
 
 # ------------------------------------------------------------------ dense kNN (utils/general_utils.py:315)
-_KNN_EXPERIMENT_FLAGS = 8 | 4096 | 16384   # first MFMA design, wave-specialised pipeline, threshold filter
+_KNN_EXPERIMENT_FLAGS = 8   # the first MFMA design (libfsg_hip_experiments.so): independent cross-check for tests / tools
 
 
 def knn_graph(x, k, c_knn=None, fix_diag=True, drop_first=False, return_dist=False, force_rows_kernel=False,

@@ -1,8 +1,9 @@
 """Loss registry (reference: losses/access_losses.py:16-93): `train.py:38` and `train_pc_ae.py` obtain their criterion
 through `get_loss_fn(name, class_weights, term_weights)`.
 
-On the hot path: 'nnunet' (CE + generalised Dice, the default of train.py) and 'chamfer' run on the HIP kernels; 'ce' is
-torch's own criterion exactly as in the reference.  The remaining names ('recall', 'ssm', 'mesh', 'dpsr') belong to
+On the hot path: 'nnunet' (CE + generalised Dice, the default of train.py), 'chamfer' and the Chamfer term of 'mesh'
+(losses/mesh_loss.py: surface samples in, regularisers only with pytorch3d) run on the HIP kernels; 'ce' is
+torch's own criterion exactly as in the reference.  The remaining names ('recall', 'ssm', 'dpsr') belong to
 pipelines outside SURVEY section 8 (mesh / shape-model / DPSR losses on pytorch3d): they are handed to the reference's own
 classes when those are importable next to this package (a reference checkout with its dependencies), and raise
 NotImplementedError otherwise -- never a silent substitute."""
@@ -14,6 +15,7 @@ import torch
 from torch import nn
 
 from .chamfer_loss import ChamferLoss
+from .mesh_loss import RegularizedMeshLoss
 from .nnu_loss import NNULoss
 
 
@@ -34,8 +36,6 @@ class Losses(Enum):
 _OUT_OF_SCOPE = {  # name -> (reference module, class, keyword names of term_weights, takes class_weights first)
     Losses.RECALL.value: ("losses.recall_loss", "BatchRecallLoss", None, False),
     Losses.SSM.value: ("losses.dgssm_loss", "DGSSMLoss", ("w_point", "w_coefficients", "w_affine"), False),
-    Losses.MESH.value: ("losses.mesh_loss", "RegularizedMeshLoss",
-                        ("w_chamfer", "w_edge_length", "w_normal_consistency", "w_laplacian"), False),
     Losses.DPSR.value: ("losses.dpsr_loss", "DPSRLoss", ("w_seg", "w_mesh", "epoch_start_mesh_loss"), True),
 }
 
@@ -62,6 +62,12 @@ def get_loss_fn(loss: Losses, class_weights: torch.Tensor = None, term_weights: 
         return nn.CrossEntropyLoss(class_weights)
     if loss == Losses.CHAMFER.value:
         return ChamferLoss()
+    if loss == Losses.MESH.value:   # access_losses.py:67-77 of the reference
+        if term_weights is not None:
+            assert len(term_weights) == 4
+            return RegularizedMeshLoss(w_chamfer=term_weights[0], w_edge_length=term_weights[1],
+                                       w_normal_consistency=term_weights[2], w_laplacian=term_weights[3])
+        return RegularizedMeshLoss()
     if loss in _OUT_OF_SCOPE:
         _, _, names, takes_cw = _OUT_OF_SCOPE[loss]
         cls = _reference_class(loss)

@@ -57,11 +57,13 @@ int fsg_knn_dense_f32(const float *x, int B, int N, int64_t stride_b, int64_t st
                       fsg_stream_t stream);
 
 /*
- * The same graph build with a caller-owned workspace (what the nn.Module layer calls).  Inside 1024 <= N <= 16384,
- * c_knn <= 64 the graph comes from the coarse-sweep + exact-refine kernel: split-bf16 products on
- * v_mfma_f32_32x32x16_bf16 nominate ~1.2 k candidates per query under a rigorous error bound, and only the nominees get the
- * arithmetic above (indices AND distance bits equal fsg_knn_dense_f32's).  Other shapes: fsg_knn_dense_f32 with the
- * workspace as xx_scratch.  workspace may be NULL (then as fsg_knn_dense_f32 with xx_scratch = NULL).
+ * The same graph build with a caller-owned workspace (what the nn.Module layer calls).  Inside 1024 <= N <= 8192 with
+ * c_knn <= 64 (N <= 4096 for 64 < c_knn <= 128) and k + drop <= 64 the graph comes from the coarse-sweep + exact-refine kernel
+ * (csrc/knn_split.hip): coarse products on the matrix cores -- ONE fp16 image of the points centred on a sampled mean and
+ * scaled by a power of two above 4 channels (v_mfma_f32_32x32x16_f16), two bf16 pieces / three products up to 4 channels
+ * (v_mfma_f32_32x32x16_bf16) -- only NOMINATE candidates under a rigorous error bound (~25 per query at k = 20), and only the
+ * nominees get the arithmetic above: indices AND distance bits equal fsg_knn_dense_f32's.  Other shapes: fsg_knn_dense_f32 with
+ * the workspace as xx_scratch.  workspace may be NULL (then as fsg_knn_dense_f32 with xx_scratch = NULL).
  */
 size_t fsg_knn_dense_workspace_bytes(int B, int N, int c_knn);
 int fsg_knn_dense_ws_f32(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn,

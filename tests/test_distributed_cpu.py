@@ -175,3 +175,49 @@ def test_gloo_world2_flat_gradient_allreduce_in_place():
         opt.step()
     for wa, p in zip(out[0]["w"], ref.parameters()):
         torch.testing.assert_close(wa, p.detach(), rtol=1e-4, atol=1e-6)
+
+
+def _worker_order(rank, world, port, out):
+    """flat_sync_step with recording stand-ins for the two graphs and an event-ordered fake collective: the collective must
+    see graph 1 finished and graph 2 not started, must be called synchronously on the optimizer's own buffer, and graph 2
+    must read the REDUCED values"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from fissure_segmentation_amd import distributed as D
+    D.init_from_env(backend="gloo")
+    flat = torch.zeros(5)
+    log, seen = [], []
+
+    def g1():
+        log.append("g1")
+        flat.fill_(float(rank + 1))
+        return "loss"
+
+    def fake_all_reduce(t, op=None, async_op=None):
+        assert log == ["g1"], log                      # after graph 1, before graph 2
+        assert async_op is False and op == dist.ReduceOp.SUM
+        assert t.data_ptr() == flat.data_ptr()         # in place, the optimizer's own buffer
+        log.append("allreduce")
+        return dist.all_reduce(t, op=op, async_op=False)
+
+    def g2():
+        assert log == ["g1", "allreduce"], log
+        log.append("g2")
+        seen.append(flat.clone())
+
+    for _ in range(2):
+        del log[:]
+        assert D.flat_sync_step(g1, flat, g2, collective=fake_all_reduce) == "loss"
+        assert log == ["g1", "allreduce", "g2"]
+    out[rank] = [t.tolist() for t in seen]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_flat_sync_step_orders_collective_between_the_graphs():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_order, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        assert out[r] == [[3.0] * 5, [3.0] * 5]        # 1 + 2 from both ranks: the update read the reduced buffer

@@ -175,9 +175,25 @@ def test_install_reference_aliases_and_loss_registry(monkeypatch):
         assert isinstance(get_loss_fn("chamfer"), ChamferLoss)
         assert isinstance(get_loss_fn("ce", torch.ones(3)), torch.nn.CrossEntropyLoss)
         assert Losses.list() == ["nnunet", "ce", "recall", "ssm", "chamfer", "mesh", "dpsr"]
-        for name in ("recall", "ssm", "mesh", "dpsr"):
+        for name in ("recall", "ssm", "dpsr"):
             with pytest.raises(NotImplementedError, match="outside the MI355X hot path"):
                 get_loss_fn(name)
+        # 'mesh' (losses/access_losses.py:67-77 of the reference): this package's RegularizedMeshLoss, Chamfer term on the HIP
+        # kernel; default / explicit term weights as in the reference; the regularisers refuse to run without pytorch3d Meshes
+        from losses.mesh_loss import RegularizedMeshLoss
+        m = get_loss_fn("mesh")
+        assert isinstance(m, RegularizedMeshLoss)
+        assert (m.w_chamfer, m.w_edge_length, m.w_normal_consistency, m.w_laplacian, m.n_samples) == (1., 1., 0.1, 0.1, 2048)
+        m = get_loss_fn(Losses.MESH, term_weights=[2., 0., 0., 0.5])
+        assert (m.w_chamfer, m.w_edge_length, m.w_normal_consistency, m.w_laplacian) == (2., 0., 0., 0.5)
+        with pytest.raises(AssertionError):
+            get_loss_fn("mesh", term_weights=[1., 1.])
+        zero = RegularizedMeshLoss(0., 0., 0., 0.)
+        assert zero(torch.zeros(1, 4, 3), torch.zeros(1, 4, 3)) == (0, {})
+        with pytest.raises(NotImplementedError, match="Edge Length"):
+            RegularizedMeshLoss(0., 1., 0., 0.)(torch.zeros(1, 4, 3), torch.zeros(1, 4, 3))
+        with pytest.raises(TypeError, match="cannot draw surface samples"):
+            RegularizedMeshLoss(1., 0., 0., 0.)(object(), object())
         with pytest.raises(ValueError, match="No loss function named"):
             get_loss_fn("nope")
     finally:

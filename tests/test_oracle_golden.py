@@ -123,6 +123,28 @@ def test_folding_ae_restatement(name):
     check_model(net, g, x, "recon")
 
 
+def test_mesh_chamfer_golden_vs_restatement():
+    """the Chamfer term of RegularizedMeshLoss at 2 x 2048 samples (oracle/make_golden_mesh.py: the reference's pairwise_dist2)
+    against both oracle layers"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    from make_golden_mesh import surface_samples
+    g = load("mesh_chamfer_s711")
+    a, b = surface_samples(int(g["seed_pred"])), surface_samples(int(g["seed_targ"]))
+    at = T(a).requires_grad_(True)
+    loss = ref_cpu.chamfer(at, T(b))
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5 * float(g["loss"])
+    # the reference's expanded form |x|^2 - 2xy + |y|^2 and the direct (x - y)^2 form pick another of two near-equidistant
+    # targets on a few rows (3 of 4096 here): rows must agree at 1e-4 except for <= 0.2 percent of them, whole tensor 5e-3 in norm
+    err = np.abs(at.grad.numpy() - g["grad_pred"])
+    rows_off = (err > 1e-4 * np.abs(g["grad_pred"]) + 1e-7).any(-1)
+    assert rows_off.mean() <= 2e-3 and np.linalg.norm(err) <= 5e-3 * np.linalg.norm(g["grad_pred"])
+    d1, _ = c_api.chamfer_nn(a, b)
+    d2, _ = c_api.chamfer_nn(b, a)
+    assert abs(d1.mean(1, dtype=np.float64).mean() + d2.mean(1, dtype=np.float64).mean() - float(g["loss"])) <= 1e-5 * float(g["loss"])
+
+
 def test_chamfer_restatement():
     g = load("chamfer_s701")
     rng = np.random.default_rng(701)

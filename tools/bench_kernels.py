@@ -26,7 +26,7 @@ if "knn" in which:
     for (B, C, N, k) in [(8, 3, 2048, 20), (8, 64, 2048, 20), (4, 3, 8192, 40), (4, 64, 8192, 40), (8, 128, 2048, 20), (8, 64, 4096, 20),
                          (8, 128, 4096, 20), (8, 3, 4096, 20)]:
         x = torch.from_numpy(cloud(1, B, C, N)).to(dev)
-        for name, rows, dbg in (("rows_mfma(v2)", False, 0), ("rows_mfma 8 waves", False, 8192), ("filter(v4)", False, 16384), ("pipe(v3)", False, 4096), ("mfma(v1)", False, 8), ("rows(v0)", True, 0)):
+        for name, rows, dbg in (("rows_mfma(v2)", False, 0), ("rows_mfma 8 waves", False, 8192), ("mfma(v1)", False, 8), ("rows(v0)", True, 0)):
             med, mn = timeit(lambda: F.knn_graph(x, k, force_rows_kernel=rows, _debug_flags=dbg))
             print(f"knn B={B} C={C} N={N} k={k} {name:14s}: median {med:8.1f} us  min {mn:8.1f} us")
 if "knn2ablate" in which:

@@ -1,14 +1,17 @@
 """Phase split / A-B switches of the production kNN kernel at the BASELINE shapes.  Variants are timed round-robin (five
 rounds of 20 launches each, best median) so that clock ramp-up does not favour whichever variant runs last.
-flags: 256 no phase B, 512 no phase A, 131072 the streamed kernel (filter on the accumulators after the first chunk), +1024 with every
-chunk through the LDS block, 262144 two 8-wave streamed workgroups per CU, 65536 plain (not XCD-aware) workgroup placement."""
+flags: 256 no phase B, 512 no phase A, 65536 plain (not XCD-aware) workgroup placement."""
 import sys, torch, numpy as np
 sys.path[:0] = ["/root/repo", "/root/repo/tests"]
 import fissure_segmentation_amd as fsg
 from golden_util import cloud
 F = fsg.functional
 dev = torch.device("cuda:0")
-VARIANTS = (("two-phase", 0), ("4-byte loads", 1048576), ("tp-noB", 256), ("tp-neither", 768), ("stream", 131072))
+# 2097152 forces the two-phase kernel (knn_rows_mfma.hip): without it fsg_knn_dense_ws_f32 routes these shapes to knn_split.hip,
+# which ignores the two-phase ablation bits
+TP = 2097152
+VARIANTS = (("split (default)", 0), ("two-phase", TP), ("tp 4-byte loads", TP | 1048576), ("tp-noB", TP | 256),
+            ("tp-neither", TP | 768))
 def med(fn, n=20):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ts = []
