@@ -75,6 +75,9 @@ SIGNATURES = {
     "fsg_group_gather_bwd_f32": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
     "fsg_vec_attn_fwd_f32": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "fsg_vec_attn_bwd_f32": ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "fsg_pw_weight_image_bytes": ([_I, _I], ctypes.c_size_t),
+    "fsg_pw_weight_image_f32": ([_P, _L, _L, _I, _I, _F, _I, _I, _P, _P], _I),
+    "fsg_pw_linear_f32": ([_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P], _I),
 }
 for _name, (_args, _res) in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here = header and library out of sync

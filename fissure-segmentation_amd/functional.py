@@ -894,6 +894,34 @@ def edgeconv2(x, idx, conv1_weight, bn1, conv2_weight, bn2, slope, x_pm=None, bo
     return (out, out_pm) if both else out
 
 
+# ------------------------------------------------------------------ point-wise layers on the bf16 matrix pipe, fp32-grade
+def pw_weight_image(w, scale=1.0, out=None, ks0=0, KS=None):
+    """(N, K) fp32 weight (any strides: a view of a wider matrix, or a transposed view) -> the three-piece bf16 operand image of
+    csrc/pointwise.hip (include/fsg_hip.h: fsg_pw_weight_image_f32).  `out` / `ks0` / `KS`: fill k-steps [ks0, ks0 + K/16) of
+    an existing image that concatenates several matrices along k."""
+    _need_gpu(w)
+    N, K = w.shape
+    ks = (K + 15) // 16
+    KS = ks if KS is None else KS
+    if out is None:
+        out = torch.empty(((N + 31) // 32) * KS * 3 * 1024, dtype=torch.uint8, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.call("fsg_pw_weight_image_f32", _p(w), w.stride(0), w.stride(1), N, K, float(scale), ks0, KS, _p(out), _stream())
+    return out
+
+
+def pw_linear(x, image, N, bias=None, tile=0):
+    """y (M, N) = x (M, K) W^T (+ bias) with W given as pw_weight_image(W): six bf16 MFMA products per fp32 product, fp32
+    accumulation (include/fsg_hip.h: fsg_pw_linear_f32)"""
+    _need_gpu(x)
+    M, K = x.shape
+    assert x.stride(1) == 1 and x.dtype == torch.float32
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.call("fsg_pw_linear_f32", _p(x), x.stride(0), _p(image), _p(bias), _p(y), N, M, N, K, tile, _stream())
+    return y
+
+
 # ------------------------------------------------------------------ BatchNorm + LeakyReLU on (M, C) rows
 class _BNAct(torch.autograd.Function):
     @staticmethod

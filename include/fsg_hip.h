@@ -442,6 +442,24 @@ int fsg_colsum_narrow_f32(const float *x, int64_t M, int C, float *out, fsg_stre
 int fsg_fold_layer1_f32(const float *pts, int cp, const float *w, int64_t ldw, const float *per_cloud, int B, int m, int Cout,
                         int relu, float *out, fsg_stream_t stream);
 
+/*
+ * Point-wise layers of the DGCNN head on the bf16 matrix pipe with fp32-grade results (csrc/pointwise.hip): replaces the
+ * Conv1d(kernel 1) products of models/dgcnn.py:123-137,156-160,282-323.  Every fp32 operand is split into three bf16 pieces
+ * (x = h + m + l, exact to 2^-27 |x|) and a product is six v_mfma_f32_32x32x16_bf16 products with fp32 accumulation: as
+ * close to real arithmetic as an fp32 fma chain, at 2.7x the rate of the fp32 matrix instruction.
+ *
+ * fsg_pw_weight_image_f32: the (N, K) matrix W(n, k) = W[n*stride_n + k*stride_k] * scale -> the register image of the MFMA's
+ *   B operand (fsg_pw_weight_image_bytes(N, K) bytes; rows and columns padded with zeros).  An image may concatenate several
+ *   matrices along k: this call fills k-steps [ks0, ks0 + ceil(K/16)) of an image with KS k-steps per 32-row block.
+ * fsg_pw_linear_f32: C (M, N) = A (M, K) W^T (+ bias), A fp32 rows with stride lda (multiple of 4, 16-byte aligned),
+ *   K % 32 == 0, W given as its image.  tile: 0 = chosen by shape, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 128x64.
+ */
+size_t fsg_pw_weight_image_bytes(int N, int K);
+int fsg_pw_weight_image_f32(const float *W, int64_t stride_n, int64_t stride_k, int N, int K, float scale, int ks0, int KS,
+                            void *image, fsg_stream_t stream);
+int fsg_pw_linear_f32(const float *A, int64_t lda, const void *image, const float *bias, float *C, int64_t ldc, int M, int N,
+                      int K, int tile, fsg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
