@@ -78,6 +78,19 @@ SIGNATURES = {
     "fsg_pw_weight_image_bytes": ([_I, _I], ctypes.c_size_t),
     "fsg_pw_weight_image_f32": ([_P, _L, _L, _I, _I, _F, _I, _I, _P, _P], _I),
     "fsg_pw_linear_f32": ([_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P], _I),
+    "fsg_pw_tile_rows": ([_I], _I),
+    "fsg_pw_rowgemm_f32": ([_P, _I, _I, _I, _P], _I),
+    "fsg_pw_tn_workspace_bytes": ([_I, _I, _I, _I], ctypes.c_size_t),
+    "fsg_pw_tn_f32": ([_P, _I, _P, ctypes.c_size_t, _P, _L, _P, _L, _P], _I),
+    "fsg_pw_bn_finalize_f32": ([_P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
+    "fsg_pw_max_finish_f32": ([_P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P], _I),
+    "fsg_pw_bnbwd_finalize_f32": ([_P, _I, _I, _I, _L, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P], _I),
+    "fsg_pw_logits_bwd_f32": ([_P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _P, _P], _I),
+    "fsg_pw_gf_prep_f32": ([_P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _F, _P, _P, _P, _P, _P, _P], _I),
+    "fsg_pw_scatter_rows_f32": ([_P, _P, _P, _L, _I, _I, _I, _I, _P, _L, _P], _I),
+    "fsg_pw_gf_dw_f32": ([_P, _P, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _P, _L, _P], _I),
+    "fsg_pw_colsum_workspace_bytes": ([_L, _I], ctypes.c_size_t),
+    "fsg_pw_colsum_f32": ([_P, _L, _L, _I, _P, _P, _P], _I),
 }
 for _name, (_args, _res) in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here = header and library out of sync
@@ -113,6 +126,23 @@ class PTLayerParams(ctypes.Structure):
 class EdgeWeightJobs(ctypes.Structure):
     """include/fsg_hip.h: fsg_edge_weight_jobs"""
     _fields_ = [("src", _P * 8), ("dst", _P * 8), ("Co", _I * 8), ("C", _I * 8), ("n", _I)]
+
+
+class PWRowGemmArgs(ctypes.Structure):
+    """include/fsg_hip.h: fsg_pw_rowgemm_args"""
+    _fields_ = [("A1", _P), ("Y1", _P), ("A2", _P), ("lda1", _L), ("lda2", _L), ("K1", _I), ("K2", _I), ("Bimg", _P),
+                ("M", _I), ("N", _I), ("rows_per_cloud", _I), ("alpha", _P), ("delta", _P), ("P", _P), ("Q", _P),
+                ("tstride", _I), ("slope", _F), ("C", _P), ("ldc", _L), ("store_n0", _I), ("bias", _P), ("rec", _P),
+                ("sgn", _P), ("sel_val", _P), ("sel_arg", _P), ("sel_n", _I), ("Yp", _P), ("ldyp", _L), ("ealpha", _P),
+                ("edelta", _P), ("emu", _P), ("er", _P), ("etstride", _I), ("rec2", _P)]
+
+
+class PWTnArgs(ctypes.Structure):
+    """include/fsg_hip.h: fsg_pw_tn_args"""
+    _fields_ = [("L1", _P), ("LY1", _P), ("L2", _P), ("ldl1", _L), ("ldl2", _L), ("N1a", _I), ("N1b", _I), ("lpro", _I),
+                ("lalpha", _P), ("ldelta", _P), ("lP", _P), ("lQ", _P), ("lts", _I), ("R", _P), ("ldr", _L), ("N2", _I),
+                ("rpro", _I), ("ralpha", _P), ("rdelta", _P), ("rts", _I), ("slope", _F), ("M", _I), ("rows_per_cloud", _I),
+                ("rows_per_slice", _I)]
 
 
 class PTLayerGrads(ctypes.Structure):

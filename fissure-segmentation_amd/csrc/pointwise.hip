@@ -399,6 +399,550 @@ int launch_rowgemm(const RowGemmArgs &a, hipStream_t st, const char *name) {
     return FSG_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pw_tn_kernel:  part[s] (N1, N2) = sum over the rows m of slice s of  L'(m, n1) R'(m, n2)  -- the weight gradients
+// dW = dy^T a (and the Gram matrix X^T X of the global-feature backward).  Both operands are (M, .) row-major activations,
+// the contraction runs over ROWS: lane = column (coalesced 256-byte row segments), a thread collects eight consecutive rows
+// of its column -- exactly one operand fragment (k = 8 h + j) -- applies the prologue with per-COLUMN constants it keeps in
+// registers, splits, and writes 16 bytes per piece into the LDS fragment image.  Tile 64 T1 x 64 T2, four waves (2 x 2),
+// 32 rows per iteration.  The S row slices are summed in slice order by pw_tn_reduce_kernel: no atomics, reproducible.
+struct TnArgs {
+    const float *L1, *LY1;   // left segment 1: (M, N1a), row stride ldl1; lpro == PRO_BNBWD: L1 = upstream gradient, LY1 = y
+    const float *L2;         // left segment 2 (plain): (M, N1b), row stride ldl2
+    long ldl1, ldl2;
+    int N1a, N1b, lpro;
+    const float *lalpha, *ldelta, *lP, *lQ;   // left tables (length N1a; ldelta / lP per cloud with stride lts)
+    int lts;
+    const float *R;          // right operand (M, N2), row stride ldr; rpro == PRO_BNACT: f(ralpha y + rdelta[cloud])
+    long ldr;
+    int N2, rpro;
+    const float *ralpha, *rdelta;
+    int rts;
+    float slope;
+    int M, rows_per_cloud, rows_per_slice;
+    float *part;             // (S, N1a + N1b, N2)
+};
+
+template <int T1, int T2>
+__global__ __launch_bounds__(256) void pw_tn_kernel(const TnArgs p) {
+    constexpr int BT1 = 64 * T1, BT2 = 64 * T2;
+    __shared__ __attribute__((aligned(16))) u32x4 Limg[(BT1 / 32) * 2 * 3 * 64];
+    __shared__ __attribute__((aligned(16))) u32x4 Rimg[(BT2 / 32) * 2 * 3 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N1 = p.N1a + p.N1b;
+    const int nt2 = (p.N2 + BT2 - 1) / BT2;
+    const int t1 = blockIdx.x / nt2, t2 = blockIdx.x - t1 * nt2, s = blockIdx.y;
+    const int c1_0 = t1 * BT1, c2_0 = t2 * BT2;
+    const int m0 = s * p.rows_per_slice, m1 = min(p.M, m0 + p.rows_per_slice);
+    const int cloud = p.rows_per_cloud > 0 ? m0 / p.rows_per_cloud : 0;
+    const int ks = wave >> 1, hh = wave & 1;            // this wave's fragment rows: 16 ks + 8 hh + 0..7 of every 32-row step
+    // per-column constants of this thread's columns
+    float la[T1], ld_[T1], lp[T1], lq[T1], lmask[T1];
+    const float *lsrc[T1], *lysrc[T1];
+    long lld[T1];
+    bool lbwd[T1];
+#pragma unroll
+    for (int g = 0; g < T1; ++g) {
+        const int col = c1_0 + 64 * g + lane;
+        const bool seg2 = (c1_0 + 64 * g) >= p.N1a && p.N1b > 0;     // 64-column groups never straddle the segments (host check)
+        const int cc = min(col, N1 - 1);
+        lmask[g] = col < N1 ? 1.f : 0.f;
+        lbwd[g] = !seg2 && p.lpro == PRO_BNBWD;
+        lsrc[g] = seg2 ? p.L2 + (cc - p.N1a) : p.L1 + cc;
+        lysrc[g] = lbwd[g] ? p.LY1 + cc : lsrc[g];
+        lld[g] = seg2 ? p.ldl2 : p.ldl1;
+        la[g] = ld_[g] = lp[g] = lq[g] = 0.f;
+        if (lbwd[g]) {
+            la[g] = p.lalpha[cc];
+            ld_[g] = p.ldelta[(long)cloud * p.lts + cc];
+            lp[g] = p.lP[(long)cloud * p.lts + cc];
+            lq[g] = p.lQ[cc];
+        }
+    }
+    float ralp[T2], rdel[T2], rmask[T2];
+    const float *rsrc[T2];
+#pragma unroll
+    for (int g = 0; g < T2; ++g) {
+        const int col = c2_0 + 64 * g + lane, cc = min(col, p.N2 - 1);
+        rmask[g] = col < p.N2 ? 1.f : 0.f;
+        rsrc[g] = p.R + cc;
+        ralp[g] = p.rpro == PRO_BNACT ? p.ralpha[cc] : 1.f;
+        rdel[g] = p.rpro == PRO_BNACT ? p.rdelta[(long)cloud * p.rts + cc] : 0.f;
+    }
+    float lv[T1][8], lyv[T1][8], rv[T2][8];
+    auto fetch = [&](int mb) {                         // rows mb + 16 ks + 8 hh + j (clamped; rows >= m1 are zeroed at use)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long row = min(mb + 16 * ks + 8 * hh + j, p.M - 1);
+#pragma unroll
+            for (int g = 0; g < T1; ++g) {
+                lv[g][j] = lsrc[g][row * lld[g]];
+                lyv[g][j] = lysrc[g][row * lld[g]];
+            }
+#pragma unroll
+            for (int g = 0; g < T2; ++g) rv[g][j] = rsrc[g][row * p.ldr];
+        }
+    };
+    f32x16 acc[T1][T2];
+#pragma unroll
+    for (int i = 0; i < T1; ++i)
+#pragma unroll
+        for (int j = 0; j < T2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int w1 = wave >> 1, w2 = wave & 1;
+    fetch(m0);
+    for (int mb = m0; mb < m1; mb += 32) {
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < T1; ++g) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float live = (mb + 16 * ks + 8 * hh + j < m1) ? lmask[g] : 0.f;
+                float v = lv[g][j];
+                if (lbwd[g]) {
+                    const float y = lyv[g][j], u = __builtin_fmaf(y, la[g], ld_[g]);
+                    const float h = v * (u > 0.f ? 1.f : p.slope);
+                    v = __builtin_fmaf(la[g], h, -__builtin_fmaf(lq[g], y, lp[g]));
+                }
+                x[j] = v * live;
+            }
+            u32x4 h, m, l;
+            split8(x, h, m, l);
+            u32x4 *dst = Limg + (((2 * g + (lane >> 5)) * 2 + ks) * 3) * 64 + (lane & 31) + 32 * hh;
+            dst[0] = h;
+            dst[64] = m;
+            dst[128] = l;
+        }
+#pragma unroll
+        for (int g = 0; g < T2; ++g) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float live = (mb + 16 * ks + 8 * hh + j < m1) ? rmask[g] : 0.f;
+                float v = rv[g][j];
+                if (p.rpro == PRO_BNACT) {
+                    const float u = __builtin_fmaf(v, ralp[g], rdel[g]);
+                    v = u > 0.f ? u : u * p.slope;
+                }
+                x[j] = v * live;
+            }
+            u32x4 h, m, l;
+            split8(x, h, m, l);
+            u32x4 *dst = Rimg + (((2 * g + (lane >> 5)) * 2 + ks) * 3) * 64 + (lane & 31) + 32 * hh;
+            dst[0] = h;
+            dst[64] = m;
+            dst[128] = l;
+        }
+        __syncthreads();
+        if (mb + 32 < m1) fetch(mb + 32);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            u32x4 af[T1][3], bf[T2][3];
+#pragma unroll
+            for (int i = 0; i < T1; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) af[i][q] = Limg[(((w1 * T1 + i) * 2 + k2) * 3 + q) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < T2; ++j)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) bf[j][q] = Rimg[(((w2 * T2 + j) * 2 + k2) * 3 + q) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < T1; ++i)
+#pragma unroll
+                for (int j = 0; j < T2; ++j) {
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, af[i][0]), am = __builtin_bit_cast(bf16x8, af[i][1]),
+                                 al = __builtin_bit_cast(bf16x8, af[i][2]);
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, bf[j][0]), bm = __builtin_bit_cast(bf16x8, bf[j][1]),
+                                 bl = __builtin_bit_cast(bf16x8, bf[j][2]);
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        }
+    }
+    float *out = p.part + (long)s * N1 * p.N2;
+    const int half = lane >> 5, lc = lane & 31;
+#pragma unroll
+    for (int i = 0; i < T1; ++i)
+#pragma unroll
+        for (int j = 0; j < T2; ++j) {
+            const int col = c2_0 + (w2 * T2 + j) * 32 + lc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = c1_0 + (w1 * T1 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (row < N1 && col < p.N2) out[(long)row * p.N2 + col] = acc[i][j][e];
+            }
+        }
+}
+
+// out rows [0, N1a) -> C1 (row stride ldc1), rows [N1a, N1) -> C2 (row stride ldc2): sum of the S slices in slice order
+__global__ __launch_bounds__(256) void pw_tn_reduce_kernel(const float *__restrict__ part, int S, int N1, int N2, int N1a,
+                                                           float *__restrict__ C1, long ldc1, float *__restrict__ C2, long ldc2) {
+    const long total = (long)N1 * N2;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int q = 0;
+        for (; q + 4 <= S; q += 4) {       // four loads in flight; fixed association ((s0+s4+..) + (s1+..)) + ...
+            a0 += part[(long)q * total + t];
+            a1 += part[(long)(q + 1) * total + t];
+            a2 += part[(long)(q + 2) * total + t];
+            a3 += part[(long)(q + 3) * total + t];
+        }
+        for (; q < S; ++q) a0 += part[(long)q * total + t];
+        const float v = (a0 + a1) + (a2 + a3);
+        const int r = (int)(t / N2), c = (int)(t - (long)r * N2);
+        if (r < N1a) C1[(long)r * ldc1 + c] = v;
+        else C2[(long)(r - N1a) * ldc2 + c] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Train-mode BatchNorm statistics from the (n, mean, M2) records of the row-GEMM epilogue (Chan's merge in fp64), with an
+// optional per-cloud shift added to every record's mean (the first head layer: y = y0 + c[cloud], models/dgcnn.py:159-160),
+// the running-statistics update of torch (unbiased variance) and the prologue tables of the consumer:
+//   alpha[c] = gamma r,  delta[b][c] = alpha (shift[b][c] - mean) + beta,  emu[b][c] = mean - shift[b][c]
+// 16 channels per workgroup, 16 record slices per channel (loads of a slice in flight together), LDS merge.
+constexpr int FS = 16;
+__global__ __launch_bounds__(256) void pw_bn_finalize_kernel(const float *__restrict__ rec, int R, int ldn, int c0, int C,
+                                                             const float *__restrict__ shift, int B, int training,
+                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                             float eps, float momentum, float *__restrict__ running_mean,
+                                                             float *__restrict__ running_var, float *__restrict__ mean_out,
+                                                             float *__restrict__ invstd_out, float *__restrict__ alpha,
+                                                             float *__restrict__ delta, float *__restrict__ emu,
+                                                             float *__restrict__ cloud_mean) {
+    __shared__ double red[3][FS][16];
+    __shared__ float stat[2][16];
+    const int ch = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + ch;
+    const bool live = c < C;
+    const int rpc = B > 0 ? R / B : R;                  // records per cloud
+    if (training) {
+        double a = 0.0, bm = 0.0, cm = 0.0;
+        if (live) {
+            for (int r = sl; r < R; r += FS) {
+                const float *pr = rec + (long)r * 3 * ldn + c0 + c;
+                const double n = pr[0];
+                double mu = pr[ldn];
+                if (shift) mu += (double)shift[(long)(r / rpc) * C + c];
+                a += n;
+                bm += n * mu;
+                cm += (double)pr[2 * ldn] + n * mu * mu;
+            }
+        }
+        red[0][sl][ch] = a;
+        red[1][sl][ch] = bm;
+        red[2][sl][ch] = cm;
+        __syncthreads();
+        if (sl == 0 && live) {
+            double n = 0.0;
+            bm = 0.0;
+            cm = 0.0;
+#pragma unroll
+            for (int q = 0; q < FS; ++q) { n += red[0][q][ch]; bm += red[1][q][ch]; cm += red[2][q][ch]; }
+            const double mu = n > 0.0 ? bm / n : 0.0;
+            double M2 = n > 0.0 ? cm - bm * mu : 0.0;
+            M2 = M2 > 0.0 ? M2 : 0.0;
+            const double var = n > 0.0 ? M2 / n : 0.0;
+            const float muf = (float)mu, rf = (float)(1.0 / sqrt(var + (double)eps));
+            mean_out[c] = muf;
+            invstd_out[c] = rf;
+            stat[0][ch] = muf;
+            stat[1][ch] = rf;
+            if (running_mean) {
+                const double unbiased = n > 1.0 ? M2 / (n - 1.0) : var;
+                running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+                running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+            }
+        }
+    } else if (sl == 0 && live) {                        // eval: running statistics (the caller passes them as mean / invstd)
+        stat[0][ch] = mean_out[c];
+        stat[1][ch] = invstd_out[c];
+    }
+    __syncthreads();
+    if (!live) return;
+    const float mu = stat[0][ch], r = stat[1][ch];
+    const float al = gamma[c] * r;
+    if (sl == 0) alpha[c] = al;
+    const int nb = shift ? B : 1;
+    for (int b = sl; b < nb; b += FS) {
+        const float sh = shift ? shift[(long)b * C + c] : 0.f;
+        delta[(long)b * C + c] = __builtin_fmaf(al, sh - mu, beta[c]);
+        if (emu) emu[(long)b * C + c] = mu - sh;
+    }
+    if (cloud_mean && training) {                        // unshifted per-cloud mean of the records (first head layer's backward)
+        for (int b = sl; b < B; b += FS) {
+            double n = 0.0, sm = 0.0;
+            for (int q = 0; q < rpc; ++q) {
+                const float *pr = rec + (long)(b * rpc + q) * 3 * ldn + c0 + c;
+                n += pr[0];
+                sm += (double)pr[0] * pr[ldn];
+            }
+            cloud_mean[(long)b * C + c] = (float)(n > 0.0 ? sm / n : 0.0);
+        }
+    }
+}
+
+// sel records of the row-GEMM epilogue -> global max-pool through the monotone BatchNorm + LeakyReLU (models/dgcnn.py:
+// 134-137,156): per (cloud, channel) the best of the cloud's row blocks (lowest row on ties); ysel = sgn * best,
+// out = lrelu(alpha ysel + delta)
+__global__ __launch_bounds__(256) void pw_max_finish_kernel(const float *__restrict__ sel_val, const int *__restrict__ sel_arg,
+                                                            const float *__restrict__ sgn, const float *__restrict__ alpha,
+                                                            const float *__restrict__ delta, int tiles, int C, float slope,
+                                                            float *__restrict__ out, float *__restrict__ ysel,
+                                                            int *__restrict__ arg) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float bv = -INFINITY;
+    int ba = 0;
+    for (int t = 0; t < tiles; ++t) {
+        const float v = sel_val[((long)b * tiles + t) * C + c];
+        const int a = sel_arg[((long)b * tiles + t) * C + c];
+        if (v > bv || (v == bv && a < ba)) { bv = v; ba = a; }
+    }
+    const float yv = sgn[c] * bv;
+    ysel[(long)b * C + c] = yv;
+    arg[(long)b * C + c] = ba;
+    const float u = __builtin_fmaf(yv, alpha[c], delta[c]);
+    out[(long)b * C + c] = u > 0.f ? u : u * slope;
+}
+
+// BatchNorm backward sums from the (sum h, sum h yhat) records -> dbeta, dgamma and the prologue tables of the products
+// that consume dy = alpha h - P - Q y:   Q = alpha r dgamma / M,   P[b] = alpha (dbeta / M - emu[b] r dgamma / M)
+// and, for the first head layer, the per-cloud column sums of dy (the gradient of the per-cloud constant c):
+//   dc[b] = alpha sum_{m in b} h - n_b P[b] - Q n_b cloud_mean[b]
+__global__ __launch_bounds__(256) void pw_bnbwd_finalize_kernel(const float *__restrict__ rec2, int R, int C, int B, long M,
+                                                                int training, const float *__restrict__ alpha,
+                                                                const float *__restrict__ invstd, const float *__restrict__ emu,
+                                                                int emu_per_cloud, const float *__restrict__ cloud_mean,
+                                                                float *__restrict__ dbeta, float *__restrict__ dgamma,
+                                                                float *__restrict__ P, float *__restrict__ Q,
+                                                                float *__restrict__ dc) {
+    __shared__ double red[2][FS][16];
+    __shared__ float tot[2][16];
+    const int ch = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + ch;
+    const bool live = c < C;
+    double sb = 0.0, sg = 0.0;
+    if (live)
+        for (int r = sl; r < R; r += FS) {
+            sb += (double)rec2[(long)r * 2 * C + c];
+            sg += (double)rec2[(long)r * 2 * C + C + c];
+        }
+    red[0][sl][ch] = sb;
+    red[1][sl][ch] = sg;
+    __syncthreads();
+    if (sl == 0 && live) {
+        sb = sg = 0.0;
+#pragma unroll
+        for (int q = 0; q < FS; ++q) { sb += red[0][q][ch]; sg += red[1][q][ch]; }
+        dbeta[c] = (float)sb;
+        dgamma[c] = (float)sg;
+        tot[0][ch] = (float)sb;
+        tot[1][ch] = (float)sg;
+    }
+    __syncthreads();
+    if (!live) return;
+    const float invM = 1.0f / (float)M;
+    const float al = alpha[c], r = invstd[c];
+    const float db = training ? tot[0][ch] * invM : 0.f, dg = training ? tot[1][ch] * invM * r : 0.f;
+    const float q = al * dg;
+    if (sl == 0) Q[c] = q;
+    const int nb = emu_per_cloud ? B : 1;
+    const int rpc = B > 0 ? R / B : R;
+    for (int b = sl; b < nb; b += FS) {
+        const float pb = al * (db - emu[(long)b * C + c] * dg);
+        P[(long)b * C + c] = pb;
+        if (dc) {
+            double sh = 0.0;
+            for (int t = 0; t < rpc; ++t) sh += (double)rec2[(long)(b * rpc + t) * 2 * C + c];
+            const float nbf = (float)(M / B);
+            dc[(long)b * C + c] = al * (float)sh - nbf * pb - q * nbf * cloud_mean[(long)b * C + c];
+        }
+    }
+}
+
+// last layer, backward (models/dgcnn.py:146: Conv1d(128, classes) with bias, no BatchNorm behind it):
+//   da[m, k] = sum_j g[m, j] W3[j, k]  (classes <= 8), stored, and the BatchNorm backward sums of the layer in front:
+//   h = da f'(alpha y + delta), records (sum h, sum h yhat) per 128-row block.  lane = channel pair, 4 waves x 32 rows.
+__global__ __launch_bounds__(256) void pw_logits_bwd_kernel(const float *__restrict__ g, int cls, const float *__restrict__ W3,
+                                                            const float *__restrict__ y, const float *__restrict__ alpha,
+                                                            const float *__restrict__ delta, const float *__restrict__ mean,
+                                                            const float *__restrict__ invstd, long M, int C, float slope,
+                                                            float *__restrict__ da, float *__restrict__ rec2) {
+    __shared__ float red[2][4][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long r0 = (long)blockIdx.x * 128;
+    for (int cb = 0; cb < C; cb += 64) {
+        const int c = cb + lane;
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = j < cls ? W3[(long)j * C + c] : 0.f;
+        const float al = alpha[c], de = delta[c], mu = mean[c], rr = invstd[c];
+        float sb = 0.f, sg = 0.f;
+        for (int i = wave; i < 128; i += 4) {
+            const long row = r0 + i;
+            if (row >= M) break;
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < cls) a = __builtin_fmaf(g[row * cls + j], w[j], a);
+            da[row * C + c] = a;
+            const float yv = y[row * C + c], u = __builtin_fmaf(yv, al, de);
+            const float h = a * (u > 0.f ? 1.f : slope);
+            sb += h;
+            sg = __builtin_fmaf(h, (yv - mu) * rr, sg);
+        }
+        red[0][wave][lane] = sb;
+        red[1][wave][lane] = sg;
+        __syncthreads();
+        if (wave == 0) {
+            float *pr = rec2 + (long)blockIdx.x * 2 * C;
+            pr[c] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+            pr[C + c] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+        }
+        __syncthreads();
+    }
+}
+
+// global-feature backward, per channel (the Gram form of DESIGN.md): with h[b] = dg[b] f'(alpha ysel[b] + delta),
+//   dbeta = sum_b h,  dgamma = sum_b h yhat_sel,  Q = alpha r dgamma / M,  P = alpha (dbeta / M - mean r dgamma / M),
+//   coef[b] = alpha h[b]   (weight of the selected row arg[b] in dy)
+__global__ __launch_bounds__(256) void pw_gf_prep_kernel(const float *__restrict__ dg, const float *__restrict__ ysel,
+                                                         const float *__restrict__ alpha, const float *__restrict__ delta,
+                                                         const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                         int B, int C, long M, int training, float slope,
+                                                         float *__restrict__ dbeta, float *__restrict__ dgamma,
+                                                         float *__restrict__ P, float *__restrict__ Q, float *__restrict__ coef) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float al = alpha[c], de = delta[c], mu = mean[c], r = invstd[c];
+    float sb = 0.f, sg = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float ys = ysel[(long)b * C + c], u = __builtin_fmaf(ys, al, de);
+        const float h = dg[(long)b * C + c] * (u > 0.f ? 1.f : slope);
+        coef[(long)b * C + c] = al * h;
+        sb += h;
+        sg = __builtin_fmaf(h, (ys - mu) * r, sg);
+    }
+    dbeta[c] = sb;
+    dgamma[c] = sg;
+    const float invM = 1.0f / (float)M;
+    const float db = training ? sb * invM : 0.f, dgm = training ? sg * invM * r : 0.f;
+    Q[c] = al * dgm;
+    P[c] = al * (db - mu * dgm);
+}
+
+// dX rows of the selected points: for every cloud, dX[b N + arg[b,c], :] += coef[b,c] W[c, :], summed per destination row in
+// channel order (no atomics): one workgroup per cloud sorts its C (arg, c) pairs by counting, one wave per destination row.
+__global__ __launch_bounds__(256) void pw_scatter_rows_kernel(const float *__restrict__ coef, const int *__restrict__ arg,
+                                                              const float *__restrict__ W, long ldw, int C, int K, int Npts,
+                                                              float *__restrict__ dX, long ldx) {
+    extern __shared__ int sh[];
+    int *cnt = sh;             // [Npts + 1] -> start offsets
+    int *order = sh + Npts + 1;   // [C] channels grouped by destination row, ascending channel inside a row
+    int *args = order + C;        // [C] this cloud's selected rows
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i <= Npts; i += 256) cnt[i] = 0;
+    for (int c = tid; c < C; c += 256) args[c] = arg[(long)b * C + c];
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) atomicAdd(&cnt[args[c] + 1], 1);
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i <= Npts; ++i) { run += cnt[i]; cnt[i] = run; }
+    }
+    __syncthreads();
+    // stable placement: channel c goes behind the channels c' < c of the same row (rank by counting, C <= a few thousand)
+    for (int c = tid; c < C; c += 256) {
+        const int a = args[c];
+        int rank = 0;
+        for (int c2 = 0; c2 < c; ++c2) rank += (args[c2] == a) ? 1 : 0;
+        order[cnt[a] + rank] = c;
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int row = wave; row < Npts; row += 4) {
+        const int e0 = cnt[row], e1 = cnt[row + 1];
+        if (e0 == e1) continue;
+        for (int k0 = 0; k0 < K; k0 += 64) {
+            const int k = k0 + lane;
+            if (k >= K) break;
+            float a = dX[((long)b * Npts + row) * ldx + k];
+            for (int e = e0; e < e1; ++e) {
+                const int c = order[e];
+                a = __builtin_fmaf(coef[(long)b * C + c], W[(long)c * ldw + k], a);
+            }
+            dX[((long)b * Npts + row) * ldx + k] = a;
+        }
+    }
+}
+
+// dW of the global-feature layer, Gram form:  dW[c, :] = sum_b coef[b,c] X[b N + arg[b,c], :] - P[c] s - Q[c] (W G)[c, :]
+__global__ __launch_bounds__(256) void pw_gf_dw_kernel(const float *__restrict__ coef, const int *__restrict__ arg,
+                                                       const float *__restrict__ X, long ldx, const float *__restrict__ s,
+                                                       const float *__restrict__ WG, const float *__restrict__ P,
+                                                       const float *__restrict__ Q, int B, int C, int K, int Npts,
+                                                       float *__restrict__ dW, long lddw) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)C * K) return;
+    const int c = (int)(t / K), k = (int)(t - (long)c * K);
+    float a = -__builtin_fmaf(Q[c], WG[(long)c * K + k], P[c] * s[k]);
+    for (int b = 0; b < B; ++b)
+        a = __builtin_fmaf(coef[(long)b * C + c], X[((long)b * Npts + arg[(long)b * C + c]) * ldx + k], a);
+    dW[(long)c * lddw + k] = a;
+}
+
+// column sums of (M, K) rows: partial sums per 128-row block, then a fixed-order sum
+__global__ __launch_bounds__(256) void pw_colsum_part_kernel(const float *__restrict__ X, long ldx, long M, int K,
+                                                             float *__restrict__ part) {
+    __shared__ float red[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long r0 = (long)blockIdx.x * 128;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        const int k = k0 + lane;
+        float a = 0.f;
+        if (k < K)
+            for (int i = wave; i < 128 && r0 + i < M; i += 4) a += X[(r0 + i) * ldx + k];
+        red[wave][lane] = a;
+        __syncthreads();
+        if (wave == 0 && k < K) part[(long)blockIdx.x * K + k] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void pw_colsum_fold_kernel(const float *__restrict__ part, int R, int K, float *__restrict__ out) {
+    __shared__ double red[16][16];
+    const int ch = threadIdx.x & 15, sl = threadIdx.x >> 4, k = blockIdx.x * 16 + ch;
+    double a = 0.0;
+    if (k < K)
+        for (int r = sl; r < R; r += 16) a += (double)part[(long)r * K + k];
+    red[sl][ch] = a;
+    __syncthreads();
+    if (sl == 0 && k < K) {
+        a = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a += red[q][ch];
+        out[k] = (float)a;
+    }
+}
+
+template <int T1, int T2>
+int launch_tn(const TnArgs &a, int S, hipStream_t st) {
+    const int N1 = a.N1a + a.N1b;
+    const dim3 grid(((N1 + 64 * T1 - 1) / (64 * T1)) * ((a.N2 + 64 * T2 - 1) / (64 * T2)), S);
+    hipLaunchKernelGGL((pw_tn_kernel<T1, T2>), grid, dim3(256), 0, st, a);
+    FSG_CHECK_LAUNCH("fsg_pw_tn_f32");
+    return FSG_OK;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------- C ABI
@@ -446,4 +990,222 @@ extern "C" int fsg_pw_linear_f32(const float *A, int64_t lda, const void *image,
     if (tile == 2) return launch_rowgemm<1, 2, PRO_NONE, PW_STORE>(a, st, "fsg_pw_linear_f32");
     if (tile == 4) return launch_rowgemm<2, 1, PRO_NONE, PW_STORE>(a, st, "fsg_pw_linear_f32");
     return launch_rowgemm<1, 1, PRO_NONE, PW_STORE>(a, st, "fsg_pw_linear_f32");
+}
+
+// ---- generic members of the family behind the fused DGCNN head (functional.py composes them; include/fsg_hip.h documents
+//      every argument).  Tile codes: 1 = 128 x 128, 2 = 64 x 128, 3 = 64 x 64, 4 = 128 x 64 (rows x columns of C).
+extern "C" int fsg_pw_tile_rows(int tile) { return (tile == 1 || tile == 4) ? 128 : 64; }
+
+static int check_rowgemm(const fsg_pw_rowgemm_args *a, int pro, int epi, int BM) {
+    FSG_REQUIRE(a && a->A1 && a->Bimg, "fsg_pw_rowgemm_f32: NULL pointer");
+    FSG_REQUIRE(a->M > 0 && a->N > 0 && a->K1 > 0 && a->K1 % 32 == 0 && a->K2 >= 0 && a->K2 % 32 == 0 && a->lda1 % 4 == 0 &&
+                    ((uintptr_t)a->A1 & 15) == 0,
+                "fsg_pw_rowgemm_f32: bad shape M=%d N=%d K1=%d K2=%d lda1=%ld", a->M, a->N, a->K1, a->K2, (long)a->lda1);
+    FSG_REQUIRE(a->K2 == 0 || (a->A2 && a->lda2 % 4 == 0 && ((uintptr_t)a->A2 & 15) == 0), "fsg_pw_rowgemm_f32: bad segment 2");
+    FSG_REQUIRE(pro == PRO_NONE || (a->alpha && a->delta), "fsg_pw_rowgemm_f32: prologue tables missing");
+    FSG_REQUIRE(pro != PRO_BNBWD || (a->Y1 && a->P && a->Q && ((uintptr_t)a->Y1 & 15) == 0), "fsg_pw_rowgemm_f32: BNBWD needs Y1, P, Q");
+    FSG_REQUIRE(!(epi & PW_STORE) || a->C, "fsg_pw_rowgemm_f32: STORE needs C");
+    FSG_REQUIRE(!(epi & PW_BIAS) || a->bias, "fsg_pw_rowgemm_f32: BIAS needs bias");
+    if (epi & (PW_STATS | PW_SEL | PW_BWDSTATS)) {
+        FSG_REQUIRE(a->M % BM == 0 && (a->rows_per_cloud == 0 || a->rows_per_cloud % BM == 0),
+                    "fsg_pw_rowgemm_f32: reducing epilogues need M (%d) and rows_per_cloud (%d) to be multiples of the tile rows %d",
+                    a->M, a->rows_per_cloud, BM);
+        FSG_REQUIRE(!(epi & PW_STATS) || a->rec, "fsg_pw_rowgemm_f32: STATS needs rec");
+        FSG_REQUIRE(!(epi & PW_SEL) || (a->sgn && a->sel_val && a->sel_arg && a->sel_n > 0 && a->rows_per_cloud > 0),
+                    "fsg_pw_rowgemm_f32: SEL needs sgn, sel_val, sel_arg, sel_n, rows_per_cloud");
+        FSG_REQUIRE(!(epi & PW_BWDSTATS) || (a->Yp && a->ealpha && a->edelta && a->emu && a->er && a->rec2),
+                    "fsg_pw_rowgemm_f32: BWDSTATS needs Yp, its tables and rec2");
+    }
+    if ((pro != PRO_NONE && a->tstride != 0) || ((epi & PW_BWDSTATS) && a->etstride != 0))
+        FSG_REQUIRE(a->rows_per_cloud > 0 && a->rows_per_cloud % BM == 0, "fsg_pw_rowgemm_f32: per-cloud tables need rows_per_cloud %% %d == 0", BM);
+    return FSG_OK;
+}
+
+static RowGemmArgs to_kernel_args(const fsg_pw_rowgemm_args *a) {
+    RowGemmArgs k{};
+    k.A1 = a->A1; k.Y1 = a->Y1; k.A2 = a->A2; k.lda1 = a->lda1; k.lda2 = a->lda2; k.K1 = a->K1; k.K2 = a->K2;
+    k.Bimg = reinterpret_cast<const u32x4 *>(a->Bimg);
+    k.M = a->M; k.N = a->N; k.rows_per_cloud = a->rows_per_cloud;
+    k.alpha = a->alpha; k.delta = a->delta; k.P = a->P; k.Q = a->Q; k.tstride = a->tstride; k.slope = a->slope;
+    k.C = a->C; k.ldc = a->ldc; k.store_n0 = a->store_n0; k.bias = a->bias; k.rec = a->rec;
+    k.sgn = a->sgn; k.sel_val = a->sel_val; k.sel_arg = a->sel_arg; k.sel_n = a->sel_n;
+    k.Yp = a->Yp; k.ldyp = a->ldyp; k.ealpha = a->ealpha; k.edelta = a->edelta; k.emu = a->emu; k.er = a->er;
+    k.etstride = a->etstride; k.rec2 = a->rec2;
+    return k;
+}
+
+extern "C" int fsg_pw_rowgemm_f32(const fsg_pw_rowgemm_args *a, int pro, int epi, int tile, fsg_stream_t stream) {
+    FSG_REQUIRE(tile >= 1 && tile <= 4, "fsg_pw_rowgemm_f32: tile %d not in 1..4", tile);
+    const int rc = check_rowgemm(a, pro, epi, fsg_pw_tile_rows(tile));
+    if (rc != FSG_OK) return rc;
+    const RowGemmArgs k = to_kernel_args(a);
+    hipStream_t st = (hipStream_t)stream;
+    const int key = pro * 1000 + epi * 10 + tile;
+#define PW_CASE(PRO, EPI, TILE, WMv, WNv) \
+    case (PRO) * 1000 + (EPI) * 10 + (TILE): return launch_rowgemm<WMv, WNv, PRO, EPI>(k, st, "fsg_pw_rowgemm_f32")
+    switch (key) {
+        PW_CASE(PRO_NONE, PW_STORE, 1, 2, 2);
+        PW_CASE(PRO_NONE, PW_STORE, 2, 1, 2);
+        PW_CASE(PRO_NONE, PW_STORE, 3, 1, 1);
+        PW_CASE(PRO_NONE, PW_STORE, 4, 2, 1);
+        PW_CASE(PRO_NONE, PW_STORE | PW_BIAS, 1, 2, 2);
+        PW_CASE(PRO_NONE, PW_STORE | PW_BIAS, 2, 1, 2);
+        PW_CASE(PRO_NONE, PW_STORE | PW_BIAS, 3, 1, 1);
+        PW_CASE(PRO_NONE, PW_STORE | PW_BIAS, 4, 2, 1);
+        PW_CASE(PRO_NONE, PW_STORE | PW_STATS, 1, 2, 2);
+        PW_CASE(PRO_NONE, PW_STORE | PW_STATS, 2, 1, 2);
+        PW_CASE(PRO_NONE, PW_STORE | PW_STATS | PW_SEL, 1, 2, 2);
+        PW_CASE(PRO_NONE, PW_STORE | PW_STATS | PW_SEL, 2, 1, 2);
+        PW_CASE(PRO_BNACT, PW_STORE | PW_STATS, 1, 2, 2);
+        PW_CASE(PRO_BNACT, PW_STORE | PW_STATS, 2, 1, 2);
+        PW_CASE(PRO_BNACT, PW_STORE | PW_STATS, 3, 1, 1);
+        PW_CASE(PRO_BNACT, PW_STORE | PW_BIAS, 3, 1, 1);
+        PW_CASE(PRO_BNACT, PW_STORE, 3, 1, 1);
+        PW_CASE(PRO_BNBWD, PW_STORE | PW_BWDSTATS, 1, 2, 2);
+        PW_CASE(PRO_BNBWD, PW_STORE | PW_BWDSTATS, 2, 1, 2);
+        PW_CASE(PRO_BNBWD, PW_STORE | PW_BWDSTATS, 3, 1, 1);
+        PW_CASE(PRO_BNBWD, PW_STORE | PW_BIAS, 1, 2, 2);
+        PW_CASE(PRO_BNBWD, PW_STORE | PW_BIAS, 3, 1, 1);
+        PW_CASE(PRO_BNBWD, PW_STORE | PW_BIAS, 4, 2, 1);
+        PW_CASE(PRO_BNBWD, PW_STORE, 3, 1, 1);
+        default: break;
+    }
+#undef PW_CASE
+    fsg_set_error("fsg_pw_rowgemm_f32: combination prologue %d / epilogue %d / tile %d is not instantiated", pro, epi, tile);
+    return FSG_ERR_UNSUPPORTED;
+}
+
+extern "C" size_t fsg_pw_tn_workspace_bytes(int N1, int N2, int M, int rows_per_slice) {
+    if (rows_per_slice <= 0) return 0;
+    return sizeof(float) * (size_t)((M + rows_per_slice - 1) / rows_per_slice) * N1 * N2;
+}
+
+extern "C" int fsg_pw_tn_f32(const fsg_pw_tn_args *a, int tile, void *workspace, size_t workspace_bytes, float *C1,
+                             int64_t ldc1, float *C2, int64_t ldc2, fsg_stream_t stream) {
+    FSG_REQUIRE(a && a->L1 && a->R && workspace && C1, "fsg_pw_tn_f32: NULL pointer");
+    const int N1 = a->N1a + a->N1b;
+    FSG_REQUIRE(a->M > 0 && a->N1a > 0 && a->N1b >= 0 && a->N2 > 0 && a->rows_per_slice > 0 && a->rows_per_slice % 32 == 0,
+                "fsg_pw_tn_f32: bad shape M=%d N1=%d+%d N2=%d rows_per_slice=%d", a->M, a->N1a, a->N1b, a->N2, a->rows_per_slice);
+    FSG_REQUIRE(a->N1b == 0 || (a->N1a % 64 == 0 && a->L2 && C2), "fsg_pw_tn_f32: two left segments need N1a %% 64 == 0, L2 and C2");
+    FSG_REQUIRE(a->lpro == PRO_NONE || (a->lpro == PRO_BNBWD && a->LY1 && a->lalpha && a->ldelta && a->lP && a->lQ),
+                "fsg_pw_tn_f32: left prologue %d needs LY1 and its tables", a->lpro);
+    FSG_REQUIRE(a->rpro == PRO_NONE || (a->rpro == PRO_BNACT && a->ralpha && a->rdelta), "fsg_pw_tn_f32: right prologue %d", a->rpro);
+    const bool per_cloud = (a->lpro != PRO_NONE && a->lts != 0) || (a->rpro != PRO_NONE && a->rts != 0);
+    FSG_REQUIRE(!per_cloud || (a->rows_per_cloud > 0 && a->rows_per_cloud % a->rows_per_slice == 0),
+                "fsg_pw_tn_f32: per-cloud tables need rows_per_cloud %% rows_per_slice == 0");
+    const int S = (a->M + a->rows_per_slice - 1) / a->rows_per_slice;
+    FSG_REQUIRE(workspace_bytes >= fsg_pw_tn_workspace_bytes(N1, a->N2, a->M, a->rows_per_slice), "fsg_pw_tn_f32: workspace too small");
+    TnArgs k{};
+    k.L1 = a->L1; k.LY1 = a->LY1; k.L2 = a->L2; k.ldl1 = a->ldl1; k.ldl2 = a->ldl2; k.N1a = a->N1a; k.N1b = a->N1b; k.lpro = a->lpro;
+    k.lalpha = a->lalpha; k.ldelta = a->ldelta; k.lP = a->lP; k.lQ = a->lQ; k.lts = a->lts;
+    k.R = a->R; k.ldr = a->ldr; k.N2 = a->N2; k.rpro = a->rpro; k.ralpha = a->ralpha; k.rdelta = a->rdelta; k.rts = a->rts;
+    k.slope = a->slope; k.M = a->M; k.rows_per_cloud = a->rows_per_cloud; k.rows_per_slice = a->rows_per_slice;
+    k.part = reinterpret_cast<float *>(workspace);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    // tile: 1 = 128 x 128, 2 = 64 x 128, 3 = 64 x 64, 5 = 128 x 192
+    if (tile == 1) rc = launch_tn<2, 2>(k, S, st);
+    else if (tile == 2) rc = launch_tn<1, 2>(k, S, st);
+    else if (tile == 3) rc = launch_tn<1, 1>(k, S, st);
+    else if (tile == 5) rc = launch_tn<2, 3>(k, S, st);
+    else { fsg_set_error("fsg_pw_tn_f32: tile %d", tile); return FSG_ERR_ARG; }
+    if (rc != FSG_OK) return rc;
+    const long total = (long)N1 * a->N2;
+    hipLaunchKernelGGL(pw_tn_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, k.part, S, N1, a->N2, a->N1a,
+                       C1, (long)ldc1, C2, (long)ldc2);
+    FSG_CHECK_LAUNCH("fsg_pw_tn_f32/reduce");
+    return FSG_OK;
+}
+
+extern "C" int fsg_pw_bn_finalize_f32(const float *rec, int R, int ldn, int c0, int C, const float *shift, int B, int training,
+                                      const float *gamma, const float *beta, float eps, float momentum, float *running_mean,
+                                      float *running_var, float *mean, float *invstd, float *alpha, float *delta, float *emu,
+                                      float *cloud_mean, fsg_stream_t stream) {
+    FSG_REQUIRE(gamma && beta && mean && invstd && alpha && delta, "fsg_pw_bn_finalize_f32: NULL pointer");
+    FSG_REQUIRE(C > 0 && (!training || (rec && R > 0 && ldn >= c0 + C)) && (!shift || (B > 0 && R % B == 0)) &&
+                    (!cloud_mean || (B > 0 && R % B == 0)),
+                "fsg_pw_bn_finalize_f32: bad shape R=%d ldn=%d c0=%d C=%d B=%d", R, ldn, c0, C, B);
+    hipLaunchKernelGGL(pw_bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, rec, R, ldn, c0, C, shift, B,
+                       training, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, alpha, delta, emu, cloud_mean);
+    FSG_CHECK_LAUNCH("fsg_pw_bn_finalize_f32");
+    return FSG_OK;
+}
+
+extern "C" int fsg_pw_max_finish_f32(const float *sel_val, const int32_t *sel_arg, const float *sgn, const float *alpha,
+                                     const float *delta, int B, int tiles, int C, float slope, float *out, float *ysel,
+                                     int32_t *arg, fsg_stream_t stream) {
+    FSG_REQUIRE(sel_val && sel_arg && sgn && alpha && delta && out && ysel && arg && B > 0 && tiles > 0 && C > 0,
+                "fsg_pw_max_finish_f32: bad arguments");
+    hipLaunchKernelGGL(pw_max_finish_kernel, dim3((C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, sel_val, sel_arg, sgn,
+                       alpha, delta, tiles, C, slope, out, ysel, arg);
+    FSG_CHECK_LAUNCH("fsg_pw_max_finish_f32");
+    return FSG_OK;
+}
+
+extern "C" int fsg_pw_bnbwd_finalize_f32(const float *rec2, int R, int C, int B, int64_t M, int training, const float *alpha,
+                                         const float *invstd, const float *emu, int emu_per_cloud, const float *cloud_mean,
+                                         float *dbeta, float *dgamma, float *P, float *Q, float *dc, fsg_stream_t stream) {
+    FSG_REQUIRE(rec2 && alpha && invstd && emu && dbeta && dgamma && P && Q && R > 0 && C > 0 && M > 0 && B > 0 && R % B == 0 &&
+                    (!dc || (cloud_mean && emu_per_cloud && M % B == 0)),
+                "fsg_pw_bnbwd_finalize_f32: bad arguments");
+    hipLaunchKernelGGL(pw_bnbwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, rec2, R, C, B, (long)M,
+                       training, alpha, invstd, emu, emu_per_cloud, cloud_mean, dbeta, dgamma, P, Q, dc);
+    FSG_CHECK_LAUNCH("fsg_pw_bnbwd_finalize_f32");
+    return FSG_OK;
+}
+
+extern "C" int fsg_pw_logits_bwd_f32(const float *g, int classes, const float *W3, const float *y, const float *alpha,
+                                     const float *delta, const float *mean, const float *invstd, int64_t M, int C, float slope,
+                                     float *da, float *rec2, fsg_stream_t stream) {
+    FSG_REQUIRE(g && W3 && y && alpha && delta && mean && invstd && da && rec2 && M > 0 && C > 0 && C % 64 == 0 && classes >= 1 &&
+                    classes <= 8, "fsg_pw_logits_bwd_f32: bad arguments (C %% 64 == 0, 1 <= classes <= 8)");
+    hipLaunchKernelGGL(pw_logits_bwd_kernel, dim3((unsigned)((M + 127) / 128)), dim3(256), 0, (hipStream_t)stream, g, classes, W3,
+                       y, alpha, delta, mean, invstd, (long)M, C, slope, da, rec2);
+    FSG_CHECK_LAUNCH("fsg_pw_logits_bwd_f32");
+    return FSG_OK;
+}
+
+extern "C" int fsg_pw_gf_prep_f32(const float *dg, const float *ysel, const float *alpha, const float *delta, const float *mean,
+                                  const float *invstd, int B, int C, int64_t M, int training, float slope, float *dbeta,
+                                  float *dgamma, float *P, float *Q, float *coef, fsg_stream_t stream) {
+    FSG_REQUIRE(dg && ysel && alpha && delta && mean && invstd && dbeta && dgamma && P && Q && coef && B > 0 && C > 0 && M > 0,
+                "fsg_pw_gf_prep_f32: bad arguments");
+    hipLaunchKernelGGL(pw_gf_prep_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, dg, ysel, alpha, delta, mean,
+                       invstd, B, C, (long)M, training, slope, dbeta, dgamma, P, Q, coef);
+    FSG_CHECK_LAUNCH("fsg_pw_gf_prep_f32");
+    return FSG_OK;
+}
+
+extern "C" int fsg_pw_scatter_rows_f32(const float *coef, const int32_t *arg, const float *W, int64_t ldw, int B, int C, int K,
+                                       int Npts, float *dX, int64_t ldx, fsg_stream_t stream) {
+    FSG_REQUIRE(coef && arg && W && dX && B > 0 && C > 0 && K > 0 && Npts > 0, "fsg_pw_scatter_rows_f32: bad arguments");
+    const size_t lds = sizeof(int) * ((size_t)Npts + 1 + 2 * (size_t)C);
+    FSG_REQUIRE(lds <= 64 * 1024, "fsg_pw_scatter_rows_f32: Npts + C = %d too large for the LDS sort", Npts + C);
+    hipLaunchKernelGGL(pw_scatter_rows_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, coef, arg, W, (long)ldw, C, K, Npts,
+                       dX, (long)ldx);
+    FSG_CHECK_LAUNCH("fsg_pw_scatter_rows_f32");
+    return FSG_OK;
+}
+
+extern "C" int fsg_pw_gf_dw_f32(const float *coef, const int32_t *arg, const float *X, int64_t ldx, const float *s,
+                                const float *WG, const float *P, const float *Q, int B, int C, int K, int Npts, float *dW,
+                                int64_t lddw, fsg_stream_t stream) {
+    FSG_REQUIRE(coef && arg && X && s && WG && P && Q && dW && B > 0 && C > 0 && K > 0 && Npts > 0, "fsg_pw_gf_dw_f32: bad arguments");
+    const long total = (long)C * K;
+    hipLaunchKernelGGL(pw_gf_dw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, coef, arg, X,
+                       (long)ldx, s, WG, P, Q, B, C, K, Npts, dW, (long)lddw);
+    FSG_CHECK_LAUNCH("fsg_pw_gf_dw_f32");
+    return FSG_OK;
+}
+
+extern "C" size_t fsg_pw_colsum_workspace_bytes(int64_t M, int K) { return sizeof(float) * (size_t)((M + 127) / 128) * K; }
+
+extern "C" int fsg_pw_colsum_f32(const float *X, int64_t ldx, int64_t M, int K, float *out, float *workspace, fsg_stream_t stream) {
+    FSG_REQUIRE(X && out && workspace && M > 0 && K > 0, "fsg_pw_colsum_f32: bad arguments");
+    const int R = (int)((M + 127) / 128);
+    hipLaunchKernelGGL(pw_colsum_part_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, X, (long)ldx, (long)M, K, workspace);
+    FSG_CHECK_LAUNCH("fsg_pw_colsum_f32/part");
+    hipLaunchKernelGGL(pw_colsum_fold_kernel, dim3((K + 15) / 16), dim3(256), 0, (hipStream_t)stream, workspace, R, K, out);
+    FSG_CHECK_LAUNCH("fsg_pw_colsum_f32/fold");
+    return FSG_OK;
 }

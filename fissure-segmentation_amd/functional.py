@@ -921,6 +921,262 @@ def pw_linear(x, image, N, bias=None, tile=0):
         _lib.call("fsg_pw_linear_f32", _p(x), x.stride(0), _p(image), _p(bias), _p(y), N, M, N, K, tile, _stream())
     return y
 
+PW_STORE, PW_STATS, PW_SEL, PW_BWDSTATS, PW_BIAS = 1, 2, 4, 8, 16
+PRO_NONE, PRO_BNACT, PRO_BNBWD = 0, 1, 2
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def pw_rowgemm(pro, epi, tile, **kw):
+    """include/fsg_hip.h: fsg_pw_rowgemm_f32 -- keyword arguments are the fields of fsg_pw_rowgemm_args (tensors or numbers)"""
+    a = _lib.PWRowGemmArgs()
+    keep = []
+    for k, v in kw.items():
+        if torch.is_tensor(v):
+            keep.append(v)
+            v = v.data_ptr()
+        setattr(a, k, v)
+    dev = keep[0].device
+    with torch.cuda.device(dev):
+        _lib.call("fsg_pw_rowgemm_f32", ctypes.byref(a), pro, epi, tile, _stream())
+
+
+def pw_tn(tile, C1, ldc1, C2=None, ldc2=0, **kw):
+    """include/fsg_hip.h: fsg_pw_tn_f32"""
+    a = _lib.PWTnArgs()
+    keep = []
+    for k, v in kw.items():
+        if torch.is_tensor(v):
+            keep.append(v)
+            v = v.data_ptr()
+        setattr(a, k, v)
+    dev = C1.device
+    nbytes = _lib.lib.fsg_pw_tn_workspace_bytes(a.N1a + a.N1b, a.N2, a.M, a.rows_per_slice)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("fsg_pw_tn_f32", ctypes.byref(a), tile, _p(ws), nbytes, _p(C1), ldc1, _p(C2), ldc2, _stream())
+
+
+def _pw_bn_finalize(rec, R, ldn, c0, C, shift, B, bn, training, momentum, with_emu=False, with_cloud_mean=False):
+    """statistics + consumer tables of one BatchNorm of the fused head; returns (mean, invstd, alpha, delta, emu, cloud_mean)"""
+    dev = bn.weight.device
+    nb = B if shift is not None else 1
+    alpha = torch.empty(C, dtype=torch.float32, device=dev)
+    delta = torch.empty(nb, C, dtype=torch.float32, device=dev)
+    emu = torch.empty(nb, C, dtype=torch.float32, device=dev) if with_emu else None
+    cm = torch.empty(B, C, dtype=torch.float32, device=dev) if (with_cloud_mean and training) else None
+    if training:
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        track = bn.track_running_stats and bn.running_mean is not None
+        rm, rv = (bn.running_mean, bn.running_var) if track else (None, None)
+    else:
+        mean = bn.running_mean.detach().float().contiguous()
+        invstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps).contiguous()
+        rm = rv = None
+    with torch.cuda.device(dev):
+        _lib.call("fsg_pw_bn_finalize_f32", _p(rec), R, ldn, c0, C, _p(shift), B, int(training), _p(bn.weight), _p(bn.bias),
+                  float(bn.eps), float(momentum), _p(rm), _p(rv), _p(mean), _p(invstd), _p(alpha), _p(delta), _p(emu), _p(cm),
+                  _stream())
+    return mean, invstd, alpha, delta, emu, cm
+
+
+class _SegHead(torch.autograd.Function):
+    """The whole point-wise head of DGCNNSeg behind the three EdgeConvs (models/dgcnn.py:123-162 of the reference) as ONE
+    autograd node on the fused kernels of csrc/pointwise.hip:
+      levels (M, 192) -> [Wg ; W0_levels] product: BatchNorm statistics + per-cloud max of the 1024 global-feature channels in
+      the epilogue (the (M, 1024) activation never exists), y0 stored -> g (B, 1024) -> c = g W0_global^T per cloud ->
+      BN0 (statistics of y0 + c[cloud] from the per-cloud records) -> layer 1, layer 2 with BatchNorm + LeakyReLU of the
+      producer applied in the prologue and statistics in the epilogue -> class logits.
+    Backward: BatchNorm backward formed in the prologues (dy never stored), its sums in the epilogue of the product that makes
+    the activation gradient, weight gradients by the row-contraction kernel, the global-feature layer in its Gram form."""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, levels, B, Npts, slope, bns, steps, Wg, gg, bg, W0, g0, b0, W1, g1, b1, W2, g2, b2, W3, b3):
+        M, KL = levels.shape
+        dev = levels.device
+        CG, C0, C1, C2, CLS = Wg.shape[0], W0.shape[0], W1.shape[0], W2.shape[0], W3.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        (tr_g, mom_g), (tr_0, mom_0), (tr_1, mom_1), (tr_2, mom_2) = steps
+        bn_g, bn_0, bn_1, bn_2 = bns
+        # weight images (three bf16 pieces in MFMA operand layout)
+        ksl = KL // 16
+        img0 = torch.empty(((CG + C0) // 32) * ksl * 3 * 1024, dtype=torch.uint8, device=dev)
+        pw_weight_image(Wg, out=img0)
+        pw_weight_image(W0[:, :KL], out=img0[(CG // 32) * ksl * 3 * 1024:])
+        img1, img2, img3 = pw_weight_image(W1), pw_weight_image(W2), pw_weight_image(W3)
+        # levels -> global-feature statistics / selection + y0
+        R0 = M // 128
+        rec0 = torch.empty(R0, 3, CG + C0, **f32)
+        sel_val = torch.empty(R0, CG, **f32)
+        sel_arg = torch.empty(R0, CG, dtype=torch.int32, device=dev)
+        y0 = torch.empty(M, C0, **f32)
+        sgn = torch.where(gg >= 0, 1.0, -1.0).to(torch.float32)
+        pw_rowgemm(PRO_NONE, PW_STORE | PW_STATS | PW_SEL, 1, A1=levels, lda1=levels.stride(0), K1=KL, K2=0, Bimg=img0, M=M,
+                   N=CG + C0, rows_per_cloud=Npts, C=y0, ldc=C0, store_n0=CG, rec=rec0, sgn=sgn, sel_val=sel_val,
+                   sel_arg=sel_arg, sel_n=CG)
+        mean_g, inv_g, al_g, de_g, _, _ = _pw_bn_finalize(rec0, R0, CG + C0, 0, CG, None, B, bn_g, tr_g, mom_g)
+        g = torch.empty(B, CG, **f32)
+        ysel = torch.empty(B, CG, **f32)
+        arg = torch.empty(B, CG, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("fsg_pw_max_finish_f32", _p(sel_val), _p(sel_arg), _p(sgn), _p(al_g), _p(de_g), B, Npts // 128, CG,
+                      slope, _p(g), _p(ysel), _p(arg), _stream())
+        c = g @ W0[:, KL:].t()                                              # (B, C0): the global part of the first head layer
+        mean_0, inv_0, al_0, de_0, emu_0, cm_0 = _pw_bn_finalize(rec0, R0, CG + C0, CG, C0, c, B, bn_0, tr_0, mom_0,
+                                                                 with_emu=True, with_cloud_mean=True)
+        # layer 1, layer 2, logits
+        R1 = M // 64
+        y1 = torch.empty(M, C1, **f32)
+        rec1 = torch.empty(R1, 3, C1, **f32)
+        pw_rowgemm(PRO_BNACT, PW_STORE | PW_STATS, 2, A1=y0, lda1=C0, K1=C0, K2=0, Bimg=img1, M=M, N=C1, rows_per_cloud=Npts,
+                   alpha=al_0, delta=de_0, tstride=C0, slope=slope, C=y1, ldc=C1, store_n0=0, rec=rec1)
+        mean_1, inv_1, al_1, de_1, _, _ = _pw_bn_finalize(rec1, R1, C1, 0, C1, None, B, bn_1, tr_1, mom_1)
+        y2 = torch.empty(M, C2, **f32)
+        rec2 = torch.empty(R1, 3, C2, **f32)
+        pw_rowgemm(PRO_BNACT, PW_STORE | PW_STATS, 3, A1=y1, lda1=C1, K1=C1, K2=0, Bimg=img2, M=M, N=C2, rows_per_cloud=Npts,
+                   alpha=al_1, delta=de_1, tstride=0, slope=slope, C=y2, ldc=C2, store_n0=0, rec=rec2)
+        mean_2, inv_2, al_2, de_2, _, _ = _pw_bn_finalize(rec2, R1, C2, 0, C2, None, B, bn_2, tr_2, mom_2)
+        out = torch.empty(M, CLS, **f32)
+        pw_rowgemm(PRO_BNACT, PW_STORE | PW_BIAS, 3, A1=y2, lda1=C2, K1=C2, K2=0, Bimg=img3, M=M, N=CLS, rows_per_cloud=Npts,
+                   alpha=al_2, delta=de_2, tstride=0, slope=slope, C=out, ldc=CLS, store_n0=0, bias=b3)
+        ctx.save_for_backward(levels, y0, y1, y2, Wg, W0, W1, W2, W3, g, ysel, arg, c,
+                              mean_g, inv_g, al_g, de_g, mean_0, inv_0, al_0, de_0, emu_0,
+                              cm_0 if cm_0 is not None else torch.zeros(B, C0, **f32), mean_1, inv_1, al_1, de_1, mean_2, inv_2, al_2, de_2)
+        ctx.meta = (B, Npts, slope, (tr_g, tr_0, tr_1, tr_2))
+        return out
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, gout):
+        (levels, y0, y1, y2, Wg, W0, W1, W2, W3, g, ysel, arg, c, mean_g, inv_g, al_g, de_g, mean_0, inv_0, al_0, de_0, emu_0,
+         cm_0, mean_1, inv_1, al_1, de_1, mean_2, inv_2, al_2, de_2) = ctx.saved_tensors
+        B, Npts, slope, (tr_g, tr_0, tr_1, tr_2) = ctx.meta
+        M, KL = levels.shape
+        dev = levels.device
+        CG, C0, C1, C2, CLS = Wg.shape[0], W0.shape[0], W1.shape[0], W2.shape[0], W3.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        gout = gout if gout.is_contiguous() else gout.contiguous()
+
+        def call(name, *a):
+            with torch.cuda.device(dev):
+                _lib.call(name, *a, _stream())
+        # ---- logits layer
+        db3 = _bias_grad(gout)
+        dW3 = torch.empty(CLS, C2, **f32)
+        pw_tn(3, dW3, C2, L1=gout, ldl1=CLS, N1a=CLS, N1b=0, lpro=PRO_NONE, R=y2, ldr=C2, N2=C2, rpro=PRO_BNACT, ralpha=al_2,
+              rdelta=de_2, rts=0, slope=slope, M=M, rows_per_cloud=Npts, rows_per_slice=128)
+        da2 = torch.empty(M, C2, **f32)
+        Rb = (M + 127) // 128
+        r2b = torch.empty(Rb, 2, C2, **f32)
+        call("fsg_pw_logits_bwd_f32", _p(gout), CLS, _p(W3), _p(y2), _p(al_2), _p(de_2), _p(mean_2), _p(inv_2), M, C2, slope,
+             _p(da2), _p(r2b))
+
+        def bwd_fin(rec, R, C, training, alpha, inv, emu, per_cloud, cm=None, want_dc=False):
+            nb = B if per_cloud else 1
+            dbeta, dgamma = torch.empty(C, **f32), torch.empty(C, **f32)
+            P, Q = torch.empty(nb, C, **f32), torch.empty(C, **f32)
+            dc = torch.empty(B, C, **f32) if want_dc else None
+            call("fsg_pw_bnbwd_finalize_f32", _p(rec), R, C, B, M, int(training), _p(alpha), _p(inv), _p(emu), int(per_cloud),
+                 _p(cm), _p(dbeta), _p(dgamma), _p(P), _p(Q), _p(dc))
+            return dbeta, dgamma, P, Q, dc
+        db2, dg2, P2, Q2, _ = bwd_fin(r2b, Rb, C2, tr_2, al_2, inv_2, mean_2, False)
+        # ---- layer 2
+        dW2 = torch.empty(C2, C1, **f32)
+        pw_tn(2, dW2, C1, L1=da2, LY1=y2, ldl1=C2, N1a=C2, N1b=0, lpro=PRO_BNBWD, lalpha=al_2, ldelta=de_2, lP=P2, lQ=Q2, lts=0,
+              R=y1, ldr=C1, N2=C1, rpro=PRO_BNACT, ralpha=al_1, rdelta=de_1, rts=0, slope=slope, M=M, rows_per_cloud=Npts,
+              rows_per_slice=256)
+        R1 = M // 64
+        da1 = torch.empty(M, C1, **f32)
+        r1b = torch.empty(R1, 2, C1, **f32)
+        pw_rowgemm(PRO_BNBWD, PW_STORE | PW_BWDSTATS, 2, A1=da2, Y1=y2, lda1=C2, K1=C2, K2=0, Bimg=pw_weight_image(W2.t()), M=M,
+                   N=C1, rows_per_cloud=Npts, alpha=al_2, delta=de_2, P=P2, Q=Q2, tstride=0, slope=slope, C=da1, ldc=C1,
+                   store_n0=0, Yp=y1, ldyp=C1, ealpha=al_1, edelta=de_1, emu=mean_1, er=inv_1, etstride=0, rec2=r1b)
+        db1, dg1, P1, Q1, _ = bwd_fin(r1b, R1, C1, tr_1, al_1, inv_1, mean_1, False)
+        # ---- layer 1
+        dW1 = torch.empty(C1, C0, **f32)
+        pw_tn(1, dW1, C0, L1=da1, LY1=y1, ldl1=C1, N1a=C1, N1b=0, lpro=PRO_BNBWD, lalpha=al_1, ldelta=de_1, lP=P1, lQ=Q1, lts=0,
+              R=y0, ldr=C0, N2=C0, rpro=PRO_BNACT, ralpha=al_0, rdelta=de_0, rts=C0, slope=slope, M=M, rows_per_cloud=Npts,
+              rows_per_slice=256)
+        da0 = torch.empty(M, C0, **f32)
+        r0b = torch.empty(R1, 2, C0, **f32)
+        pw_rowgemm(PRO_BNBWD, PW_STORE | PW_BWDSTATS, 2, A1=da1, Y1=y1, lda1=C1, K1=C1, K2=0, Bimg=pw_weight_image(W1.t()), M=M,
+                   N=C0, rows_per_cloud=Npts, alpha=al_1, delta=de_1, P=P1, Q=Q1, tstride=0, slope=slope, C=da0, ldc=C0,
+                   store_n0=0, Yp=y0, ldyp=C0, ealpha=al_0, edelta=de_0, emu=emu_0, er=inv_0, etstride=C0, rec2=r0b)
+        db0, dg0, P0, Q0, dc = bwd_fin(r0b, R1, C0, tr_0, al_0, inv_0, emu_0, True, cm=cm_0, want_dc=True)
+        # ---- first head layer (levels part + per-cloud global part) and the global-feature layer in its Gram form
+        W0G = W0[:, KL:]
+        dg = dc @ W0G                                                       # (B, CG)
+        dW0 = torch.empty(C0, KL + CG, **f32)
+        dW0[:, KL:] = dc.t() @ g
+        dbg, dgg = torch.empty(CG, **f32), torch.empty(CG, **f32)
+        Pg, Qg, coef = torch.empty(CG, **f32), torch.empty(CG, **f32), torch.empty(B, CG, **f32)
+        call("fsg_pw_gf_prep_f32", _p(dg), _p(ysel), _p(al_g), _p(de_g), _p(mean_g), _p(inv_g), B, CG, M, int(tr_g), slope,
+             _p(dbg), _p(dgg), _p(Pg), _p(Qg), _p(coef))
+        M1 = (Wg * Qg.unsqueeze(1)).t() @ Wg                                # (KL, KL) = W^T diag(Q) W
+        npvec = -(Pg @ Wg)                                                  # (KL,)
+        ks_a, ks_b = C0 // 16, KL // 16
+        img_lv = torch.empty((KL // 32) * (ks_a + ks_b) * 3 * 1024, dtype=torch.uint8, device=dev)
+        pw_weight_image(W0[:, :KL].t(), out=img_lv, ks0=0, KS=ks_a + ks_b)
+        pw_weight_image(M1, scale=-1.0, out=img_lv, ks0=ks_a, KS=ks_a + ks_b)
+        G = torch.empty(KL, KL, **f32)
+        pw_tn(5, dW0, KL + CG, G, KL, L1=da0, LY1=y0, L2=levels, ldl1=C0, ldl2=levels.stride(0), N1a=C0, N1b=KL, lpro=PRO_BNBWD,
+              lalpha=al_0, ldelta=de_0, lP=P0, lQ=Q0, lts=C0, R=levels, ldr=levels.stride(0), N2=KL, rpro=PRO_NONE, slope=slope,
+              M=M, rows_per_cloud=Npts, rows_per_slice=256)
+        dlv = torch.empty(M, KL, **f32)
+        pw_rowgemm(PRO_BNBWD, PW_STORE | PW_BIAS, 4, A1=da0, Y1=y0, A2=levels, lda1=C0, lda2=levels.stride(0), K1=C0, K2=KL,
+                   Bimg=img_lv, M=M, N=KL, rows_per_cloud=Npts, alpha=al_0, delta=de_0, P=P0, Q=Q0, tstride=C0, slope=slope,
+                   C=dlv, ldc=KL, store_n0=0, bias=npvec)
+        call("fsg_pw_scatter_rows_f32", _p(coef), _p(arg), _p(Wg), Wg.stride(0), B, CG, KL, Npts, _p(dlv), KL)
+        s = torch.empty(KL, **f32)
+        wsb = _lib.lib.fsg_pw_colsum_workspace_bytes(M, KL)
+        ws = torch.empty(wsb // 4, **f32)
+        call("fsg_pw_colsum_f32", _p(levels), levels.stride(0), M, KL, _p(s), _p(ws))
+        WGm = Wg @ G
+        dWg = torch.empty(CG, KL, **f32)
+        call("fsg_pw_gf_dw_f32", _p(coef), _p(arg), _p(levels), levels.stride(0), _p(s), _p(WGm), _p(Pg), _p(Qg), B, CG, KL, Npts,
+             _p(dWg), KL)
+        return (dlv, None, None, None, None, None, dWg, dgg, dbg, dW0, dg0, db0, dW1, dg1, db1, dW2, dg2, db2, dW3, db3)
+
+
+_fused_head = _os.environ.get("FSG_FUSED_HEAD", "1") != "0"
+
+
+def set_fused_head(flag):
+    """switch the fused point-wise head of DGCNNSeg (csrc/pointwise.hip) on / off; off = vendor GEMMs + fsg_bn_act_* stages
+    (the round-2 path, kept for shapes outside the fused kernels' envelope and as their cross-check); returns the old value"""
+    global _fused_head
+    old, _fused_head = _fused_head, bool(flag)
+    return old
+
+
+def seg_head_supported(levels, B, Npts, Wg, W0, W1, W2, W3):
+    """the fused head needs: fp32 GPU rows, clouds of a multiple of 256 points, channel counts on the 32 / 64 grid"""
+    if not _fused_head or bf16_operands():
+        return False
+    KL = levels.shape[1]
+    return (levels.is_cuda and levels.dtype == torch.float32 and levels.stride(1) == 1 and levels.stride(0) % 4 == 0 and
+            Npts % 256 == 0 and levels.shape[0] == B * Npts and KL % 64 == 0 and Wg.shape[0] % 128 == 0 and
+            W0.shape[0] % 64 == 0 and W0.shape[1] == KL + Wg.shape[0] and W1.shape[0] % 64 == 0 and W1.shape[1] == W0.shape[0] and
+            W2.shape[0] % 64 == 0 and W2.shape[1] == W1.shape[0] and W3.shape[1] == W2.shape[0] and W3.shape[0] <= 8 and
+            W2.shape[0] % 32 == 0 and Npts + Wg.shape[0] <= 16000)
+
+
+def seg_head(levels, B, Npts, global_block, seg_blocks):
+    """DGCNNSeg's head on point-major `levels` (B * Npts, 192): global feature block (conv, BN, LeakyReLU) + the four
+    segmentation blocks -> logits (B * Npts, classes).  See _SegHead."""
+    gconv, gbn, gact = global_block.layers
+    (c0, bn0, _), (c1, bn1, _), (c2, bn2, _) = (blk.layers for blk in seg_blocks[:3])
+    c3 = seg_blocks[3].layers[0]
+    bns = (gbn, bn0, bn1, bn2)
+    steps = tuple(_bn_step(bn) for bn in bns)
+    w = lambda conv: conv.weight.view(conv.out_channels, conv.in_channels)
+    return _SegHead.apply(levels, B, Npts, float(gact.negative_slope), bns, steps, w(gconv), gbn.weight, gbn.bias, w(c0),
+                          bn0.weight, bn0.bias, w(c1), bn1.weight, bn1.bias, w(c2), bn2.weight, bn2.bias, w(c3), c3.bias)
+
 
 # ------------------------------------------------------------------ BatchNorm + LeakyReLU on (M, C) rows
 class _BNAct(torch.autograd.Function):

@@ -250,6 +250,26 @@ class DGCNNSeg(DGCNNBase):
         _, p3 = self.ec3(x2, self.knn_graph, x_pm=p2, both=True, w_cat=w3)
         levels = torch.cat([p1c, p2c, p3], dim=2).view(B * N, 192)
         gf = self.global_feature[0].layers                                                   # conv, BN, LeakyReLU
+        seg0 = self.segmentation[0]
+        w = lambda conv: conv.weight.view(conv.out_channels, -1)
+        if F_hip.seg_head_supported(levels, B, N, w(gf[0]), w(seg0.layers[0]), w(self.segmentation[1].layers[0]),
+                                    w(self.segmentation[2].layers[0]), w(self.segmentation[3].layers[0])):
+            # the whole head as ONE autograd node on the fused kernels of csrc/pointwise.hip: fp32-grade products on the bf16
+            # matrix pipe, BatchNorm statistics / apply / backward inside the products' epilogues and prologues, the
+            # (B*N, 1024) global-feature activation never written, its backward in Gram form
+            y = F_hip.seg_head(levels, B, N, self.global_feature[0], list(self.segmentation))
+        else:
+            y = self._head_unfused(levels, B, N)
+        out = y.view(B, N, self.num_classes).transpose(1, 2)
+        # training: hand the loss the (B,cls,N) VIEW of the point-major logits (the fused loss and every ATen loss take
+        # strided input; its gradient then arrives point-major, no transposing copies either way); inference keeps the
+        # reference's contiguous layout
+        return out if self.training and torch.is_grad_enabled() else out.contiguous()
+
+    def _head_unfused(self, levels, B, N):
+        """the round-2 head: vendor GEMMs + fsg_bn_act_* stages (shapes outside the fused kernels' envelope, bf16 operand
+        mode, cross-check of the fused head)"""
+        gf = self.global_feature[0].layers
         # the two layers that read `levels` (global-feature conv and the `levels` half of the first head conv) share one
         # autograd node, so that their input gradients are accumulated by the second GEMM instead of an extra add
         seg0 = self.segmentation[0]
@@ -266,11 +286,7 @@ class DGCNNSeg(DGCNNBase):
         y = _norm_act(y.view(B * N, -1), list(seg0.layers)[1:])
         for block in list(self.segmentation)[1:]:
             y = pointwise_block(y, block)
-        out = y.view(B, N, self.num_classes).transpose(1, 2)
-        # training: hand the loss the (B,cls,N) VIEW of the point-major logits (the fused loss and every ATen loss take
-        # strided input; its gradient then arrives point-major, no transposing copies either way); inference keeps the
-        # reference's contiguous layout
-        return out if self.training and torch.is_grad_enabled() else out.contiguous()
+        return y
 
 
 class DGCNNReg(DGCNNBase):

@@ -460,6 +460,127 @@ int fsg_pw_weight_image_f32(const float *W, int64_t stride_n, int64_t stride_k, 
 int fsg_pw_linear_f32(const float *A, int64_t lda, const void *image, const float *bias, float *C, int64_t ldc, int M, int N,
                       int K, int tile, fsg_stream_t stream);
 
+/*
+ * The members of the family behind the fused DGCNN head (`functional.seg_head`; models/dgcnn.py:123-162 of the reference).
+ * Tile codes: 1 = 128 x 128, 2 = 64 x 128, 3 = 64 x 64, 4 = 128 x 64 (rows x columns of C); fsg_pw_tile_rows(tile) = rows.
+ *
+ * fsg_pw_rowgemm_f32:  C (M, N) = pro(A) (M, K1 + K2) . B,  B given as a weight image with (K1 + K2) / 16 k-steps.
+ *   prologue `pro` on segment 1 of A (segment 2 is always plain):
+ *     0 none
+ *     1 BatchNorm + LeakyReLU of the producing layer:  a = lrelu(alpha[k] A1[m,k] + delta[cloud(m)][k])
+ *     2 BatchNorm backward:  a = alpha[k] A1[m,k] f'(alpha[k] Y1[m,k] + delta[cloud][k]) - P[cloud][k] - Q[k] Y1[m,k]
+ *       (A1 = gradient w.r.t. the layer's activation, Y1 = its pre-BatchNorm values; P, Q from fsg_pw_bnbwd_finalize_f32)
+ *     per-cloud tables have `tstride` floats between clouds (0: one row for all), cloud(m) = m / rows_per_cloud
+ *   epilogue `epi` = OR of
+ *     1  STORE     columns >= store_n0 go to C[m * ldc + n - store_n0]
+ *     2  STATS     rec (M / rows, 3, N): (n, mean, M2) of every column over the tile's rows (train-mode BatchNorm statistics)
+ *     4  SEL       columns < sel_n: sel_val (M / rows, sel_n) = max over the tile's rows of sgn[n] * c, sel_arg = its row inside
+ *                  the cloud, lowest row on ties (the global max-pool through the monotone BatchNorm + LeakyReLU)
+ *     8  BWDSTATS  rec2 (M / rows, 2, N): sums over the tile's rows of h = c f'(ealpha Yp + edelta[cloud]) and
+ *                  h (Yp - emu[cloud]) er  (BatchNorm backward sums of the layer whose activation gradient C is)
+ *     16 BIAS      bias[n] added on the way out (with STORE)
+ *   K1, K2 multiples of 32; A rows 16-byte aligned with strides that are multiples of 4; reducing epilogues need M and
+ *   rows_per_cloud to be multiples of the tile's rows.  Only the combinations the head uses are instantiated
+ *   (FSG_ERR_UNSUPPORTED otherwise).
+ */
+typedef struct fsg_pw_rowgemm_args {
+    const float *A1, *Y1, *A2;
+    int64_t lda1, lda2;
+    int K1, K2;
+    const void *Bimg;
+    int M, N, rows_per_cloud;
+    const float *alpha, *delta, *P, *Q;
+    int tstride;
+    float slope;
+    float *C;
+    int64_t ldc;
+    int store_n0;
+    const float *bias;
+    float *rec;
+    const float *sgn;
+    float *sel_val;
+    int32_t *sel_arg;
+    int sel_n;
+    const float *Yp;
+    int64_t ldyp;
+    const float *ealpha, *edelta, *emu, *er;
+    int etstride;
+    float *rec2;
+} fsg_pw_rowgemm_args;
+int fsg_pw_tile_rows(int tile);
+int fsg_pw_rowgemm_f32(const fsg_pw_rowgemm_args *args, int pro, int epi, int tile, fsg_stream_t stream);
+
+/*
+ * fsg_pw_tn_f32:  [C1 ; C2] (N1a + N1b, N2) = sum_m L'(m, :)^T R'(m, :)  -- weight gradients dW = dy^T a and the Gram matrix
+ *   of the global-feature backward; contraction over the M rows, split into slices of rows_per_slice rows (multiple of 32)
+ *   whose partial products are summed in slice order (reproducible).  Left operand = [segment 1 | segment 2]: segment 1
+ *   (N1a columns) with prologue lpro = 0 or 2 (as above: L1 = gradient, LY1 = pre-BatchNorm values), segment 2 (N1b columns,
+ *   N1a % 64 == 0 then) plain; right operand (N2 columns) with rpro = 0 or 1.  Rows of the result below N1a go to C1, the
+ *   others to C2.  tile: 1 = 128 x 128, 2 = 64 x 128, 3 = 64 x 64, 5 = 128 x 192 (N1 x N2).  workspace:
+ *   fsg_pw_tn_workspace_bytes(N1a + N1b, N2, M, rows_per_slice) bytes.
+ */
+typedef struct fsg_pw_tn_args {
+    const float *L1, *LY1, *L2;
+    int64_t ldl1, ldl2;
+    int N1a, N1b, lpro;
+    const float *lalpha, *ldelta, *lP, *lQ;
+    int lts;
+    const float *R;
+    int64_t ldr;
+    int N2, rpro;
+    const float *ralpha, *rdelta;
+    int rts;
+    float slope;
+    int M, rows_per_cloud, rows_per_slice;
+} fsg_pw_tn_args;
+size_t fsg_pw_tn_workspace_bytes(int N1, int N2, int M, int rows_per_slice);
+int fsg_pw_tn_f32(const fsg_pw_tn_args *args, int tile, void *workspace, size_t workspace_bytes, float *C1, int64_t ldc1,
+                  float *C2, int64_t ldc2, fsg_stream_t stream);
+
+/*
+ * fsg_pw_bn_finalize_f32: STATS records (R, 3, ldn), columns [c0, c0 + C) -> train-mode BatchNorm statistics (Chan's merge in
+ *   fp64; `shift` (B, C) or NULL is added to the mean of every record of its cloud: y = y0 + shift[cloud]), torch's running
+ *   update (unbiased variance), and the tables of the consumers: alpha = gamma invstd, delta (B or 1, C) = alpha (shift - mean)
+ *   + beta, emu (B or 1, C) = mean - shift (nullable), cloud_mean (B, C) = unshifted per-cloud mean (nullable).
+ *   training == 0: mean / invstd are inputs (running statistics), only the tables are written.
+ * fsg_pw_max_finish_f32: SEL records (B * tiles, C) -> out (B, C) = lrelu(alpha ysel + delta), ysel, arg (row inside the cloud).
+ * fsg_pw_bnbwd_finalize_f32: BWDSTATS records (R, 2, C) -> dbeta, dgamma, P (B or 1, C), Q (C) of prologue 2, and (first head
+ *   layer, dc != NULL) dc (B, C) = per-cloud column sums of dy = the gradient of the per-cloud constant.
+ * fsg_pw_logits_bwd_f32: last layer (Conv1d(C, classes) + bias): da (M, C) = g (M, classes) W3, stored, + BWDSTATS records
+ *   (ceil(M / 128), 2, C) of the BatchNorm in front of it.
+ */
+int fsg_pw_bn_finalize_f32(const float *rec, int R, int ldn, int c0, int C, const float *shift, int B, int training,
+                           const float *gamma, const float *beta, float eps, float momentum, float *running_mean,
+                           float *running_var, float *mean, float *invstd, float *alpha, float *delta, float *emu,
+                           float *cloud_mean, fsg_stream_t stream);
+int fsg_pw_max_finish_f32(const float *sel_val, const int32_t *sel_arg, const float *sgn, const float *alpha, const float *delta,
+                          int B, int tiles, int C, float slope, float *out, float *ysel, int32_t *arg, fsg_stream_t stream);
+int fsg_pw_bnbwd_finalize_f32(const float *rec2, int R, int C, int B, int64_t M, int training, const float *alpha,
+                              const float *invstd, const float *emu, int emu_per_cloud, const float *cloud_mean, float *dbeta,
+                              float *dgamma, float *P, float *Q, float *dc, fsg_stream_t stream);
+int fsg_pw_logits_bwd_f32(const float *g, int classes, const float *W3, const float *y, const float *alpha, const float *delta,
+                          const float *mean, const float *invstd, int64_t M, int C, float slope, float *da, float *rec2,
+                          fsg_stream_t stream);
+
+/*
+ * Global-feature layer, backward in its Gram form (the (M, 1024) activation gradient is never formed): after the max over the
+ * points only B * C entries of dY are "selected", the BatchNorm terms are affine in y = X W^T, so with G = X^T X, s = sum_m X_m:
+ *   dX = selected rows - 1 (W^T P)^T - X (W^T diag(Q) W),   dW = selected rows - P s^T - diag(Q) W G.
+ * fsg_pw_gf_prep_f32: per channel dbeta, dgamma, P, Q and coef (B, C) = weight of the selected row in dy.
+ * fsg_pw_scatter_rows_f32: dX[b Npts + arg[b,c], :] += coef[b,c] W[c, :], summed per destination row in channel order.
+ * fsg_pw_gf_dw_f32: dW[c, :] = sum_b coef[b,c] X[b Npts + arg[b,c], :] - P[c] s - Q[c] WG[c, :]  (WG = W G, (C, K) contiguous).
+ * fsg_pw_colsum_f32: s = column sums of (M, K) rows (fixed order; workspace fsg_pw_colsum_workspace_bytes(M, K)).
+ */
+int fsg_pw_gf_prep_f32(const float *dg, const float *ysel, const float *alpha, const float *delta, const float *mean,
+                       const float *invstd, int B, int C, int64_t M, int training, float slope, float *dbeta, float *dgamma,
+                       float *P, float *Q, float *coef, fsg_stream_t stream);
+int fsg_pw_scatter_rows_f32(const float *coef, const int32_t *arg, const float *W, int64_t ldw, int B, int C, int K, int Npts,
+                            float *dX, int64_t ldx, fsg_stream_t stream);
+int fsg_pw_gf_dw_f32(const float *coef, const int32_t *arg, const float *X, int64_t ldx, const float *s, const float *WG,
+                     const float *P, const float *Q, int B, int C, int K, int Npts, float *dW, int64_t lddw, fsg_stream_t stream);
+size_t fsg_pw_colsum_workspace_bytes(int64_t M, int K);
+int fsg_pw_colsum_f32(const float *X, int64_t ldx, int64_t M, int K, float *out, float *workspace, fsg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
