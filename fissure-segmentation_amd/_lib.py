@@ -77,18 +77,22 @@ SIGNATURES = {
     "fsg_vec_attn_bwd_f32": ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "fsg_pw_weight_image_bytes": ([_I, _I], ctypes.c_size_t),
     "fsg_pw_weight_image_f32": ([_P, _L, _L, _I, _I, _F, _I, _I, _P, _P], _I),
+    "fsg_pw_weight_images_f32": ([_P, _P], _I),
     "fsg_pw_linear_f32": ([_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P], _I),
     "fsg_pw_tile_rows": ([_I], _I),
     "fsg_pw_rowgemm_f32": ([_P, _I, _I, _I, _P], _I),
     "fsg_pw_tn_workspace_bytes": ([_I, _I, _I, _I], ctypes.c_size_t),
     "fsg_pw_tn_f32": ([_P, _I, _P, ctypes.c_size_t, _P, _L, _P, _L, _P], _I),
-    "fsg_pw_bn_finalize_f32": ([_P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
+    "fsg_pw_tn_reduce_f32": ([_P, _P], _I),
+    "fsg_pw_bn_finalize_f32": ([_P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P], _I),
     "fsg_pw_max_finish_f32": ([_P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P], _I),
     "fsg_pw_bnbwd_finalize_f32": ([_P, _I, _I, _I, _L, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P], _I),
     "fsg_pw_logits_bwd_f32": ([_P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _P, _P], _I),
-    "fsg_pw_gf_prep_f32": ([_P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _F, _P, _P, _P, _P, _P, _P], _I),
-    "fsg_pw_scatter_rows_f32": ([_P, _P, _P, _L, _I, _I, _I, _I, _P, _L, _P], _I),
-    "fsg_pw_gf_dw_f32": ([_P, _P, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _P, _L, _P], _I),
+    "fsg_pw_gf_prep_f32": ([_P, _P, _L, _I, _P, _P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _F, _P, _P, _P, _P, _P, _P], _I),
+    "fsg_pw_gf_m1_f32": ([_P, _L, _P, _P, _I, _I, _P, _P, _P], _I),
+    "fsg_pw_scatter_rows_workspace_bytes": ([_I, _I], ctypes.c_size_t),
+    "fsg_pw_scatter_rows_f32": ([_P, _P, _P, _L, _I, _I, _I, _I, _P, _L, _P, _P], _I),
+    "fsg_pw_gf_dw_f32": ([_P, _P, _P, _L, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _P, _L, _P], _I),
     "fsg_pw_colsum_workspace_bytes": ([_L, _I], ctypes.c_size_t),
     "fsg_pw_colsum_f32": ([_P, _L, _L, _I, _P, _P, _P], _I),
 }
@@ -135,6 +139,26 @@ class PWRowGemmArgs(ctypes.Structure):
                 ("tstride", _I), ("slope", _F), ("C", _P), ("ldc", _L), ("store_n0", _I), ("bias", _P), ("rec", _P),
                 ("sgn", _P), ("sel_val", _P), ("sel_arg", _P), ("sel_n", _I), ("Yp", _P), ("ldyp", _L), ("ealpha", _P),
                 ("edelta", _P), ("emu", _P), ("er", _P), ("etstride", _I), ("rec2", _P)]
+
+
+PW_MAX_IMAGE_JOBS = 10
+
+
+class PWImageJobs(ctypes.Structure):
+    """include/fsg_hip.h: fsg_pw_image_jobs"""
+    _fields_ = [("W", _P * PW_MAX_IMAGE_JOBS), ("stride_n", _L * PW_MAX_IMAGE_JOBS), ("stride_k", _L * PW_MAX_IMAGE_JOBS),
+                ("N", _I * PW_MAX_IMAGE_JOBS), ("K", _I * PW_MAX_IMAGE_JOBS), ("ks0", _I * PW_MAX_IMAGE_JOBS),
+                ("KS", _I * PW_MAX_IMAGE_JOBS), ("scale", _F * PW_MAX_IMAGE_JOBS), ("image", _P * PW_MAX_IMAGE_JOBS), ("n", _I)]
+
+
+PW_MAX_REDUCE_JOBS = 6
+
+
+class PWTnReduceJobs(ctypes.Structure):
+    """include/fsg_hip.h: fsg_pw_tn_reduce_jobs"""
+    _fields_ = [("workspace", _P * PW_MAX_REDUCE_JOBS), ("C1", _P * PW_MAX_REDUCE_JOBS), ("C2", _P * PW_MAX_REDUCE_JOBS),
+                ("ldc1", _L * PW_MAX_REDUCE_JOBS), ("ldc2", _L * PW_MAX_REDUCE_JOBS), ("S", _I * PW_MAX_REDUCE_JOBS),
+                ("N1", _I * PW_MAX_REDUCE_JOBS), ("N2", _I * PW_MAX_REDUCE_JOBS), ("N1a", _I * PW_MAX_REDUCE_JOBS), ("n", _I)]
 
 
 class PWTnArgs(ctypes.Structure):

@@ -78,6 +78,45 @@ __global__ __launch_bounds__(256) void pw_weight_image_kernel(const float *__res
     o[128] = l;
 }
 
+// several images in one launch (the weights of a whole head, both orientations): job j owns the 64-thread blocks
+// [first[j], first[j + 1])
+struct ImageJobs {
+    const float *W[FSG_PW_MAX_IMAGE_JOBS];
+    long sn[FSG_PW_MAX_IMAGE_JOBS], sk[FSG_PW_MAX_IMAGE_JOBS];
+    int N[FSG_PW_MAX_IMAGE_JOBS], K[FSG_PW_MAX_IMAGE_JOBS], ks0[FSG_PW_MAX_IMAGE_JOBS], KS[FSG_PW_MAX_IMAGE_JOBS];
+    float scale[FSG_PW_MAX_IMAGE_JOBS];
+    u32x4 *img[FSG_PW_MAX_IMAGE_JOBS];
+    long first[FSG_PW_MAX_IMAGE_JOBS + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void pw_weight_images_kernel(const ImageJobs jobs) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = (int)(t & 63);
+    const long blk = t >> 6;
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < FSG_PW_MAX_IMAGE_JOBS; ++q)
+        if (q < jobs.n && blk >= jobs.first[q]) j = q;
+    if (blk >= jobs.first[jobs.n]) return;
+    const long lb = blk - jobs.first[j];
+    const int N = jobs.N[j], K = jobs.K[j], ksteps = (K + 15) / 16;
+    const int ks = (int)(lb % ksteps), nb = (int)(lb / ksteps);
+    const int n = nb * 32 + (lane & 31), k0 = ks * 16 + 8 * (lane >> 5);
+    const float *W = jobs.W[j];
+    const long sn = jobs.sn[j], sk = jobs.sk[j];
+    const float scale = jobs.scale[j];
+    float x[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) x[q] = (n < N && k0 + q < K) ? W[(long)n * sn + (long)(k0 + q) * sk] * scale : 0.f;
+    u32x4 h, m, l;
+    split8(x, h, m, l);
+    u32x4 *o = jobs.img[j] + (((long)nb * jobs.KS[j] + jobs.ks0[j] + ks) * 3) * 64 + lane;
+    o[0] = h;
+    o[64] = m;
+    o[128] = l;
+}
+
 struct RowGemmArgs {
     const float *A1;      // segment 1 of the A operand: (M, K1) rows, row stride lda1; PRO_BNBWD: the upstream gradient `da`
     const float *Y1;      // PRO_BNBWD: the pre-BatchNorm values y of the same shape / stride
@@ -317,7 +356,7 @@ __global__ __launch_bounds__(256) void pw_rowgemm_kernel(const RowGemmArgs p) {
                 __syncthreads();
             }
             if ((EPI & PW_SEL) && col0 < p.sel_n) {
-                const float sg = col < p.sel_n ? p.sgn[col] : 1.f;
+                const float sg = (col < p.sel_n && p.sgn[col] < 0.f) ? -1.f : 1.f;      // sgn = the BatchNorm weight: only its sign is used
                 float best = -INFINITY;
                 int brow = 0;
 #pragma unroll
@@ -609,8 +648,8 @@ __global__ __launch_bounds__(256) void pw_tn_reduce_kernel(const float *__restri
 // optional per-cloud shift added to every record's mean (the first head layer: y = y0 + c[cloud], models/dgcnn.py:159-160),
 // the running-statistics update of torch (unbiased variance) and the prologue tables of the consumer:
 //   alpha[c] = gamma r,  delta[b][c] = alpha (shift[b][c] - mean) + beta,  emu[b][c] = mean - shift[b][c]
-// 16 channels per workgroup, 16 record slices per channel (loads of a slice in flight together), LDS merge.
-constexpr int FS = 16;
+// 4 channels per workgroup, 64 contiguous record slices per channel (two to eight records each), LDS merge.
+constexpr int FS = 64, FC = 4;   // record slices and channels per workgroup: few dependent round trips per thread
 __global__ __launch_bounds__(256) void pw_bn_finalize_kernel(const float *__restrict__ rec, int R, int ldn, int c0, int C,
                                                              const float *__restrict__ shift, int B, int training,
                                                              const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -618,21 +657,50 @@ __global__ __launch_bounds__(256) void pw_bn_finalize_kernel(const float *__rest
                                                              float *__restrict__ running_var, float *__restrict__ mean_out,
                                                              float *__restrict__ invstd_out, float *__restrict__ alpha,
                                                              float *__restrict__ delta, float *__restrict__ emu,
-                                                             float *__restrict__ cloud_mean) {
-    __shared__ double red[3][FS][16];
-    __shared__ float stat[2][16];
-    const int ch = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + ch;
+                                                             float *__restrict__ cloud_mean, const float *__restrict__ gfeat,
+                                                             const float *__restrict__ Wglob, long ldwg, int CGf,
+                                                             float *__restrict__ shift_out) {
+    __shared__ double red[3][FS][FC];
+    __shared__ float stat[2][FC];
+    __shared__ float part[FS][FC];
+    __shared__ float shl[64][FC];                        // the in-kernel shift (B <= 64)
+    const int ch = threadIdx.x & (FC - 1), sl = threadIdx.x / FC;
+    const int c = blockIdx.x * FC + ch;
     const bool live = c < C;
+    auto shift_of = [&](int b) -> float { return gfeat ? shl[b][ch] : shift[(long)b * C + c]; };
+    if (gfeat) {
+        // shift[b][c] = sum_j gfeat[b][j] Wglob[c][j]: the per-cloud constant of the first head layer (models/dgcnn.py:159-160:
+        // the repeated global feature times its block of the weight), computed here instead of by a vendor GEMM launch.
+        // Slice sl sums j = sl, sl + FS, ...; fixed-order LDS fold.  Written to shift_out (B, C), which the caller passes as
+        // `shift` too.
+        for (int b = 0; b < B; ++b) {
+            float a = 0.f;
+            if (live)
+                for (int j = sl; j < CGf; j += FS) a = __builtin_fmaf(gfeat[(long)b * CGf + j], Wglob[(long)c * ldwg + j], a);
+            part[sl][ch] = a;
+            __syncthreads();
+            if (sl == 0 && live) {
+                float t = 0.f;
+#pragma unroll 8
+                for (int q = 0; q < FS; ++q) t += part[q][ch];
+                shift_out[(long)b * C + c] = t;
+                shl[b][ch] = t;
+            }
+            __syncthreads();
+        }
+    }
     const int rpc = B > 0 ? R / B : R;                  // records per cloud
+    // slice sl owns the records [sl * per, (sl + 1) * per): contiguous, so a slice stays inside one cloud when per | rpc
+    const int per = (R + FS - 1) / FS;
     if (training) {
         double a = 0.0, bm = 0.0, cm = 0.0;
         if (live) {
-            for (int r = sl; r < R; r += FS) {
+            const int r0 = sl * per, r1 = min(R, r0 + per);
+            for (int r = r0; r < r1; ++r) {
                 const float *pr = rec + (long)r * 3 * ldn + c0 + c;
                 const double n = pr[0];
                 double mu = pr[ldn];
-                if (shift) mu += (double)shift[(long)(r / rpc) * C + c];
+                if (shift) mu += (double)shift_of(r / rpc);
                 a += n;
                 bm += n * mu;
                 cm += (double)pr[2 * ldn] + n * mu * mu;
@@ -646,7 +714,7 @@ __global__ __launch_bounds__(256) void pw_bn_finalize_kernel(const float *__rest
             double n = 0.0;
             bm = 0.0;
             cm = 0.0;
-#pragma unroll
+#pragma unroll 8
             for (int q = 0; q < FS; ++q) { n += red[0][q][ch]; bm += red[1][q][ch]; cm += red[2][q][ch]; }
             const double mu = n > 0.0 ? bm / n : 0.0;
             double M2 = n > 0.0 ? cm - bm * mu : 0.0;
@@ -674,17 +742,23 @@ __global__ __launch_bounds__(256) void pw_bn_finalize_kernel(const float *__rest
     if (sl == 0) alpha[c] = al;
     const int nb = shift ? B : 1;
     for (int b = sl; b < nb; b += FS) {
-        const float sh = shift ? shift[(long)b * C + c] : 0.f;
+        const float sh = shift ? shift_of(b) : 0.f;
         delta[(long)b * C + c] = __builtin_fmaf(al, sh - mu, beta[c]);
         if (emu) emu[(long)b * C + c] = mu - sh;
     }
     if (cloud_mean && training) {                        // unshifted per-cloud mean of the records (first head layer's backward)
+        const bool aligned = per > 0 && rpc % per == 0 && R % per == 0;
         for (int b = sl; b < B; b += FS) {
             double n = 0.0, sm = 0.0;
-            for (int q = 0; q < rpc; ++q) {
-                const float *pr = rec + (long)(b * rpc + q) * 3 * ldn + c0 + c;
-                n += pr[0];
-                sm += (double)pr[0] * pr[ldn];
+            if (aligned) {                               // whole slices per cloud: their (n, n mu) sums are in LDS already; the
+                for (int q = b * (rpc / per); q < (b + 1) * (rpc / per); ++q) { n += red[0][q][ch]; sm += red[1][q][ch]; }
+                if (shift && n > 0.0) sm -= n * (double)shift_of(b);      // slices carry the cloud's shift: take it out
+            } else {
+                for (int q = 0; q < rpc; ++q) {
+                    const float *pr = rec + (long)(b * rpc + q) * 3 * ldn + c0 + c;
+                    n += pr[0];
+                    sm += (double)pr[0] * pr[ldn];
+                }
             }
             cloud_mean[(long)b * C + c] = (float)(n > 0.0 ? sm / n : 0.0);
         }
@@ -708,7 +782,7 @@ __global__ __launch_bounds__(256) void pw_max_finish_kernel(const float *__restr
         const int a = sel_arg[((long)b * tiles + t) * C + c];
         if (v > bv || (v == bv && a < ba)) { bv = v; ba = a; }
     }
-    const float yv = sgn[c] * bv;
+    const float yv = (sgn[c] < 0.f ? -1.f : 1.f) * bv;
     ysel[(long)b * C + c] = yv;
     arg[(long)b * C + c] = ba;
     const float u = __builtin_fmaf(yv, alpha[c], delta[c]);
@@ -726,23 +800,26 @@ __global__ __launch_bounds__(256) void pw_bnbwd_finalize_kernel(const float *__r
                                                                 float *__restrict__ dbeta, float *__restrict__ dgamma,
                                                                 float *__restrict__ P, float *__restrict__ Q,
                                                                 float *__restrict__ dc) {
-    __shared__ double red[2][FS][16];
-    __shared__ float tot[2][16];
-    const int ch = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + ch;
+    __shared__ double red[2][FS][FC];
+    __shared__ float tot[2][FC];
+    const int ch = threadIdx.x & (FC - 1), sl = threadIdx.x / FC;
+    const int c = blockIdx.x * FC + ch;
     const bool live = c < C;
+    const int per = (R + FS - 1) / FS;
     double sb = 0.0, sg = 0.0;
-    if (live)
-        for (int r = sl; r < R; r += FS) {
+    if (live) {
+        const int r0 = sl * per, r1 = min(R, r0 + per);
+        for (int r = r0; r < r1; ++r) {
             sb += (double)rec2[(long)r * 2 * C + c];
             sg += (double)rec2[(long)r * 2 * C + C + c];
         }
+    }
     red[0][sl][ch] = sb;
     red[1][sl][ch] = sg;
     __syncthreads();
     if (sl == 0 && live) {
         sb = sg = 0.0;
-#pragma unroll
+#pragma unroll 8
         for (int q = 0; q < FS; ++q) { sb += red[0][q][ch]; sg += red[1][q][ch]; }
         dbeta[c] = (float)sb;
         dgamma[c] = (float)sg;
@@ -758,12 +835,17 @@ __global__ __launch_bounds__(256) void pw_bnbwd_finalize_kernel(const float *__r
     if (sl == 0) Q[c] = q;
     const int nb = emu_per_cloud ? B : 1;
     const int rpc = B > 0 ? R / B : R;
+    const bool aligned = per > 0 && rpc % per == 0 && R % per == 0;
     for (int b = sl; b < nb; b += FS) {
         const float pb = al * (db - emu[(long)b * C + c] * dg);
         P[(long)b * C + c] = pb;
         if (dc) {
             double sh = 0.0;
-            for (int t = 0; t < rpc; ++t) sh += (double)rec2[(long)(b * rpc + t) * 2 * C + c];
+            if (aligned) {
+                for (int t = b * (rpc / per); t < (b + 1) * (rpc / per); ++t) sh += red[0][t][ch];
+            } else {
+                for (int t = 0; t < rpc; ++t) sh += (double)rec2[(long)(b * rpc + t) * 2 * C + c];
+            }
             const float nbf = (float)(M / B);
             dc[(long)b * C + c] = al * (float)sh - nbf * pb - q * nbf * cloud_mean[(long)b * C + c];
         }
@@ -772,34 +854,41 @@ __global__ __launch_bounds__(256) void pw_bnbwd_finalize_kernel(const float *__r
 
 // last layer, backward (models/dgcnn.py:146: Conv1d(128, classes) with bias, no BatchNorm behind it):
 //   da[m, k] = sum_j g[m, j] W3[j, k]  (classes <= 8), stored, and the BatchNorm backward sums of the layer in front:
-//   h = da f'(alpha y + delta), records (sum h, sum h yhat) per 128-row block.  lane = channel pair, 4 waves x 32 rows.
+//   h = da f'(alpha y + delta), records (sum h, sum h yhat) per 32-row block.  lane = channel, 4 waves x 8 rows, all loads of a
+//   wave's rows in flight together.
+constexpr int LB_ROWS = 32;
 __global__ __launch_bounds__(256) void pw_logits_bwd_kernel(const float *__restrict__ g, int cls, const float *__restrict__ W3,
                                                             const float *__restrict__ y, const float *__restrict__ alpha,
                                                             const float *__restrict__ delta, const float *__restrict__ mean,
                                                             const float *__restrict__ invstd, long M, int C, float slope,
                                                             float *__restrict__ da, float *__restrict__ rec2) {
-    __shared__ float red[2][4][256];
+    __shared__ float red[2][4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long r0 = (long)blockIdx.x * 128;
+    const long r0 = (long)blockIdx.x * LB_ROWS + wave * 8;
+    float gv[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gv[i][j] = (j < cls && r0 + i < M) ? g[(r0 + i) * cls + j] : 0.f;
     for (int cb = 0; cb < C; cb += 64) {
         const int c = cb + lane;
-        float w[8];
+        float w[8], yv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) w[j] = j < cls ? W3[(long)j * C + c] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) yv[i] = y[min(r0 + i, M - 1) * C + c];
         const float al = alpha[c], de = delta[c], mu = mean[c], rr = invstd[c];
         float sb = 0.f, sg = 0.f;
-        for (int i = wave; i < 128; i += 4) {
-            const long row = r0 + i;
-            if (row >= M) break;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
             float a = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (j < cls) a = __builtin_fmaf(g[row * cls + j], w[j], a);
-            da[row * C + c] = a;
-            const float yv = y[row * C + c], u = __builtin_fmaf(yv, al, de);
-            const float h = a * (u > 0.f ? 1.f : slope);
+            for (int j = 0; j < 8; ++j) a = __builtin_fmaf(gv[i][j], w[j], a);
+            if (r0 + i < M) da[(r0 + i) * C + c] = a;
+            const float u = __builtin_fmaf(yv[i], al, de);
+            const float h = a * (u > 0.f ? 1.f : slope);      // rows behind M carry g = 0, so h = 0
             sb += h;
-            sg = __builtin_fmaf(h, (yv - mu) * rr, sg);
+            sg = __builtin_fmaf(h, (yv[i] - mu) * rr, sg);
         }
         red[0][wave][lane] = sb;
         red[1][wave][lane] = sg;
@@ -813,26 +902,61 @@ __global__ __launch_bounds__(256) void pw_logits_bwd_kernel(const float *__restr
     }
 }
 
-// global-feature backward, per channel (the Gram form of DESIGN.md): with h[b] = dg[b] f'(alpha ysel[b] + delta),
+// global-feature backward, per channel j (the Gram form of DESIGN.md).  First the two tiny products around the per-cloud
+// constant c = g W0_global^T of the first head layer (models/dgcnn.py:159-160), which a vendor GEMM would need a launch each for:
+//   dg[b, j] = sum_k dc[b, k] W0g[k, j]   (gradient reaching the global feature),   dW0g[k, j] = sum_b dc[b, k] g[b, j]
+// then, with h[b] = dg[b] f'(alpha ysel[b] + delta):
 //   dbeta = sum_b h,  dgamma = sum_b h yhat_sel,  Q = alpha r dgamma / M,  P = alpha (dbeta / M - mean r dgamma / M),
 //   coef[b] = alpha h[b]   (weight of the selected row arg[b] in dy)
-__global__ __launch_bounds__(256) void pw_gf_prep_kernel(const float *__restrict__ dg, const float *__restrict__ ysel,
+constexpr int GP_MAXB = 16;
+__global__ __launch_bounds__(256) void pw_gf_prep_kernel(const float *__restrict__ dc, const float *__restrict__ W0g, long ldw0,
+                                                         int C0, const float *__restrict__ gfeat, float *__restrict__ dW0g,
+                                                         long lddw0, const float *__restrict__ dg_in,
+                                                         const float *__restrict__ ysel,
                                                          const float *__restrict__ alpha, const float *__restrict__ delta,
                                                          const float *__restrict__ mean, const float *__restrict__ invstd,
                                                          int B, int C, long M, int training, float slope,
                                                          float *__restrict__ dbeta, float *__restrict__ dgamma,
                                                          float *__restrict__ P, float *__restrict__ Q, float *__restrict__ coef) {
+    extern __shared__ float dcs[];     // (B, C0) when dc is given
     const int c = blockIdx.x * 256 + threadIdx.x;
+    float dgv[GP_MAXB];
+    if (dc) {
+        for (int e = threadIdx.x; e < B * C0; e += 256) dcs[e] = dc[e];
+        __syncthreads();
+        if (c < C) {
+            float gv[GP_MAXB];
+#pragma unroll
+            for (int b = 0; b < GP_MAXB; ++b) { dgv[b] = 0.f; gv[b] = b < B ? gfeat[(long)b * C + c] : 0.f; }
+            for (int k = 0; k < C0; ++k) {
+                const float w = W0g[(long)k * ldw0 + c];
+                float dw = 0.f;
+#pragma unroll
+                for (int b = 0; b < GP_MAXB; ++b)
+                    if (b < B) {
+                        const float d = dcs[b * C0 + k];
+                        dgv[b] = __builtin_fmaf(d, w, dgv[b]);
+                        dw = __builtin_fmaf(d, gv[b], dw);
+                    }
+                dW0g[(long)k * lddw0 + c] = dw;
+            }
+        }
+    } else if (c < C) {
+#pragma unroll
+        for (int b = 0; b < GP_MAXB; ++b) dgv[b] = b < B ? dg_in[(long)b * C + c] : 0.f;
+    }
     if (c >= C) return;
     const float al = alpha[c], de = delta[c], mu = mean[c], r = invstd[c];
     float sb = 0.f, sg = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float ys = ysel[(long)b * C + c], u = __builtin_fmaf(ys, al, de);
-        const float h = dg[(long)b * C + c] * (u > 0.f ? 1.f : slope);
-        coef[(long)b * C + c] = al * h;
-        sb += h;
-        sg = __builtin_fmaf(h, (ys - mu) * r, sg);
-    }
+#pragma unroll
+    for (int b = 0; b < GP_MAXB; ++b)
+        if (b < B) {
+            const float ys = ysel[(long)b * C + c], u = __builtin_fmaf(ys, al, de);
+            const float h = dgv[b] * (u > 0.f ? 1.f : slope);
+            coef[(long)b * C + c] = al * h;
+            sb += h;
+            sg = __builtin_fmaf(h, (ys - mu) * r, sg);
+        }
     dbeta[c] = sb;
     dgamma[c] = sg;
     const float invM = 1.0f / (float)M;
@@ -841,80 +965,200 @@ __global__ __launch_bounds__(256) void pw_gf_prep_kernel(const float *__restrict
     P[c] = al * (db - mu * dgm);
 }
 
+// M1 = W^T diag(Q) W (K x K) and npvec = -W^T P (K) of the Gram-form backward: output row i (row K = npvec) per workgroup
+// row, lane = column chunk, the four waves split the C channels; fixed-order LDS fold
+__global__ __launch_bounds__(256) void pw_gf_m1_kernel(const float *__restrict__ W, long ldw, const float *__restrict__ Q,
+                                                       const float *__restrict__ P, int C, int K, float *__restrict__ M1,
+                                                       float *__restrict__ npvec) {
+    __shared__ float red[4][64];
+    const int i = blockIdx.x, j = blockIdx.y * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int jj = min(j, K - 1);
+    const int per = (C + 3) / 4, c0 = wave * per, c1 = min(C, c0 + per);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int c = c0;
+    for (; c + 4 <= c1; c += 4) {
+        const float s0 = i < K ? Q[c] * W[(long)c * ldw + i] : -P[c];
+        const float s1 = i < K ? Q[c + 1] * W[(long)(c + 1) * ldw + i] : -P[c + 1];
+        const float s2 = i < K ? Q[c + 2] * W[(long)(c + 2) * ldw + i] : -P[c + 2];
+        const float s3 = i < K ? Q[c + 3] * W[(long)(c + 3) * ldw + i] : -P[c + 3];
+        a0 = __builtin_fmaf(s0, W[(long)c * ldw + jj], a0);
+        a1 = __builtin_fmaf(s1, W[(long)(c + 1) * ldw + jj], a1);
+        a2 = __builtin_fmaf(s2, W[(long)(c + 2) * ldw + jj], a2);
+        a3 = __builtin_fmaf(s3, W[(long)(c + 3) * ldw + jj], a3);
+    }
+    for (; c < c1; ++c) a0 = __builtin_fmaf(i < K ? Q[c] * W[(long)c * ldw + i] : -P[c], W[(long)c * ldw + jj], a0);
+    red[wave][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (wave == 0 && j < K) {
+        const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (i < K) M1[(long)i * K + j] = v;
+        else npvec[j] = v;
+    }
+}
+
 // dX rows of the selected points: for every cloud, dX[b N + arg[b,c], :] += coef[b,c] W[c, :], summed per destination row in
-// channel order (no atomics): one workgroup per cloud sorts its C (arg, c) pairs by counting, one wave per destination row.
-__global__ __launch_bounds__(256) void pw_scatter_rows_kernel(const float *__restrict__ coef, const int *__restrict__ arg,
-                                                              const float *__restrict__ W, long ldw, int C, int K, int Npts,
-                                                              float *__restrict__ dX, long ldx) {
-    extern __shared__ int sh[];
-    int *cnt = sh;             // [Npts + 1] -> start offsets
-    int *order = sh + Npts + 1;   // [C] channels grouped by destination row, ascending channel inside a row
-    int *args = order + C;        // [C] this cloud's selected rows
-    const int b = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i <= Npts; i += 256) cnt[i] = 0;
-    for (int c = tid; c < C; c += 256) args[c] = arg[(long)b * C + c];
-    __syncthreads();
-    for (int c = tid; c < C; c += 256) atomicAdd(&cnt[args[c] + 1], 1);
-    __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int i = 0; i <= Npts; ++i) { run += cnt[i]; cnt[i] = run; }
+// channel order (no atomics, reproducible).  pw_sort_sel_kernel sorts the cloud's keys (arg << 12 | c) once (bitonic in LDS,
+// one key per thread); pw_scatter_rows_kernel gives every workgroup a chunk of the sorted list: it owns the row segments whose
+// first entry lies in its chunk, issues ALL of the chunk's loads (weights rows, coefficients, old dX values) before the first
+// use, accumulates a segment in registers (thread = column) and writes its dX row once.
+constexpr int SC_CHUNK = 16;
+// one wave per cloud, KPL keys per lane in registers: compare-exchanges with a partner inside the lane are plain register
+// swaps (34 of the 55 stages at 1024 keys), the others cross lanes with __shfl_xor -- no LDS, no barriers
+template <int KPL>
+__global__ __launch_bounds__(64) void pw_sort_sel_wave_kernel(const int *__restrict__ arg, int C, unsigned *__restrict__ sorted) {
+    constexpr int NK = 64 * KPL;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    unsigned v[KPL];
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) {
+        const int i = lane * KPL + r;
+        v[r] = i < C ? ((unsigned)arg[(long)b * C + i] << 12) | (unsigned)i : 0xFFFFFFFFu;
     }
-    __syncthreads();
-    // stable placement: channel c goes behind the channels c' < c of the same row (rank by counting, C <= a few thousand)
-    for (int c = tid; c < C; c += 256) {
-        const int a = args[c];
-        int rank = 0;
-        for (int c2 = 0; c2 < c; ++c2) rank += (args[c2] == a) ? 1 : 0;
-        order[cnt[a] + rank] = c;
-    }
-    __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int row = wave; row < Npts; row += 4) {
-        const int e0 = cnt[row], e1 = cnt[row + 1];
-        if (e0 == e1) continue;
-        for (int k0 = 0; k0 < K; k0 += 64) {
-            const int k = k0 + lane;
-            if (k >= K) break;
-            float a = dX[((long)b * Npts + row) * ldx + k];
-            for (int e = e0; e < e1; ++e) {
-                const int c = order[e];
-                a = __builtin_fmaf(coef[(long)b * C + c], W[(long)c * ldw + k], a);
+#pragma unroll
+    for (int k = 2; k <= NK; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j < KPL) {
+#pragma unroll
+                for (int r = 0; r < KPL; ++r) {
+                    if ((r & j) == 0) {
+                        const bool up = ((lane * KPL + r) & k) == 0;
+                        const unsigned a = v[r], c = v[r | j];
+                        const unsigned lo = a < c ? a : c, hi = a < c ? c : a;
+                        v[r] = up ? lo : hi;
+                        v[r | j] = up ? hi : lo;
+                    }
+                }
+            } else {
+                const int J = j / KPL;
+                const bool lower = (lane & J) == 0;
+#pragma unroll
+                for (int r = 0; r < KPL; ++r) {
+                    const unsigned other = __shfl_xor(v[r], J);
+                    const bool up = ((lane * KPL + r) & k) == 0;
+                    const unsigned lo = v[r] < other ? v[r] : other, hi = v[r] < other ? other : v[r];
+                    v[r] = (lower == up) ? lo : hi;
+                }
             }
-            dX[((long)b * Npts + row) * ldx + k] = a;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) sorted[(long)b * NK + lane * KPL + r] = v[r];
+}
+
+// larger channel counts: bitonic sort in LDS
+__global__ __launch_bounds__(1024) void pw_sort_sel_kernel(const int *__restrict__ arg, int C, int Cp2, unsigned *__restrict__ sorted) {
+    extern __shared__ unsigned keys[];   // [Cp2]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < Cp2; i += 1024) keys[i] = i < C ? ((unsigned)arg[(long)b * C + i] << 12) | (unsigned)i : 0xFFFFFFFFu;
+    __syncthreads();
+    for (int k = 2; k <= Cp2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < Cp2; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned a = keys[i], c = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > c) == up) { keys[i] = c; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < Cp2; i += 1024) sorted[(long)b * Cp2 + i] = keys[i];
+}
+
+__global__ __launch_bounds__(256) void pw_scatter_rows_kernel(const float *__restrict__ coef, const unsigned *__restrict__ sorted,
+                                                              const float *__restrict__ W, long ldw, int C, int Cp2, int K,
+                                                              int Npts, float *__restrict__ dX, long ldx) {
+    const int b = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
+    const unsigned *keys = sorted + (long)b * Cp2;
+    const int c0 = chunk * SC_CHUNK;
+    if (c0 >= C) return;
+    unsigned key[SC_CHUNK];
+    const unsigned prev = c0 > 0 ? keys[c0 - 1] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < SC_CHUNK; ++i) key[i] = c0 + i < C ? keys[c0 + i] : 0xFFFFFFFFu;
+    for (int k0 = 0; k0 < K; k0 += 256) {
+        const int k = min(k0 + tid, K - 1);
+        float wv[SC_CHUNK], cf[SC_CHUNK], old[SC_CHUNK];
+#pragma unroll
+        for (int i = 0; i < SC_CHUNK; ++i) {      // every load unconditional (padded entries read row 0 / channel 0 and are never used)
+            const bool live = key[i] != 0xFFFFFFFFu;
+            const unsigned r = live ? key[i] >> 12 : 0u, c = live ? key[i] & 4095u : 0u;
+            wv[i] = W[(long)c * ldw + k];
+            cf[i] = coef[(long)b * C + c];
+            old[i] = dX[((long)b * Npts + r) * ldx + k];
+        }
+        if (k0 + tid >= K) continue;
+        float acc = 0.f, base = 0.f;
+        bool open = false;                                  // a segment whose head lies in this chunk is being summed
+        unsigned row = 0;
+#pragma unroll
+        for (int i = 0; i < SC_CHUNK; ++i) {
+            if (key[i] == 0xFFFFFFFFu) break;
+            const unsigned r = key[i] >> 12;
+            const bool head = (i == 0 ? (prev >> 12) : (key[i - 1] >> 12)) != r || (i == 0 && prev == 0xFFFFFFFFu);
+            if (head) {
+                if (open) dX[((long)b * Npts + row) * ldx + k] = base + acc;
+                open = true;
+                row = r;
+                base = old[i];
+                acc = 0.f;
+            }
+            if (open) acc = __builtin_fmaf(cf[i], wv[i], acc);
+        }
+        if (open) {                                          // the last segment may run on into the next chunks
+            for (int e = c0 + SC_CHUNK; e < C && (keys[e] >> 12) == row; ++e) {
+                const unsigned c = keys[e] & 4095u;
+                acc = __builtin_fmaf(coef[(long)b * C + c], W[(long)c * ldw + k], acc);
+            }
+            dX[((long)b * Npts + row) * ldx + k] = base + acc;
         }
     }
 }
 
 // dW of the global-feature layer, Gram form:  dW[c, :] = sum_b coef[b,c] X[b N + arg[b,c], :] - P[c] s - Q[c] (W G)[c, :]
+// (the small product W G is formed here: thread (c, k) walks row c of W against column k of G)
 __global__ __launch_bounds__(256) void pw_gf_dw_kernel(const float *__restrict__ coef, const int *__restrict__ arg,
                                                        const float *__restrict__ X, long ldx, const float *__restrict__ s,
-                                                       const float *__restrict__ WG, const float *__restrict__ P,
-                                                       const float *__restrict__ Q, int B, int C, int K, int Npts,
-                                                       float *__restrict__ dW, long lddw) {
+                                                       const float *__restrict__ W, long ldw, const float *__restrict__ G,
+                                                       const float *__restrict__ P, const float *__restrict__ Q, int B, int C,
+                                                       int K, int Npts, float *__restrict__ dW, long lddw) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long)C * K) return;
     const int c = (int)(t / K), k = (int)(t - (long)c * K);
-    float a = -__builtin_fmaf(Q[c], WG[(long)c * K + k], P[c] * s[k]);
+    float wg0 = 0.f, wg1 = 0.f;
+    int i = 0;
+    for (; i + 2 <= K; i += 2) {
+        wg0 = __builtin_fmaf(W[(long)c * ldw + i], G[(long)i * K + k], wg0);
+        wg1 = __builtin_fmaf(W[(long)c * ldw + i + 1], G[(long)(i + 1) * K + k], wg1);
+    }
+    for (; i < K; ++i) wg0 = __builtin_fmaf(W[(long)c * ldw + i], G[(long)i * K + k], wg0);
+    float a = -__builtin_fmaf(Q[c], wg0 + wg1, P[c] * s[k]);
     for (int b = 0; b < B; ++b)
         a = __builtin_fmaf(coef[(long)b * C + c], X[((long)b * Npts + arg[(long)b * C + c]) * ldx + k], a);
     dW[(long)c * lddw + k] = a;
 }
 
-// column sums of (M, K) rows: partial sums per 128-row block, then a fixed-order sum
+// column sums of (M, K) rows: partial sums per 64-row block (wave = 16 rows, lane = column, all loads independent), then a
+// fixed-order sum in fp64
+constexpr int CS_ROWS = 64;
 __global__ __launch_bounds__(256) void pw_colsum_part_kernel(const float *__restrict__ X, long ldx, long M, int K,
                                                              float *__restrict__ part) {
     __shared__ float red[4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long r0 = (long)blockIdx.x * 128;
+    const long r0 = (long)blockIdx.x * CS_ROWS + wave * 16;
     for (int k0 = 0; k0 < K; k0 += 64) {
-        const int k = k0 + lane;
+        const int k = min(k0 + lane, K - 1);
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = r0 + i < M ? X[(r0 + i) * ldx + k] : 0.f;
         float a = 0.f;
-        if (k < K)
-            for (int i = wave; i < 128 && r0 + i < M; i += 4) a += X[(r0 + i) * ldx + k];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a += v[i];
         red[wave][lane] = a;
         __syncthreads();
-        if (wave == 0 && k < K) part[(long)blockIdx.x * K + k] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (wave == 0 && k0 + lane < K) part[(long)blockIdx.x * K + k0 + lane] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
         __syncthreads();
     }
 }
@@ -932,6 +1176,40 @@ __global__ __launch_bounds__(256) void pw_colsum_fold_kernel(const float *__rest
         for (int q = 0; q < 16; ++q) a += red[q][ch];
         out[k] = (float)a;
     }
+}
+
+// several deferred reductions in one launch: job j owns the elements [first[j], first[j + 1])
+struct TnReduceJobs {
+    const float *part[FSG_PW_MAX_REDUCE_JOBS];
+    float *C1[FSG_PW_MAX_REDUCE_JOBS], *C2[FSG_PW_MAX_REDUCE_JOBS];
+    long ldc1[FSG_PW_MAX_REDUCE_JOBS], ldc2[FSG_PW_MAX_REDUCE_JOBS], first[FSG_PW_MAX_REDUCE_JOBS + 1];
+    int S[FSG_PW_MAX_REDUCE_JOBS], N1[FSG_PW_MAX_REDUCE_JOBS], N2[FSG_PW_MAX_REDUCE_JOBS], N1a[FSG_PW_MAX_REDUCE_JOBS];
+    int n;
+};
+__global__ __launch_bounds__(256) void pw_tn_reduce_many_kernel(const TnReduceJobs jobs) {
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= jobs.first[jobs.n]) return;
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < FSG_PW_MAX_REDUCE_JOBS; ++q)
+        if (q < jobs.n && g >= jobs.first[q]) j = q;
+    const long t = g - jobs.first[j];
+    const int S = jobs.S[j], N2 = jobs.N2[j];
+    const long total = (long)jobs.N1[j] * N2;
+    const float *part = jobs.part[j];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int q = 0;
+    for (; q + 4 <= S; q += 4) {
+        a0 += part[(long)q * total + t];
+        a1 += part[(long)(q + 1) * total + t];
+        a2 += part[(long)(q + 2) * total + t];
+        a3 += part[(long)(q + 3) * total + t];
+    }
+    for (; q < S; ++q) a0 += part[(long)q * total + t];
+    const float v = (a0 + a1) + (a2 + a3);
+    const int r = (int)(t / N2), c = (int)(t - (long)r * N2);
+    if (r < jobs.N1a[j]) jobs.C1[j][(long)r * jobs.ldc1[j] + c] = v;
+    else jobs.C2[j][(long)(r - jobs.N1a[j]) * jobs.ldc2[j] + c] = v;
 }
 
 template <int T1, int T2>
@@ -959,6 +1237,26 @@ extern "C" int fsg_pw_weight_image_f32(const float *W, int64_t stride_n, int64_t
     hipLaunchKernelGGL(pw_weight_image_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W,
                        (long)stride_n, (long)stride_k, N, K, scale, ks0, KS, reinterpret_cast<u32x4 *>(image));
     FSG_CHECK_LAUNCH("fsg_pw_weight_image_f32");
+    return FSG_OK;
+}
+
+extern "C" int fsg_pw_weight_images_f32(const fsg_pw_image_jobs *jobs, fsg_stream_t stream) {
+    FSG_REQUIRE(jobs && jobs->n >= 1 && jobs->n <= FSG_PW_MAX_IMAGE_JOBS, "fsg_pw_weight_images_f32: 1..%d jobs", FSG_PW_MAX_IMAGE_JOBS);
+    ImageJobs k{};
+    k.n = jobs->n;
+    long blocks = 0;
+    for (int j = 0; j < jobs->n; ++j) {
+        FSG_REQUIRE(jobs->W[j] && jobs->image[j] && jobs->N[j] > 0 && jobs->K[j] > 0 && jobs->ks0[j] >= 0 &&
+                        jobs->ks0[j] + (jobs->K[j] + 15) / 16 <= jobs->KS[j], "fsg_pw_weight_images_f32: bad job %d", j);
+        k.W[j] = jobs->W[j]; k.sn[j] = jobs->stride_n[j]; k.sk[j] = jobs->stride_k[j]; k.N[j] = jobs->N[j]; k.K[j] = jobs->K[j];
+        k.ks0[j] = jobs->ks0[j]; k.KS[j] = jobs->KS[j]; k.scale[j] = jobs->scale[j];
+        k.img[j] = reinterpret_cast<u32x4 *>(jobs->image[j]);
+        k.first[j] = blocks;
+        blocks += (long)((jobs->N[j] + 31) / 32) * ((jobs->K[j] + 15) / 16);
+    }
+    k.first[jobs->n] = blocks;
+    hipLaunchKernelGGL(pw_weight_images_kernel, dim3((unsigned)((blocks * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k);
+    FSG_CHECK_LAUNCH("fsg_pw_weight_images_f32");
     return FSG_OK;
 }
 
@@ -1082,11 +1380,11 @@ extern "C" size_t fsg_pw_tn_workspace_bytes(int N1, int N2, int M, int rows_per_
 
 extern "C" int fsg_pw_tn_f32(const fsg_pw_tn_args *a, int tile, void *workspace, size_t workspace_bytes, float *C1,
                              int64_t ldc1, float *C2, int64_t ldc2, fsg_stream_t stream) {
-    FSG_REQUIRE(a && a->L1 && a->R && workspace && C1, "fsg_pw_tn_f32: NULL pointer");
+    FSG_REQUIRE(a && a->L1 && a->R && workspace, "fsg_pw_tn_f32: NULL pointer");
     const int N1 = a->N1a + a->N1b;
     FSG_REQUIRE(a->M > 0 && a->N1a > 0 && a->N1b >= 0 && a->N2 > 0 && a->rows_per_slice > 0 && a->rows_per_slice % 32 == 0,
                 "fsg_pw_tn_f32: bad shape M=%d N1=%d+%d N2=%d rows_per_slice=%d", a->M, a->N1a, a->N1b, a->N2, a->rows_per_slice);
-    FSG_REQUIRE(a->N1b == 0 || (a->N1a % 64 == 0 && a->L2 && C2), "fsg_pw_tn_f32: two left segments need N1a %% 64 == 0, L2 and C2");
+    FSG_REQUIRE(a->N1b == 0 || (a->N1a % 64 == 0 && a->L2 && (C2 || !C1)), "fsg_pw_tn_f32: two left segments need N1a %% 64 == 0, L2 and C2");
     FSG_REQUIRE(a->lpro == PRO_NONE || (a->lpro == PRO_BNBWD && a->LY1 && a->lalpha && a->ldelta && a->lP && a->lQ),
                 "fsg_pw_tn_f32: left prologue %d needs LY1 and its tables", a->lpro);
     FSG_REQUIRE(a->rpro == PRO_NONE || (a->rpro == PRO_BNACT && a->ralpha && a->rdelta), "fsg_pw_tn_f32: right prologue %d", a->rpro);
@@ -1110,6 +1408,7 @@ extern "C" int fsg_pw_tn_f32(const fsg_pw_tn_args *a, int tile, void *workspace,
     else if (tile == 5) rc = launch_tn<2, 3>(k, S, st);
     else { fsg_set_error("fsg_pw_tn_f32: tile %d", tile); return FSG_ERR_ARG; }
     if (rc != FSG_OK) return rc;
+    if (!C1) return FSG_OK;          // the caller folds the slices later (fsg_pw_tn_reduce_f32: several products, one launch)
     const long total = (long)N1 * a->N2;
     hipLaunchKernelGGL(pw_tn_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, k.part, S, N1, a->N2, a->N1a,
                        C1, (long)ldc1, C2, (long)ldc2);
@@ -1117,16 +1416,40 @@ extern "C" int fsg_pw_tn_f32(const fsg_pw_tn_args *a, int tile, void *workspace,
     return FSG_OK;
 }
 
+extern "C" int fsg_pw_tn_reduce_f32(const fsg_pw_tn_reduce_jobs *jobs, fsg_stream_t stream) {
+    FSG_REQUIRE(jobs && jobs->n >= 1 && jobs->n <= FSG_PW_MAX_REDUCE_JOBS, "fsg_pw_tn_reduce_f32: 1..%d jobs", FSG_PW_MAX_REDUCE_JOBS);
+    TnReduceJobs k{};
+    k.n = jobs->n;
+    long total = 0;
+    for (int j = 0; j < jobs->n; ++j) {
+        FSG_REQUIRE(jobs->workspace[j] && jobs->C1[j] && jobs->S[j] > 0 && jobs->N1[j] > 0 && jobs->N2[j] > 0 &&
+                        (jobs->N1a[j] >= jobs->N1[j] || jobs->C2[j]), "fsg_pw_tn_reduce_f32: bad job %d", j);
+        k.part[j] = reinterpret_cast<const float *>(jobs->workspace[j]);
+        k.C1[j] = jobs->C1[j]; k.C2[j] = jobs->C2[j]; k.ldc1[j] = jobs->ldc1[j]; k.ldc2[j] = jobs->ldc2[j];
+        k.S[j] = jobs->S[j]; k.N1[j] = jobs->N1[j]; k.N2[j] = jobs->N2[j]; k.N1a[j] = jobs->N1a[j];
+        k.first[j] = total;
+        total += (long)jobs->N1[j] * jobs->N2[j];
+    }
+    k.first[jobs->n] = total;
+    hipLaunchKernelGGL(pw_tn_reduce_many_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k);
+    FSG_CHECK_LAUNCH("fsg_pw_tn_reduce_f32");
+    return FSG_OK;
+}
+
 extern "C" int fsg_pw_bn_finalize_f32(const float *rec, int R, int ldn, int c0, int C, const float *shift, int B, int training,
                                       const float *gamma, const float *beta, float eps, float momentum, float *running_mean,
                                       float *running_var, float *mean, float *invstd, float *alpha, float *delta, float *emu,
-                                      float *cloud_mean, fsg_stream_t stream) {
+                                      float *cloud_mean, const float *gfeat, const float *Wglob, int64_t ldwg, int CG,
+                                      float *shift_out, fsg_stream_t stream) {
     FSG_REQUIRE(gamma && beta && mean && invstd && alpha && delta, "fsg_pw_bn_finalize_f32: NULL pointer");
+    FSG_REQUIRE(!gfeat || (Wglob && shift_out && shift == shift_out && CG > 0 && B > 0 && B <= 64),
+                "fsg_pw_bn_finalize_f32: an in-kernel shift needs gfeat, Wglob, CG and shift == shift_out");
     FSG_REQUIRE(C > 0 && (!training || (rec && R > 0 && ldn >= c0 + C)) && (!shift || (B > 0 && R % B == 0)) &&
                     (!cloud_mean || (B > 0 && R % B == 0)),
                 "fsg_pw_bn_finalize_f32: bad shape R=%d ldn=%d c0=%d C=%d B=%d", R, ldn, c0, C, B);
-    hipLaunchKernelGGL(pw_bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, rec, R, ldn, c0, C, shift, B,
-                       training, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, alpha, delta, emu, cloud_mean);
+    hipLaunchKernelGGL(pw_bn_finalize_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, (hipStream_t)stream, rec, R, ldn, c0, C, shift, B,
+                       training, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, alpha, delta, emu, cloud_mean,
+                       gfeat, Wglob, (long)ldwg, CG, shift_out);
     FSG_CHECK_LAUNCH("fsg_pw_bn_finalize_f32");
     return FSG_OK;
 }
@@ -1148,7 +1471,7 @@ extern "C" int fsg_pw_bnbwd_finalize_f32(const float *rec2, int R, int C, int B,
     FSG_REQUIRE(rec2 && alpha && invstd && emu && dbeta && dgamma && P && Q && R > 0 && C > 0 && M > 0 && B > 0 && R % B == 0 &&
                     (!dc || (cloud_mean && emu_per_cloud && M % B == 0)),
                 "fsg_pw_bnbwd_finalize_f32: bad arguments");
-    hipLaunchKernelGGL(pw_bnbwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, rec2, R, C, B, (long)M,
+    hipLaunchKernelGGL(pw_bnbwd_finalize_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, (hipStream_t)stream, rec2, R, C, B, (long)M,
                        training, alpha, invstd, emu, emu_per_cloud, cloud_mean, dbeta, dgamma, P, Q, dc);
     FSG_CHECK_LAUNCH("fsg_pw_bnbwd_finalize_f32");
     return FSG_OK;
@@ -1159,50 +1482,74 @@ extern "C" int fsg_pw_logits_bwd_f32(const float *g, int classes, const float *W
                                      float *da, float *rec2, fsg_stream_t stream) {
     FSG_REQUIRE(g && W3 && y && alpha && delta && mean && invstd && da && rec2 && M > 0 && C > 0 && C % 64 == 0 && classes >= 1 &&
                     classes <= 8, "fsg_pw_logits_bwd_f32: bad arguments (C %% 64 == 0, 1 <= classes <= 8)");
-    hipLaunchKernelGGL(pw_logits_bwd_kernel, dim3((unsigned)((M + 127) / 128)), dim3(256), 0, (hipStream_t)stream, g, classes, W3,
+    hipLaunchKernelGGL(pw_logits_bwd_kernel, dim3((unsigned)((M + LB_ROWS - 1) / LB_ROWS)), dim3(256), 0, (hipStream_t)stream, g, classes, W3,
                        y, alpha, delta, mean, invstd, (long)M, C, slope, da, rec2);
     FSG_CHECK_LAUNCH("fsg_pw_logits_bwd_f32");
     return FSG_OK;
 }
 
-extern "C" int fsg_pw_gf_prep_f32(const float *dg, const float *ysel, const float *alpha, const float *delta, const float *mean,
-                                  const float *invstd, int B, int C, int64_t M, int training, float slope, float *dbeta,
-                                  float *dgamma, float *P, float *Q, float *coef, fsg_stream_t stream) {
-    FSG_REQUIRE(dg && ysel && alpha && delta && mean && invstd && dbeta && dgamma && P && Q && coef && B > 0 && C > 0 && M > 0,
-                "fsg_pw_gf_prep_f32: bad arguments");
-    hipLaunchKernelGGL(pw_gf_prep_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, dg, ysel, alpha, delta, mean,
-                       invstd, B, C, (long)M, training, slope, dbeta, dgamma, P, Q, coef);
+extern "C" int fsg_pw_gf_prep_f32(const float *dc, const float *W0g, int64_t ldw0, int C0, const float *gfeat, float *dW0g,
+                                  int64_t lddw0, const float *dg, const float *ysel, const float *alpha, const float *delta,
+                                  const float *mean, const float *invstd, int B, int C, int64_t M, int training, float slope,
+                                  float *dbeta, float *dgamma, float *P, float *Q, float *coef, fsg_stream_t stream) {
+    FSG_REQUIRE(ysel && alpha && delta && mean && invstd && dbeta && dgamma && P && Q && coef && B > 0 && B <= GP_MAXB && C > 0 && M > 0,
+                "fsg_pw_gf_prep_f32: bad arguments (B <= %d)", GP_MAXB);
+    FSG_REQUIRE((dc && W0g && gfeat && dW0g && C0 > 0 && (size_t)B * C0 * 4 <= 48 * 1024) || (!dc && dg),
+                "fsg_pw_gf_prep_f32: either dc + W0g + gfeat + dW0g (B C0 <= 12288) or dg");
+    hipLaunchKernelGGL(pw_gf_prep_kernel, dim3((C + 255) / 256), dim3(256), dc ? sizeof(float) * B * C0 : 0, (hipStream_t)stream, dc,
+                       W0g, (long)ldw0, C0, gfeat, dW0g, (long)lddw0, dg, ysel, alpha, delta, mean, invstd, B, C, (long)M, training,
+                       slope, dbeta, dgamma, P, Q, coef);
     FSG_CHECK_LAUNCH("fsg_pw_gf_prep_f32");
     return FSG_OK;
 }
 
+extern "C" int fsg_pw_gf_m1_f32(const float *W, int64_t ldw, const float *Q, const float *P, int C, int K, float *M1, float *npvec,
+                                fsg_stream_t stream) {
+    FSG_REQUIRE(W && Q && P && M1 && npvec && C > 0 && K > 0, "fsg_pw_gf_m1_f32: bad arguments");
+    hipLaunchKernelGGL(pw_gf_m1_kernel, dim3(K + 1, (K + 63) / 64), dim3(256), 0, (hipStream_t)stream, W, (long)ldw, Q, P, C, K, M1, npvec);
+    FSG_CHECK_LAUNCH("fsg_pw_gf_m1_f32");
+    return FSG_OK;
+}
+
+static int scatter_cp2(int C) {
+    int Cp2 = 1;
+    while (Cp2 < C) Cp2 <<= 1;
+    return Cp2;
+}
+
+extern "C" size_t fsg_pw_scatter_rows_workspace_bytes(int B, int C) { return sizeof(unsigned) * (size_t)(B > 0 ? B : 0) * scatter_cp2(C); }
+
 extern "C" int fsg_pw_scatter_rows_f32(const float *coef, const int32_t *arg, const float *W, int64_t ldw, int B, int C, int K,
-                                       int Npts, float *dX, int64_t ldx, fsg_stream_t stream) {
-    FSG_REQUIRE(coef && arg && W && dX && B > 0 && C > 0 && K > 0 && Npts > 0, "fsg_pw_scatter_rows_f32: bad arguments");
-    const size_t lds = sizeof(int) * ((size_t)Npts + 1 + 2 * (size_t)C);
-    FSG_REQUIRE(lds <= 64 * 1024, "fsg_pw_scatter_rows_f32: Npts + C = %d too large for the LDS sort", Npts + C);
-    hipLaunchKernelGGL(pw_scatter_rows_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, coef, arg, W, (long)ldw, C, K, Npts,
-                       dX, (long)ldx);
+                                       int Npts, float *dX, int64_t ldx, void *workspace, fsg_stream_t stream) {
+    FSG_REQUIRE(coef && arg && W && dX && workspace && B > 0 && C > 0 && C <= 4096 && K > 0 && Npts > 0 && Npts <= (1 << 20),
+                "fsg_pw_scatter_rows_f32: bad arguments (C <= 4096, Npts <= 2^20)");
+    const int Cp2 = scatter_cp2(C);
+    unsigned *sorted = reinterpret_cast<unsigned *>(workspace);
+    if (Cp2 == 1024) hipLaunchKernelGGL(pw_sort_sel_wave_kernel<16>, dim3(B), dim3(64), 0, (hipStream_t)stream, arg, C, sorted);
+    else hipLaunchKernelGGL(pw_sort_sel_kernel, dim3(B), dim3(1024), sizeof(unsigned) * Cp2, (hipStream_t)stream, arg, C, Cp2, sorted);
+    FSG_CHECK_LAUNCH("fsg_pw_scatter_rows_f32/sort");
+    hipLaunchKernelGGL(pw_scatter_rows_kernel, dim3(B, (C + SC_CHUNK - 1) / SC_CHUNK), dim3(256), 0, (hipStream_t)stream, coef,
+                       sorted, W, (long)ldw, C, Cp2, K, Npts, dX, (long)ldx);
     FSG_CHECK_LAUNCH("fsg_pw_scatter_rows_f32");
     return FSG_OK;
 }
 
 extern "C" int fsg_pw_gf_dw_f32(const float *coef, const int32_t *arg, const float *X, int64_t ldx, const float *s,
-                                const float *WG, const float *P, const float *Q, int B, int C, int K, int Npts, float *dW,
-                                int64_t lddw, fsg_stream_t stream) {
-    FSG_REQUIRE(coef && arg && X && s && WG && P && Q && dW && B > 0 && C > 0 && K > 0 && Npts > 0, "fsg_pw_gf_dw_f32: bad arguments");
+                                const float *W, int64_t ldw, const float *G, const float *P, const float *Q, int B, int C, int K,
+                                int Npts, float *dW, int64_t lddw, fsg_stream_t stream) {
+    FSG_REQUIRE(coef && arg && X && s && W && G && P && Q && dW && B > 0 && C > 0 && K > 0 && Npts > 0, "fsg_pw_gf_dw_f32: bad arguments");
     const long total = (long)C * K;
     hipLaunchKernelGGL(pw_gf_dw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, coef, arg, X,
-                       (long)ldx, s, WG, P, Q, B, C, K, Npts, dW, (long)lddw);
+                       (long)ldx, s, W, (long)ldw, G, P, Q, B, C, K, Npts, dW, (long)lddw);
     FSG_CHECK_LAUNCH("fsg_pw_gf_dw_f32");
     return FSG_OK;
 }
 
-extern "C" size_t fsg_pw_colsum_workspace_bytes(int64_t M, int K) { return sizeof(float) * (size_t)((M + 127) / 128) * K; }
+extern "C" size_t fsg_pw_colsum_workspace_bytes(int64_t M, int K) { return sizeof(float) * (size_t)((M + CS_ROWS - 1) / CS_ROWS) * K; }
 
 extern "C" int fsg_pw_colsum_f32(const float *X, int64_t ldx, int64_t M, int K, float *out, float *workspace, fsg_stream_t stream) {
     FSG_REQUIRE(X && out && workspace && M > 0 && K > 0, "fsg_pw_colsum_f32: bad arguments");
-    const int R = (int)((M + 127) / 128);
+    const int R = (int)((M + CS_ROWS - 1) / CS_ROWS);
     hipLaunchKernelGGL(pw_colsum_part_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, X, (long)ldx, (long)M, K, workspace);
     FSG_CHECK_LAUNCH("fsg_pw_colsum_f32/part");
     hipLaunchKernelGGL(pw_colsum_fold_kernel, dim3((K + 15) / 16), dim3(256), 0, (hipStream_t)stream, workspace, R, K, out);

@@ -910,6 +910,26 @@ def pw_weight_image(w, scale=1.0, out=None, ks0=0, KS=None):
     return out
 
 
+def pw_weight_images(specs):
+    """several weight images in ONE launch: specs = [(w (N, K) view, scale, out uint8 tensor or None, ks0, KS or None), ...];
+    returns the image tensors (include/fsg_hip.h: fsg_pw_weight_images_f32)"""
+    jobs = _lib.PWImageJobs()
+    outs = []
+    assert 1 <= len(specs) <= _lib.PW_MAX_IMAGE_JOBS
+    for j, (w, scale, out, ks0, KS) in enumerate(specs):
+        N, K = w.shape
+        KS = (K + 15) // 16 if KS is None else KS
+        if out is None:
+            out = torch.empty(((N + 31) // 32) * KS * 3 * 1024, dtype=torch.uint8, device=w.device)
+        jobs.W[j], jobs.stride_n[j], jobs.stride_k[j], jobs.N[j], jobs.K[j] = w.data_ptr(), w.stride(0), w.stride(1), N, K
+        jobs.ks0[j], jobs.KS[j], jobs.scale[j], jobs.image[j] = ks0, KS, float(scale), out.data_ptr()
+        outs.append(out)
+    jobs.n = len(specs)
+    with torch.cuda.device(specs[0][0].device):
+        _lib.call("fsg_pw_weight_images_f32", ctypes.byref(jobs), _stream())
+    return outs
+
+
 def pw_linear(x, image, N, bias=None, tile=0):
     """y (M, N) = x (M, K) W^T (+ bias) with W given as pw_weight_image(W): six bf16 MFMA products per fp32 product, fp32
     accumulation (include/fsg_hip.h: fsg_pw_linear_f32)"""
@@ -943,8 +963,9 @@ def pw_rowgemm(pro, epi, tile, **kw):
         _lib.call("fsg_pw_rowgemm_f32", ctypes.byref(a), pro, epi, tile, _stream())
 
 
-def pw_tn(tile, C1, ldc1, C2=None, ldc2=0, **kw):
-    """include/fsg_hip.h: fsg_pw_tn_f32"""
+def pw_tn(tile, C1, ldc1, C2=None, ldc2=0, defer=None, **kw):
+    """include/fsg_hip.h: fsg_pw_tn_f32.  `defer`: a list -- the slices stay in their workspace and the job is appended to the
+    list, to be folded by `pw_tn_reduce(list)` together with the other products' (one launch instead of one per product)"""
     a = _lib.PWTnArgs()
     keep = []
     for k, v in kw.items():
@@ -956,11 +977,29 @@ def pw_tn(tile, C1, ldc1, C2=None, ldc2=0, **kw):
     nbytes = _lib.lib.fsg_pw_tn_workspace_bytes(a.N1a + a.N1b, a.N2, a.M, a.rows_per_slice)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.call("fsg_pw_tn_f32", ctypes.byref(a), tile, _p(ws), nbytes, _p(C1), ldc1, _p(C2), ldc2, _stream())
+        if defer is None:
+            _lib.call("fsg_pw_tn_f32", ctypes.byref(a), tile, _p(ws), nbytes, _p(C1), ldc1, _p(C2), ldc2, _stream())
+        else:
+            _lib.call("fsg_pw_tn_f32", ctypes.byref(a), tile, _p(ws), nbytes, None, 0, None, 0, _stream())
+            defer.append((ws, C1, ldc1, C2, ldc2, (a.M + a.rows_per_slice - 1) // a.rows_per_slice, a.N1a + a.N1b, a.N2, a.N1a))
 
 
-def _pw_bn_finalize(rec, R, ldn, c0, C, shift, B, bn, training, momentum, with_emu=False, with_cloud_mean=False):
-    """statistics + consumer tables of one BatchNorm of the fused head; returns (mean, invstd, alpha, delta, emu, cloud_mean)"""
+def pw_tn_reduce(jobs):
+    """include/fsg_hip.h: fsg_pw_tn_reduce_f32 -- fold the slices of the deferred products of pw_tn, one launch"""
+    j = _lib.PWTnReduceJobs()
+    assert 1 <= len(jobs) <= _lib.PW_MAX_REDUCE_JOBS
+    for i, (ws, C1, ldc1, C2, ldc2, S, N1, N2, N1a) in enumerate(jobs):
+        j.workspace[i], j.C1[i], j.ldc1[i], j.C2[i], j.ldc2[i] = ws.data_ptr(), C1.data_ptr(), ldc1, _ptr(C2), ldc2
+        j.S[i], j.N1[i], j.N2[i], j.N1a[i] = S, N1, N2, N1a
+    j.n = len(jobs)
+    with torch.cuda.device(jobs[0][0].device):
+        _lib.call("fsg_pw_tn_reduce_f32", ctypes.byref(j), _stream())
+
+
+def _pw_bn_finalize(rec, R, ldn, c0, C, shift, B, bn, training, momentum, with_emu=False, with_cloud_mean=False, gfeat=None,
+                    wglob=None):
+    """statistics + consumer tables of one BatchNorm of the fused head; returns (mean, invstd, alpha, delta, emu, cloud_mean).
+    `gfeat` (B, CG) + `wglob` (C, CG) view: the per-cloud shift gfeat wglob^T is formed inside the kernel (written to `shift`)"""
     dev = bn.weight.device
     nb = B if shift is not None else 1
     alpha = torch.empty(C, dtype=torch.float32, device=dev)
@@ -979,7 +1018,8 @@ def _pw_bn_finalize(rec, R, ldn, c0, C, shift, B, bn, training, momentum, with_e
     with torch.cuda.device(dev):
         _lib.call("fsg_pw_bn_finalize_f32", _p(rec), R, ldn, c0, C, _p(shift), B, int(training), _p(bn.weight), _p(bn.bias),
                   float(bn.eps), float(momentum), _p(rm), _p(rv), _p(mean), _p(invstd), _p(alpha), _p(delta), _p(emu), _p(cm),
-                  _stream())
+                  _p(gfeat), _p(wglob), wglob.stride(0) if wglob is not None else 0, gfeat.shape[1] if gfeat is not None else 0,
+                  _p(shift) if gfeat is not None else None, _stream())
     return mean, invstd, alpha, delta, emu, cm
 
 
@@ -1005,16 +1045,21 @@ class _SegHead(torch.autograd.Function):
         # weight images (three bf16 pieces in MFMA operand layout)
         ksl = KL // 16
         img0 = torch.empty(((CG + C0) // 32) * ksl * 3 * 1024, dtype=torch.uint8, device=dev)
-        pw_weight_image(Wg, out=img0)
-        pw_weight_image(W0[:, :KL], out=img0[(CG // 32) * ksl * 3 * 1024:])
-        img1, img2, img3 = pw_weight_image(W1), pw_weight_image(W2), pw_weight_image(W3)
+        ks_a, ks_b = C0 // 16, KL // 16
+        img_lv = torch.empty((KL // 32) * (ks_a + ks_b) * 3 * 1024, dtype=torch.uint8, device=dev)   # [W0_levels^T ; -M1]: backward
+        specs = [(Wg, 1.0, img0, 0, None), (W0[:, :KL], 1.0, img0[(CG // 32) * ksl * 3 * 1024:], 0, None), (W1, 1.0, None, 0, None),
+                 (W2, 1.0, None, 0, None), (W3, 1.0, None, 0, None)]
+        # transposed images for the backward products ride in the same launch
+        specs += [(W2.t(), 1.0, None, 0, None), (W1.t(), 1.0, None, 0, None), (W0[:, :KL].t(), 1.0, img_lv, 0, ks_a + ks_b)]
+        imgs = pw_weight_images(specs)
+        img1, img2, img3, img2t, img1t = imgs[2], imgs[3], imgs[4], imgs[5], imgs[6]
         # levels -> global-feature statistics / selection + y0
         R0 = M // 128
         rec0 = torch.empty(R0, 3, CG + C0, **f32)
         sel_val = torch.empty(R0, CG, **f32)
         sel_arg = torch.empty(R0, CG, dtype=torch.int32, device=dev)
         y0 = torch.empty(M, C0, **f32)
-        sgn = torch.where(gg >= 0, 1.0, -1.0).to(torch.float32)
+        sgn = gg                     # only the sign of the BatchNorm weight is used (max of sgn * y through the monotone BN + LeakyReLU)
         pw_rowgemm(PRO_NONE, PW_STORE | PW_STATS | PW_SEL, 1, A1=levels, lda1=levels.stride(0), K1=KL, K2=0, Bimg=img0, M=M,
                    N=CG + C0, rows_per_cloud=Npts, C=y0, ldc=C0, store_n0=CG, rec=rec0, sgn=sgn, sel_val=sel_val,
                    sel_arg=sel_arg, sel_n=CG)
@@ -1025,9 +1070,9 @@ class _SegHead(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.call("fsg_pw_max_finish_f32", _p(sel_val), _p(sel_arg), _p(sgn), _p(al_g), _p(de_g), B, Npts // 128, CG,
                       slope, _p(g), _p(ysel), _p(arg), _stream())
-        c = g @ W0[:, KL:].t()                                              # (B, C0): the global part of the first head layer
+        c = torch.empty(B, C0, **f32)     # g W0_global^T: the global part of the first head layer, formed inside the finalize kernel
         mean_0, inv_0, al_0, de_0, emu_0, cm_0 = _pw_bn_finalize(rec0, R0, CG + C0, CG, C0, c, B, bn_0, tr_0, mom_0,
-                                                                 with_emu=True, with_cloud_mean=True)
+                                                                 with_emu=True, with_cloud_mean=True, gfeat=g, wglob=W0[:, KL:])
         # layer 1, layer 2, logits
         R1 = M // 64
         y1 = torch.empty(M, C1, **f32)
@@ -1043,6 +1088,7 @@ class _SegHead(torch.autograd.Function):
         out = torch.empty(M, CLS, **f32)
         pw_rowgemm(PRO_BNACT, PW_STORE | PW_BIAS, 3, A1=y2, lda1=C2, K1=C2, K2=0, Bimg=img3, M=M, N=CLS, rows_per_cloud=Npts,
                    alpha=al_2, delta=de_2, tstride=0, slope=slope, C=out, ldc=CLS, store_n0=0, bias=b3)
+        ctx.images = (img2t, img1t, img_lv)
         ctx.save_for_backward(levels, y0, y1, y2, Wg, W0, W1, W2, W3, g, ysel, arg, c,
                               mean_g, inv_g, al_g, de_g, mean_0, inv_0, al_0, de_0, emu_0,
                               cm_0 if cm_0 is not None else torch.zeros(B, C0, **f32), mean_1, inv_1, al_1, de_1, mean_2, inv_2, al_2, de_2)
@@ -1055,6 +1101,7 @@ class _SegHead(torch.autograd.Function):
         (levels, y0, y1, y2, Wg, W0, W1, W2, W3, g, ysel, arg, c, mean_g, inv_g, al_g, de_g, mean_0, inv_0, al_0, de_0, emu_0,
          cm_0, mean_1, inv_1, al_1, de_1, mean_2, inv_2, al_2, de_2) = ctx.saved_tensors
         B, Npts, slope, (tr_g, tr_0, tr_1, tr_2) = ctx.meta
+        img2t, img1t, img_lv = ctx.images
         M, KL = levels.shape
         dev = levels.device
         CG, C0, C1, C2, CLS = Wg.shape[0], W0.shape[0], W1.shape[0], W2.shape[0], W3.shape[0]
@@ -1067,10 +1114,11 @@ class _SegHead(torch.autograd.Function):
         # ---- logits layer
         db3 = _bias_grad(gout)
         dW3 = torch.empty(CLS, C2, **f32)
-        pw_tn(3, dW3, C2, L1=gout, ldl1=CLS, N1a=CLS, N1b=0, lpro=PRO_NONE, R=y2, ldr=C2, N2=C2, rpro=PRO_BNACT, ralpha=al_2,
+        folds = []                      # the four weight-gradient products leave their row slices; one launch folds them at the end
+        pw_tn(3, dW3, C2, defer=folds, L1=gout, ldl1=CLS, N1a=CLS, N1b=0, lpro=PRO_NONE, R=y2, ldr=C2, N2=C2, rpro=PRO_BNACT, ralpha=al_2,
               rdelta=de_2, rts=0, slope=slope, M=M, rows_per_cloud=Npts, rows_per_slice=128)
         da2 = torch.empty(M, C2, **f32)
-        Rb = (M + 127) // 128
+        Rb = (M + 31) // 32
         r2b = torch.empty(Rb, 2, C2, **f32)
         call("fsg_pw_logits_bwd_f32", _p(gout), CLS, _p(W3), _p(y2), _p(al_2), _p(de_2), _p(mean_2), _p(inv_2), M, C2, slope,
              _p(da2), _p(r2b))
@@ -1086,59 +1134,56 @@ class _SegHead(torch.autograd.Function):
         db2, dg2, P2, Q2, _ = bwd_fin(r2b, Rb, C2, tr_2, al_2, inv_2, mean_2, False)
         # ---- layer 2
         dW2 = torch.empty(C2, C1, **f32)
-        pw_tn(2, dW2, C1, L1=da2, LY1=y2, ldl1=C2, N1a=C2, N1b=0, lpro=PRO_BNBWD, lalpha=al_2, ldelta=de_2, lP=P2, lQ=Q2, lts=0,
+        pw_tn(2, dW2, C1, defer=folds, L1=da2, LY1=y2, ldl1=C2, N1a=C2, N1b=0, lpro=PRO_BNBWD, lalpha=al_2, ldelta=de_2, lP=P2, lQ=Q2, lts=0,
               R=y1, ldr=C1, N2=C1, rpro=PRO_BNACT, ralpha=al_1, rdelta=de_1, rts=0, slope=slope, M=M, rows_per_cloud=Npts,
               rows_per_slice=256)
         R1 = M // 64
         da1 = torch.empty(M, C1, **f32)
         r1b = torch.empty(R1, 2, C1, **f32)
-        pw_rowgemm(PRO_BNBWD, PW_STORE | PW_BWDSTATS, 2, A1=da2, Y1=y2, lda1=C2, K1=C2, K2=0, Bimg=pw_weight_image(W2.t()), M=M,
+        pw_rowgemm(PRO_BNBWD, PW_STORE | PW_BWDSTATS, 2, A1=da2, Y1=y2, lda1=C2, K1=C2, K2=0, Bimg=img2t, M=M,
                    N=C1, rows_per_cloud=Npts, alpha=al_2, delta=de_2, P=P2, Q=Q2, tstride=0, slope=slope, C=da1, ldc=C1,
                    store_n0=0, Yp=y1, ldyp=C1, ealpha=al_1, edelta=de_1, emu=mean_1, er=inv_1, etstride=0, rec2=r1b)
         db1, dg1, P1, Q1, _ = bwd_fin(r1b, R1, C1, tr_1, al_1, inv_1, mean_1, False)
         # ---- layer 1
         dW1 = torch.empty(C1, C0, **f32)
-        pw_tn(1, dW1, C0, L1=da1, LY1=y1, ldl1=C1, N1a=C1, N1b=0, lpro=PRO_BNBWD, lalpha=al_1, ldelta=de_1, lP=P1, lQ=Q1, lts=0,
+        pw_tn(1, dW1, C0, defer=folds, L1=da1, LY1=y1, ldl1=C1, N1a=C1, N1b=0, lpro=PRO_BNBWD, lalpha=al_1, ldelta=de_1, lP=P1, lQ=Q1, lts=0,
               R=y0, ldr=C0, N2=C0, rpro=PRO_BNACT, ralpha=al_0, rdelta=de_0, rts=C0, slope=slope, M=M, rows_per_cloud=Npts,
               rows_per_slice=256)
         da0 = torch.empty(M, C0, **f32)
         r0b = torch.empty(R1, 2, C0, **f32)
-        pw_rowgemm(PRO_BNBWD, PW_STORE | PW_BWDSTATS, 2, A1=da1, Y1=y1, lda1=C1, K1=C1, K2=0, Bimg=pw_weight_image(W1.t()), M=M,
+        pw_rowgemm(PRO_BNBWD, PW_STORE | PW_BWDSTATS, 2, A1=da1, Y1=y1, lda1=C1, K1=C1, K2=0, Bimg=img1t, M=M,
                    N=C0, rows_per_cloud=Npts, alpha=al_1, delta=de_1, P=P1, Q=Q1, tstride=0, slope=slope, C=da0, ldc=C0,
                    store_n0=0, Yp=y0, ldyp=C0, ealpha=al_0, edelta=de_0, emu=emu_0, er=inv_0, etstride=C0, rec2=r0b)
         db0, dg0, P0, Q0, dc = bwd_fin(r0b, R1, C0, tr_0, al_0, inv_0, emu_0, True, cm=cm_0, want_dc=True)
         # ---- first head layer (levels part + per-cloud global part) and the global-feature layer in its Gram form
-        W0G = W0[:, KL:]
-        dg = dc @ W0G                                                       # (B, CG)
         dW0 = torch.empty(C0, KL + CG, **f32)
-        dW0[:, KL:] = dc.t() @ g
         dbg, dgg = torch.empty(CG, **f32), torch.empty(CG, **f32)
         Pg, Qg, coef = torch.empty(CG, **f32), torch.empty(CG, **f32), torch.empty(B, CG, **f32)
-        call("fsg_pw_gf_prep_f32", _p(dg), _p(ysel), _p(al_g), _p(de_g), _p(mean_g), _p(inv_g), B, CG, M, int(tr_g), slope,
-             _p(dbg), _p(dgg), _p(Pg), _p(Qg), _p(coef))
-        M1 = (Wg * Qg.unsqueeze(1)).t() @ Wg                                # (KL, KL) = W^T diag(Q) W
-        npvec = -(Pg @ Wg)                                                  # (KL,)
+        W0G, dW0G = W0[:, KL:], dW0[:, KL:]
+        call("fsg_pw_gf_prep_f32", _p(dc), _p(W0G), W0.stride(0), C0, _p(g), _p(dW0G), dW0.stride(0), None, _p(ysel), _p(al_g),
+             _p(de_g), _p(mean_g), _p(inv_g), B, CG, M, int(tr_g), slope, _p(dbg), _p(dgg), _p(Pg), _p(Qg), _p(coef))
+        M1, npvec = torch.empty(KL, KL, **f32), torch.empty(KL, **f32)     # W^T diag(Q) W and -(W^T P)
+        call("fsg_pw_gf_m1_f32", _p(Wg), Wg.stride(0), _p(Qg), _p(Pg), CG, KL, _p(M1), _p(npvec))
         ks_a, ks_b = C0 // 16, KL // 16
-        img_lv = torch.empty((KL // 32) * (ks_a + ks_b) * 3 * 1024, dtype=torch.uint8, device=dev)
-        pw_weight_image(W0[:, :KL].t(), out=img_lv, ks0=0, KS=ks_a + ks_b)
         pw_weight_image(M1, scale=-1.0, out=img_lv, ks0=ks_a, KS=ks_a + ks_b)
         G = torch.empty(KL, KL, **f32)
-        pw_tn(5, dW0, KL + CG, G, KL, L1=da0, LY1=y0, L2=levels, ldl1=C0, ldl2=levels.stride(0), N1a=C0, N1b=KL, lpro=PRO_BNBWD,
+        pw_tn(5, dW0, KL + CG, G, KL, defer=folds, L1=da0, LY1=y0, L2=levels, ldl1=C0, ldl2=levels.stride(0), N1a=C0, N1b=KL, lpro=PRO_BNBWD,
               lalpha=al_0, ldelta=de_0, lP=P0, lQ=Q0, lts=C0, R=levels, ldr=levels.stride(0), N2=KL, rpro=PRO_NONE, slope=slope,
               M=M, rows_per_cloud=Npts, rows_per_slice=256)
+        pw_tn_reduce(folds)             # dW3, dW2, dW1, [dW0_levels ; G]
         dlv = torch.empty(M, KL, **f32)
         pw_rowgemm(PRO_BNBWD, PW_STORE | PW_BIAS, 4, A1=da0, Y1=y0, A2=levels, lda1=C0, lda2=levels.stride(0), K1=C0, K2=KL,
                    Bimg=img_lv, M=M, N=KL, rows_per_cloud=Npts, alpha=al_0, delta=de_0, P=P0, Q=Q0, tstride=C0, slope=slope,
                    C=dlv, ldc=KL, store_n0=0, bias=npvec)
-        call("fsg_pw_scatter_rows_f32", _p(coef), _p(arg), _p(Wg), Wg.stride(0), B, CG, KL, Npts, _p(dlv), KL)
+        sws = torch.empty(_lib.lib.fsg_pw_scatter_rows_workspace_bytes(B, CG) // 4, dtype=torch.int32, device=dev)
+        call("fsg_pw_scatter_rows_f32", _p(coef), _p(arg), _p(Wg), Wg.stride(0), B, CG, KL, Npts, _p(dlv), KL, _p(sws))
         s = torch.empty(KL, **f32)
         wsb = _lib.lib.fsg_pw_colsum_workspace_bytes(M, KL)
         ws = torch.empty(wsb // 4, **f32)
         call("fsg_pw_colsum_f32", _p(levels), levels.stride(0), M, KL, _p(s), _p(ws))
-        WGm = Wg @ G
         dWg = torch.empty(CG, KL, **f32)
-        call("fsg_pw_gf_dw_f32", _p(coef), _p(arg), _p(levels), levels.stride(0), _p(s), _p(WGm), _p(Pg), _p(Qg), B, CG, KL, Npts,
-             _p(dWg), KL)
+        call("fsg_pw_gf_dw_f32", _p(coef), _p(arg), _p(levels), levels.stride(0), _p(s), _p(Wg), Wg.stride(0), _p(G), _p(Pg), _p(Qg),
+             B, CG, KL, Npts, _p(dWg), KL)
         return (dlv, None, None, None, None, None, dWg, dgg, dbg, dW0, dg0, db0, dW1, dg1, db1, dW2, dg2, db2, dW3, db3)
 
 

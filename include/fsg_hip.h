@@ -453,7 +453,18 @@ int fsg_fold_layer1_f32(const float *pts, int cp, const float *w, int64_t ldw, c
  *   matrices along k: this call fills k-steps [ks0, ks0 + ceil(K/16)) of an image with KS k-steps per 32-row block.
  * fsg_pw_linear_f32: C (M, N) = A (M, K) W^T (+ bias), A fp32 rows with stride lda (multiple of 4, 16-byte aligned),
  *   K % 32 == 0, W given as its image.  tile: 0 = chosen by shape, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 128x64.
+ * fsg_pw_weight_images_f32: up to FSG_PW_MAX_IMAGE_JOBS images in one launch (the weights of a whole head, both orientations).
  */
+#define FSG_PW_MAX_IMAGE_JOBS 10
+typedef struct fsg_pw_image_jobs {
+    const float *W[FSG_PW_MAX_IMAGE_JOBS];
+    int64_t stride_n[FSG_PW_MAX_IMAGE_JOBS], stride_k[FSG_PW_MAX_IMAGE_JOBS];
+    int N[FSG_PW_MAX_IMAGE_JOBS], K[FSG_PW_MAX_IMAGE_JOBS], ks0[FSG_PW_MAX_IMAGE_JOBS], KS[FSG_PW_MAX_IMAGE_JOBS];
+    float scale[FSG_PW_MAX_IMAGE_JOBS];
+    void *image[FSG_PW_MAX_IMAGE_JOBS];
+    int n;
+} fsg_pw_image_jobs;
+int fsg_pw_weight_images_f32(const fsg_pw_image_jobs *jobs, fsg_stream_t stream);
 size_t fsg_pw_weight_image_bytes(int N, int K);
 int fsg_pw_weight_image_f32(const float *W, int64_t stride_n, int64_t stride_k, int N, int K, float scale, int ks0, int KS,
                             void *image, fsg_stream_t stream);
@@ -518,6 +529,8 @@ int fsg_pw_rowgemm_f32(const fsg_pw_rowgemm_args *args, int pro, int epi, int ti
  *   N1a % 64 == 0 then) plain; right operand (N2 columns) with rpro = 0 or 1.  Rows of the result below N1a go to C1, the
  *   others to C2.  tile: 1 = 128 x 128, 2 = 64 x 128, 3 = 64 x 64, 5 = 128 x 192 (N1 x N2).  workspace:
  *   fsg_pw_tn_workspace_bytes(N1a + N1b, N2, M, rows_per_slice) bytes.
+ *   C1 == NULL: the slices are left in the workspace, to be folded later by fsg_pw_tn_reduce_f32 -- the reductions of several
+ *   products in ONE launch (job j: S = ceil(M / rows_per_slice) slices of (N1, N2) in workspace[j]; rows < N1a -> C1, others -> C2).
  */
 typedef struct fsg_pw_tn_args {
     const float *L1, *LY1, *L2;
@@ -533,6 +546,15 @@ typedef struct fsg_pw_tn_args {
     float slope;
     int M, rows_per_cloud, rows_per_slice;
 } fsg_pw_tn_args;
+#define FSG_PW_MAX_REDUCE_JOBS 6
+typedef struct fsg_pw_tn_reduce_jobs {
+    const void *workspace[FSG_PW_MAX_REDUCE_JOBS];
+    float *C1[FSG_PW_MAX_REDUCE_JOBS], *C2[FSG_PW_MAX_REDUCE_JOBS];
+    int64_t ldc1[FSG_PW_MAX_REDUCE_JOBS], ldc2[FSG_PW_MAX_REDUCE_JOBS];
+    int S[FSG_PW_MAX_REDUCE_JOBS], N1[FSG_PW_MAX_REDUCE_JOBS], N2[FSG_PW_MAX_REDUCE_JOBS], N1a[FSG_PW_MAX_REDUCE_JOBS];
+    int n;
+} fsg_pw_tn_reduce_jobs;
+int fsg_pw_tn_reduce_f32(const fsg_pw_tn_reduce_jobs *jobs, fsg_stream_t stream);
 size_t fsg_pw_tn_workspace_bytes(int N1, int N2, int M, int rows_per_slice);
 int fsg_pw_tn_f32(const fsg_pw_tn_args *args, int tile, void *workspace, size_t workspace_bytes, float *C1, int64_t ldc1,
                   float *C2, int64_t ldc2, fsg_stream_t stream);
@@ -543,16 +565,19 @@ int fsg_pw_tn_f32(const fsg_pw_tn_args *args, int tile, void *workspace, size_t 
  *   update (unbiased variance), and the tables of the consumers: alpha = gamma invstd, delta (B or 1, C) = alpha (shift - mean)
  *   + beta, emu (B or 1, C) = mean - shift (nullable), cloud_mean (B, C) = unshifted per-cloud mean (nullable).
  *   training == 0: mean / invstd are inputs (running statistics), only the tables are written.
+ *   gfeat (B, CG) != NULL: the shift is computed in the kernel first, shift[b][c] = sum_j gfeat[b][j] Wglob[c * ldwg + j] (the
+ *   per-cloud constant of the first head layer, models/dgcnn.py:159-160), and written to shift_out == shift (B <= 64).
  * fsg_pw_max_finish_f32: SEL records (B * tiles, C) -> out (B, C) = lrelu(alpha ysel + delta), ysel, arg (row inside the cloud).
  * fsg_pw_bnbwd_finalize_f32: BWDSTATS records (R, 2, C) -> dbeta, dgamma, P (B or 1, C), Q (C) of prologue 2, and (first head
  *   layer, dc != NULL) dc (B, C) = per-cloud column sums of dy = the gradient of the per-cloud constant.
  * fsg_pw_logits_bwd_f32: last layer (Conv1d(C, classes) + bias): da (M, C) = g (M, classes) W3, stored, + BWDSTATS records
- *   (ceil(M / 128), 2, C) of the BatchNorm in front of it.
+ *   (ceil(M / 32), 2, C) of the BatchNorm in front of it.
  */
 int fsg_pw_bn_finalize_f32(const float *rec, int R, int ldn, int c0, int C, const float *shift, int B, int training,
                            const float *gamma, const float *beta, float eps, float momentum, float *running_mean,
                            float *running_var, float *mean, float *invstd, float *alpha, float *delta, float *emu,
-                           float *cloud_mean, fsg_stream_t stream);
+                           float *cloud_mean, const float *gfeat, const float *Wglob, int64_t ldwg, int CG, float *shift_out,
+                           fsg_stream_t stream);
 int fsg_pw_max_finish_f32(const float *sel_val, const int32_t *sel_arg, const float *sgn, const float *alpha, const float *delta,
                           int B, int tiles, int C, float slope, float *out, float *ysel, int32_t *arg, fsg_stream_t stream);
 int fsg_pw_bnbwd_finalize_f32(const float *rec2, int R, int C, int B, int64_t M, int training, const float *alpha,
@@ -566,18 +591,27 @@ int fsg_pw_logits_bwd_f32(const float *g, int classes, const float *W3, const fl
  * Global-feature layer, backward in its Gram form (the (M, 1024) activation gradient is never formed): after the max over the
  * points only B * C entries of dY are "selected", the BatchNorm terms are affine in y = X W^T, so with G = X^T X, s = sum_m X_m:
  *   dX = selected rows - 1 (W^T P)^T - X (W^T diag(Q) W),   dW = selected rows - P s^T - diag(Q) W G.
- * fsg_pw_gf_prep_f32: per channel dbeta, dgamma, P, Q and coef (B, C) = weight of the selected row in dy.
- * fsg_pw_scatter_rows_f32: dX[b Npts + arg[b,c], :] += coef[b,c] W[c, :], summed per destination row in channel order.
- * fsg_pw_gf_dw_f32: dW[c, :] = sum_b coef[b,c] X[b Npts + arg[b,c], :] - P[c] s - Q[c] WG[c, :]  (WG = W G, (C, K) contiguous).
+ * fsg_pw_gf_prep_f32: per channel dbeta, dgamma, P, Q and coef (B, C) = weight of the selected row in dy.  The gradient of the
+ *   global feature is either given (dg (B, C), dc == NULL) or formed here from the gradient dc (B, C0) of the first head layer's
+ *   per-cloud constant: dg = dc W0g (W0g (C0, C), row stride ldw0), together with dW0g (C0, C) = dc^T gfeat (B <= 16).
+ * fsg_pw_gf_m1_f32: M1 (K, K) = W^T diag(Q) W and npvec (K) = -W^T P.
+ * fsg_pw_scatter_rows_f32: dX[b Npts + arg[b,c], :] += coef[b,c] W[c, :], summed per destination row in channel order
+ *   (C <= 4096; workspace fsg_pw_scatter_rows_workspace_bytes(B, C) bytes for the sorted selection keys).
+ * fsg_pw_gf_dw_f32: dW[c, :] = sum_b coef[b,c] X[b Npts + arg[b,c], :] - P[c] s - Q[c] (W G)[c, :]  (G (K, K) contiguous).
  * fsg_pw_colsum_f32: s = column sums of (M, K) rows (fixed order; workspace fsg_pw_colsum_workspace_bytes(M, K)).
  */
-int fsg_pw_gf_prep_f32(const float *dg, const float *ysel, const float *alpha, const float *delta, const float *mean,
+int fsg_pw_gf_prep_f32(const float *dc, const float *W0g, int64_t ldw0, int C0, const float *gfeat, float *dW0g, int64_t lddw0,
+                       const float *dg, const float *ysel, const float *alpha, const float *delta, const float *mean,
                        const float *invstd, int B, int C, int64_t M, int training, float slope, float *dbeta, float *dgamma,
                        float *P, float *Q, float *coef, fsg_stream_t stream);
+int fsg_pw_gf_m1_f32(const float *W, int64_t ldw, const float *Q, const float *P, int C, int K, float *M1, float *npvec,
+                     fsg_stream_t stream);
+size_t fsg_pw_scatter_rows_workspace_bytes(int B, int C);
 int fsg_pw_scatter_rows_f32(const float *coef, const int32_t *arg, const float *W, int64_t ldw, int B, int C, int K, int Npts,
-                            float *dX, int64_t ldx, fsg_stream_t stream);
-int fsg_pw_gf_dw_f32(const float *coef, const int32_t *arg, const float *X, int64_t ldx, const float *s, const float *WG,
-                     const float *P, const float *Q, int B, int C, int K, int Npts, float *dW, int64_t lddw, fsg_stream_t stream);
+                            float *dX, int64_t ldx, void *workspace, fsg_stream_t stream);
+int fsg_pw_gf_dw_f32(const float *coef, const int32_t *arg, const float *X, int64_t ldx, const float *s, const float *W,
+                     int64_t ldw, const float *G, const float *P, const float *Q, int B, int C, int K, int Npts, float *dW,
+                     int64_t lddw, fsg_stream_t stream);
 size_t fsg_pw_colsum_workspace_bytes(int64_t M, int K);
 int fsg_pw_colsum_f32(const float *X, int64_t ldx, int64_t M, int K, float *out, float *workspace, fsg_stream_t stream);
 

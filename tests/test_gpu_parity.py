@@ -2242,7 +2242,7 @@ def test_dgcnnseg_config4_full_batch_bf16_properties(fsg, device, monkeypatch):
     pinned to the oracle at 1 x 8192 -- ON THE SAME GRAPHS (the bf16 run's graphs are replayed into the fp32 run: with its own
     graphs a dynamic-graph net answers a 1e-2 feature perturbation with other neighbours, measured mean |logit error| 0.07)
     logits within the stated bf16 tolerance and gradient direction kept; (4) in eval mode (no cross-cloud BatchNorm coupling)
-    the batch is independent clouds: cloud 2 of the batch equals the same cloud run alone, bit for bit; (5) the
+    the batch is independent clouds: cloud 2 of the batch equals the same cloud run alone (1e-5); (5) the
     hipGraph-replayed bf16 step equals the eager one bit for bit."""
     from fissure_segmentation_amd.models.dgcnn import DGCNNSeg
     F_hip = fsg.functional
@@ -2286,7 +2286,9 @@ def test_dgcnnseg_config4_full_batch_bf16_properties(fsg, device, monkeypatch):
     with torch.no_grad(), F_hip.mfma_operands("bf16"):
         yb = net(x)
         y1 = net(x[2:3].contiguous())
-    assert torch.equal(yb[2:3], y1)
+    # (bf16 operand mode runs the head on vendor GEMMs, which may pick another kernel for another M: same values up to fp32
+    # summation order, not the same bits)
+    torch.testing.assert_close(yb[2:3], y1, rtol=1e-5, atol=1e-5)
     net.train()
     # hipGraph replay of the bf16 step == eager
     static_x = x.clone()

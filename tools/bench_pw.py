@@ -1,6 +1,8 @@
 """fsg_pw_linear_f32 (three-piece bf16 split, six MFMA products, csrc/pointwise.hip) against the vendor fp32 GEMM at the shapes
 of the DGCNN head (BASELINE config 2: M = 16384 points).  Both captured into a hipGraph (10 launches) and replayed between HIP
-events; TF = algorithmic fp32 flop 2 M N K per second."""
+events; TF = algorithmic fp32 flop 2 M N K per second.
+(profiles/r3_pw_rowgemm_ablation.txt: phase ablations of the first version of the kernel, taken with runtime switches that were
+removed again because the branches themselves cost the 128x128 tile 30 %.)"""
 import sys
 import numpy as np
 import torch
