@@ -21,6 +21,8 @@
 //   Epilogues on the accumulator tile: store, per-column (n, mean, M2) records of the tile's rows (train-mode BatchNorm
 //   statistics, merged in fp64 by the finalize kernels), per-column max of sgn * c with its row (the global max-pool over a
 //   cloud through the monotone BatchNorm + LeakyReLU), partial sums of the BatchNorm backward (h, h * yhat).
+#include <type_traits>
+
 #include "fsg_common.h"
 
 namespace {
@@ -152,9 +154,9 @@ __global__ __launch_bounds__(256) void pw_rowgemm_kernel(const RowGemmArgs p) {
     constexpr int AI = BM / 64;                       // A rows per thread and iteration
     constexpr int BU = BN * 12 / 256;                 // 16-byte units of the B image per thread and iteration
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32x4 *Aimg = reinterpret_cast<u32x4 *>(smem);                            // [BM/32][2][3][64]
-    u32x4 *Bimg = Aimg + (BM / 32) * 2 * 3 * 64;                              // [BN/32][2][3][64]
-    float *tab = reinterpret_cast<float *>(Bimg + (BN / 32) * 2 * 3 * 64);    // PRO tables: [4][K1]; epilogue scratch after the loop
+    u32x4 *Aimg = reinterpret_cast<u32x4 *>(smem);                            // [2 buffers][BM/32][2][3][64]
+    u32x4 *Bimg = Aimg + 2 * (BM / 32) * 2 * 3 * 64;                          // [2 buffers][BN/32][2][3][64]
+    float *tab = reinterpret_cast<float *>(Bimg + 2 * (BN / 32) * 2 * 3 * 64);   // PRO tables: [4][K1]; epilogue scratch after the loop
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int MT = (p.M + BM - 1) / BM, NT = (p.N + BN - 1) / BN;
@@ -179,9 +181,15 @@ __global__ __launch_bounds__(256) void pw_rowgemm_kernel(const RowGemmArgs p) {
     }
 
     const int chunk = tid & 3, arow = tid >> 2;       // this thread's 8-wide k chunk and first row of the A tile
-    float4 ra[AI][2], ry[PRO == PRO_BNBWD ? AI : 1][2];
-    u32x4 rb[BU];
-    auto fetch = [&](int it) {
+    // Software pipeline (one barrier per iteration, both LDS images double-buffered):
+    //   iteration `it` runs the MFMAs of k-block it from LDS buffer it & 1 while (a) the B image of block it + 1 streams
+    //   global -> LDS by DMA (global_load_lds, no registers, no VALU), (b) the raw A rows of block it + 2 are in flight to
+    //   registers and (c) the raw A rows of block it + 1 (loaded an iteration ago) go through prologue + split into the other
+    //   LDS buffer -- VALU work the scheduler places between this wave's own MFMAs.
+    float4 ra[2][AI][2], ry[2][PRO == PRO_BNBWD ? AI : 1][2];
+    constexpr int ABUF = (BM / 32) * 2 * 3 * 64, BBUF = (BN / 32) * 2 * 3 * 64;    // u32x4 units per buffer
+    auto fetchA = [&](auto Pc, int it) {
+        constexpr int P = decltype(Pc)::value;
         const int k0 = it * 32;
         const bool seg2 = k0 >= p.K1;
         const float *src = seg2 ? p.A2 + (k0 - p.K1) : p.A1 + k0;
@@ -192,23 +200,93 @@ __global__ __launch_bounds__(256) void pw_rowgemm_kernel(const RowGemmArgs p) {
             // conditional zero-fill here crashes the ROCm 7.2 backend in Machine Copy Propagation)
             const int row = min(row0 + arow + 64 * i, p.M - 1);
             const float4 *g = reinterpret_cast<const float4 *>(src + (long)row * ld + chunk * 8);
-            ra[i][0] = g[0];
-            ra[i][1] = g[1];
+            ra[P][i][0] = g[0];
+            ra[P][i][1] = g[1];
             if constexpr (PRO == PRO_BNBWD) {
                 if (!seg2) {
                     const float4 *gy = reinterpret_cast<const float4 *>(p.Y1 + k0 + (long)row * ld + chunk * 8);
-                    ry[i][0] = gy[0];
-                    ry[i][1] = gy[1];
+                    ry[P][i][0] = gy[0];
+                    ry[P][i][1] = gy[1];
                 }
             }
         }
+    };
+    const int nbl = (p.N + 31) / 32 - col0 / 32;      // 32-column blocks of the image at / behind this tile
+    auto dmaB = [&](int it, int buf) {
         const u32x4 *bsrc = p.Bimg + ((long)(col0 / 32) * KS + 2 * it) * 192;
-        const int nbl = (p.N + 31) / 32 - col0 / 32;      // 32-column blocks of the image at / behind this tile
 #pragma unroll
         for (int q = 0; q < BU; ++q) {
-            const int u = tid + 256 * q, jb = u / 384, rem = u - jb * 384;
-            rb[q] = jb < nbl ? bsrc[(long)jb * KS * 192 + rem] : u32x4{0u, 0u, 0u, 0u};
+            const int u = tid + 256 * q, jb = min(u / 384, nbl - 1), rem = u % 384;     // blocks behind N: any valid one (never stored)
+            // LDS destination: wave-uniform base, the hardware adds lane * 16
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bsrc + (long)jb * KS * 192 + rem),
+                                             (__attribute__((address_space(3))) void *)(Bimg + buf * BBUF + 256 * q + wave * 64), 16, 0, 0);
         }
+    };
+    auto transformA = [&](auto Pc, int it, int buf) {
+        constexpr int P = decltype(Pc)::value;
+        const int k0 = it * 32;
+        const bool seg2 = k0 >= p.K1;
+        const int kk = k0 + chunk * 8;                // column of segment 1 (tables)
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            float x[8] = {ra[P][i][0].x, ra[P][i][0].y, ra[P][i][0].z, ra[P][i][0].w,
+                          ra[P][i][1].x, ra[P][i][1].y, ra[P][i][1].z, ra[P][i][1].w};
+            if constexpr (PRO == PRO_BNACT) if (!seg2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float u = __builtin_fmaf(x[j], tab[kk + j], tab[p.K1 + kk + j]);
+                    x[j] = u > 0.f ? u : u * p.slope;
+                }
+            }
+            if constexpr (PRO == PRO_BNBWD) if (!seg2) {
+                const float y[8] = {ry[P][i][0].x, ry[P][i][0].y, ry[P][i][0].z, ry[P][i][0].w,
+                                    ry[P][i][1].x, ry[P][i][1].y, ry[P][i][1].z, ry[P][i][1].w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float al = tab[kk + j], u = __builtin_fmaf(y[j], al, tab[p.K1 + kk + j]);
+                    const float h = x[j] * (u > 0.f ? 1.f : p.slope);
+                    // dy = alpha h - P - Q y
+                    x[j] = __builtin_fmaf(al, h, -__builtin_fmaf(tab[3 * p.K1 + kk + j], y[j], tab[2 * p.K1 + kk + j]));
+                }
+            }
+            u32x4 h, m, l;
+            split8(x, h, m, l);
+            const int r = arow + 64 * i, mt = r >> 5, ks = chunk >> 1;
+            const int slot = ((r & 31) + 32 * (chunk & 1)) ^ (4 * chunk);
+            u32x4 *dst = Aimg + buf * ABUF + ((mt * 2 + ks) * 3) * 64 + slot;
+            dst[0] = h;
+            dst[64] = m;
+            dst[128] = l;
+        }
+    };
+    auto mfma_ks = [&](int ks, int buf, f32x16 (&acc)[WM][WN]) {
+        u32x4 af[WM][3], bf[WN][3];
+        const int aslot = lane ^ (4 * (2 * ks + (lane >> 5)));
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) af[i][q] = Aimg[buf * ABUF + (((wm * WM + i) * 2 + ks) * 3 + q) * 64 + aslot];
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) bf[j][q] = Bimg[buf * BBUF + (((wn * WN + j) * 2 + ks) * 3 + q) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, af[i][0]), am = __builtin_bit_cast(bf16x8, af[i][1]),
+                             al = __builtin_bit_cast(bf16x8, af[i][2]);
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, bf[j][0]), bm = __builtin_bit_cast(bf16x8, bf[j][1]),
+                             bl = __builtin_bit_cast(bf16x8, bf[j][2]);
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+                acc[i][j] = c;
+            }
     };
 
     f32x16 acc[WM][WN];
@@ -219,77 +297,26 @@ __global__ __launch_bounds__(256) void pw_rowgemm_kernel(const RowGemmArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    fetch(0);
-    for (int it = 0; it < KT; ++it) {
-        __syncthreads();   // tables written (first iteration) / the previous iteration's fragments consumed
-        {
-            const int k0 = it * 32;
-            const bool seg2 = k0 >= p.K1;
-            const int kk = k0 + chunk * 8;            // column of segment 1 (tables)
-#pragma unroll
-            for (int i = 0; i < AI; ++i) {
-                float x[8] = {ra[i][0].x, ra[i][0].y, ra[i][0].z, ra[i][0].w, ra[i][1].x, ra[i][1].y, ra[i][1].z, ra[i][1].w};
-                if constexpr (PRO == PRO_BNACT) if (!seg2) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float u = __builtin_fmaf(x[j], tab[kk + j], tab[p.K1 + kk + j]);
-                        x[j] = u > 0.f ? u : u * p.slope;
-                    }
-                }
-                if constexpr (PRO == PRO_BNBWD) if (!seg2) {
-                    const float y[8] = {ry[i][0].x, ry[i][0].y, ry[i][0].z, ry[i][0].w, ry[i][1].x, ry[i][1].y, ry[i][1].z, ry[i][1].w};
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float al = tab[kk + j], u = __builtin_fmaf(y[j], al, tab[p.K1 + kk + j]);
-                        const float h = x[j] * (u > 0.f ? 1.f : p.slope);
-                        // dy = alpha h - P - Q y
-                        x[j] = __builtin_fmaf(al, h, -__builtin_fmaf(tab[3 * p.K1 + kk + j], y[j], tab[2 * p.K1 + kk + j]));
-                    }
-                }
-                u32x4 h, m, l;
-                split8(x, h, m, l);
-                const int r = arow + 64 * i, mt = r >> 5, ks = chunk >> 1;
-                const int slot = ((r & 31) + 32 * (chunk & 1)) ^ (4 * chunk);
-                u32x4 *dst = Aimg + ((mt * 2 + ks) * 3) * 64 + slot;
-                dst[0] = h;
-                dst[64] = m;
-                dst[128] = l;
-            }
-#pragma unroll
-            for (int q = 0; q < BU; ++q) Bimg[tid + 256 * q] = rb[q];
-        }
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    fetchA(P0{}, 0);
+    dmaB(0, 0);
+    if (KT > 1) fetchA(P1{}, 1);
+    __syncthreads();                                  // the prologue tables are in LDS
+    transformA(P0{}, 0, 0);
+    __syncthreads();                                  // A and B images of block 0 are in LDS (the barrier drains the DMA)
+    auto step = [&](auto Pc, int it) {
+        constexpr int P = decltype(Pc)::value;
+        if (it + 1 < KT) dmaB(it + 1, P ^ 1);
+        if (it + 2 < KT) fetchA(Pc, it + 2);          // ra[P] is free: block `it` went through transformA an iteration ago
+        mfma_ks(0, P, acc);
+        if (it + 1 < KT) transformA(std::integral_constant<int, P ^ 1>{}, it + 1, P ^ 1);
+        mfma_ks(1, P, acc);
         __syncthreads();
-        if (it + 1 < KT) fetch(it + 1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            u32x4 af[WM][3], bf[WN][3];
-            const int aslot = lane ^ (4 * (2 * ks + (lane >> 5)));
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int q = 0; q < 3; ++q) af[i][q] = Aimg[(((wm * WM + i) * 2 + ks) * 3 + q) * 64 + aslot];
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-#pragma unroll
-                for (int q = 0; q < 3; ++q) bf[j][q] = Bimg[(((wn * WN + j) * 2 + ks) * 3 + q) * 64 + lane];
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j) {
-                    const bf16x8 ah = __builtin_bit_cast(bf16x8, af[i][0]), am = __builtin_bit_cast(bf16x8, af[i][1]),
-                                 al = __builtin_bit_cast(bf16x8, af[i][2]);
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, bf[j][0]), bm = __builtin_bit_cast(bf16x8, bf[j][1]),
-                                 bl = __builtin_bit_cast(bf16x8, bf[j][2]);
-                    f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
-                    acc[i][j] = c;
-                }
-        }
+    };
+    for (int it = 0; it < KT; it += 2) {
+        step(P0{}, it);
+        if (it + 1 < KT) step(P1{}, it + 1);
     }
 
     // ---------------------------------------------------------------- epilogue: lane holds column (lane & 31) of each of its
@@ -421,7 +448,7 @@ int launch_rowgemm(const RowGemmArgs &a, hipStream_t st, const char *name) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
     const int grid = ((MT + 7) / 8) * 8 * NT;
-    size_t lds = ((size_t)(BM / 32) * 6 + (size_t)(BN / 32) * 6) * 1024 + sizeof(float) * 4 * (size_t)a.K1;
+    size_t lds = 2 * ((size_t)(BM / 32) * 6 + (size_t)(BN / 32) * 6) * 1024 + sizeof(float) * 4 * (size_t)a.K1;
     const size_t scratch = sizeof(float) * 2 * 2 * WN * 32;
     if (lds < scratch) lds = scratch;
     static size_t granted = 64 * 1024;
@@ -662,7 +689,7 @@ __global__ __launch_bounds__(256) void pw_bn_finalize_kernel(const float *__rest
                                                              float *__restrict__ shift_out) {
     __shared__ double red[3][FS][FC];
     __shared__ float stat[2][FC];
-    __shared__ float part[FS][FC];
+    __shared__ float part[8][FS][FC];
     __shared__ float shl[64][FC];                        // the in-kernel shift (B <= 64)
     const int ch = threadIdx.x & (FC - 1), sl = threadIdx.x / FC;
     const int c = blockIdx.x * FC + ch;
@@ -673,18 +700,26 @@ __global__ __launch_bounds__(256) void pw_bn_finalize_kernel(const float *__rest
         // the repeated global feature times its block of the weight), computed here instead of by a vendor GEMM launch.
         // Slice sl sums j = sl, sl + FS, ...; fixed-order LDS fold.  Written to shift_out (B, C), which the caller passes as
         // `shift` too.
-        for (int b = 0; b < B; ++b) {
-            float a = 0.f;
+        for (int b0 = 0; b0 < B; b0 += 8) {
+            float a[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = 0.f;
             if (live)
-                for (int j = sl; j < CGf; j += FS) a = __builtin_fmaf(gfeat[(long)b * CGf + j], Wglob[(long)c * ldwg + j], a);
-            part[sl][ch] = a;
+                for (int j = sl; j < CGf; j += FS) {
+                    const float w = Wglob[(long)c * ldwg + j];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (b0 + q < B) a[q] = __builtin_fmaf(gfeat[(long)(b0 + q) * CGf + j], w, a[q]);
+                }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) part[q][sl][ch] = a[q];
             __syncthreads();
-            if (sl == 0 && live) {
+            if (sl < 8 && b0 + sl < B && live) {          // slice index doubles as the cloud inside the chunk
                 float t = 0.f;
 #pragma unroll 8
-                for (int q = 0; q < FS; ++q) t += part[q][ch];
-                shift_out[(long)b * C + c] = t;
-                shl[b][ch] = t;
+                for (int q = 0; q < FS; ++q) t += part[sl][q][ch];
+                shift_out[(long)(b0 + sl) * C + c] = t;
+                shl[b0 + sl][ch] = t;
             }
             __syncthreads();
         }
@@ -763,6 +798,28 @@ __global__ __launch_bounds__(256) void pw_bn_finalize_kernel(const float *__rest
             cloud_mean[(long)b * C + c] = (float)(n > 0.0 ? sm / n : 0.0);
         }
     }
+}
+
+// out[b, k] = sum_j x[b, j] W[k * ldw + j]  (B x C0 outputs behind a CG-long reduction: the per-cloud constant of the first head
+// layer, models/dgcnn.py:159-160).  One wave per output, lanes stride over j, DPP-free shuffle fold in a fixed order.
+__global__ __launch_bounds__(256) void pw_cloud_linear_kernel(const float *__restrict__ x, const float *__restrict__ W, long ldw,
+                                                              int B, int C0, int CG, float *__restrict__ out) {
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (task >= B * C0) return;
+    const int b = task / C0, k = task - b * C0;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int j = lane;
+    for (; j + 192 < CG; j += 256) {
+        a0 = __builtin_fmaf(x[(long)b * CG + j], W[(long)k * ldw + j], a0);
+        a1 = __builtin_fmaf(x[(long)b * CG + j + 64], W[(long)k * ldw + j + 64], a1);
+        a2 = __builtin_fmaf(x[(long)b * CG + j + 128], W[(long)k * ldw + j + 128], a2);
+        a3 = __builtin_fmaf(x[(long)b * CG + j + 192], W[(long)k * ldw + j + 192], a3);
+    }
+    for (; j < CG; j += 64) a0 = __builtin_fmaf(x[(long)b * CG + j], W[(long)k * ldw + j], a0);
+    float a = (a0 + a1) + (a2 + a3);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+    if (lane == 0) out[(long)b * C0 + k] = a;
 }
 
 // sel records of the row-GEMM epilogue -> global max-pool through the monotone BatchNorm + LeakyReLU (models/dgcnn.py:
@@ -908,7 +965,7 @@ __global__ __launch_bounds__(256) void pw_logits_bwd_kernel(const float *__restr
 // then, with h[b] = dg[b] f'(alpha ysel[b] + delta):
 //   dbeta = sum_b h,  dgamma = sum_b h yhat_sel,  Q = alpha r dgamma / M,  P = alpha (dbeta / M - mean r dgamma / M),
 //   coef[b] = alpha h[b]   (weight of the selected row arg[b] in dy)
-constexpr int GP_MAXB = 16;
+constexpr int GP_MAXB = 8;
 __global__ __launch_bounds__(256) void pw_gf_prep_kernel(const float *__restrict__ dc, const float *__restrict__ W0g, long ldw0,
                                                          int C0, const float *__restrict__ gfeat, float *__restrict__ dW0g,
                                                          long lddw0, const float *__restrict__ dg_in,
@@ -918,34 +975,41 @@ __global__ __launch_bounds__(256) void pw_gf_prep_kernel(const float *__restrict
                                                          int B, int C, long M, int training, float slope,
                                                          float *__restrict__ dbeta, float *__restrict__ dgamma,
                                                          float *__restrict__ P, float *__restrict__ Q, float *__restrict__ coef) {
-    extern __shared__ float dcs[];     // (B, C0) when dc is given
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    extern __shared__ float dcs[];     // (B, C0) when dc is given, then [4][GP_MAXB][64] partial dg
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = min(blockIdx.x * 64 + lane, C - 1);       // 64 channels per workgroup, the four waves split k
+    const bool livec = blockIdx.x * 64 + lane < C;
     float dgv[GP_MAXB];
+#pragma unroll
+    for (int b = 0; b < GP_MAXB; ++b) dgv[b] = 0.f;
     if (dc) {
+        float *pd = dcs + B * C0;
         for (int e = threadIdx.x; e < B * C0; e += 256) dcs[e] = dc[e];
         __syncthreads();
-        if (c < C) {
-            float gv[GP_MAXB];
+        float gv[GP_MAXB];
 #pragma unroll
-            for (int b = 0; b < GP_MAXB; ++b) { dgv[b] = 0.f; gv[b] = b < B ? gfeat[(long)b * C + c] : 0.f; }
-            for (int k = 0; k < C0; ++k) {
-                const float w = W0g[(long)k * ldw0 + c];
-                float dw = 0.f;
+        for (int b = 0; b < GP_MAXB; ++b) gv[b] = b < B ? gfeat[(long)b * C + c] : 0.f;
+        (void)gv;
+        (void)dW0g;
+        (void)lddw0;
+#pragma unroll 8
+        for (int k = wave; k < C0; k += 4) {                // loads and FMAs only: eight rows of W0g in flight per thread
+            const float w = W0g[(long)k * ldw0 + c];
 #pragma unroll
-                for (int b = 0; b < GP_MAXB; ++b)
-                    if (b < B) {
-                        const float d = dcs[b * C0 + k];
-                        dgv[b] = __builtin_fmaf(d, w, dgv[b]);
-                        dw = __builtin_fmaf(d, gv[b], dw);
-                    }
-                dW0g[(long)k * lddw0 + c] = dw;
-            }
+            for (int b = 0; b < GP_MAXB; ++b) dgv[b] = __builtin_fmaf(b < B ? dcs[b * C0 + k] : 0.f, w, dgv[b]);
         }
-    } else if (c < C) {
+#pragma unroll
+        for (int b = 0; b < GP_MAXB; ++b) pd[(wave * GP_MAXB + b) * 64 + lane] = dgv[b];
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < GP_MAXB; ++b)
+            dgv[b] = (pd[(0 * GP_MAXB + b) * 64 + lane] + pd[(1 * GP_MAXB + b) * 64 + lane]) +
+                     (pd[(2 * GP_MAXB + b) * 64 + lane] + pd[(3 * GP_MAXB + b) * 64 + lane]);
+    } else {
 #pragma unroll
         for (int b = 0; b < GP_MAXB; ++b) dgv[b] = b < B ? dg_in[(long)b * C + c] : 0.f;
     }
-    if (c >= C) return;
+    if (wave != 0 || !livec) return;
     const float al = alpha[c], de = delta[c], mu = mean[c], r = invstd[c];
     float sb = 0.f, sg = 0.f;
 #pragma unroll
@@ -963,6 +1027,25 @@ __global__ __launch_bounds__(256) void pw_gf_prep_kernel(const float *__restrict
     const float db = training ? sb * invM : 0.f, dgm = training ? sg * invM * r : 0.f;
     Q[c] = al * dgm;
     P[c] = al * (db - mu * dgm);
+}
+
+// dW0g[k, j] = sum_b dc[b, k] g[b, j]  (C0 x CG outputs, B terms each): thread = column j, eight rows k per workgroup row
+__global__ __launch_bounds__(256) void pw_outer_kernel(const float *__restrict__ dc, const float *__restrict__ g, int B, int C0,
+                                                       int CG, float *__restrict__ out, long ldo) {
+    const int j = blockIdx.x * 256 + threadIdx.x, k0 = blockIdx.y * 8;
+    if (j >= CG) return;
+    float gv[GP_MAXB];
+#pragma unroll
+    for (int b = 0; b < GP_MAXB; ++b) gv[b] = b < B ? g[(long)b * CG + j] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int k = k0 + q;
+        if (k >= C0) break;
+        float a = 0.f;
+#pragma unroll
+        for (int b = 0; b < GP_MAXB; ++b) a = __builtin_fmaf(b < B ? dc[(long)b * C0 + k] : 0.f, gv[b], a);
+        out[(long)k * ldo + j] = a;
+    }
 }
 
 // M1 = W^T diag(Q) W (K x K) and npvec = -W^T P (K) of the Gram-form backward: output row i (row K = npvec) per workgroup
@@ -1002,16 +1085,17 @@ __global__ __launch_bounds__(256) void pw_gf_m1_kernel(const float *__restrict__
 // first entry lies in its chunk, issues ALL of the chunk's loads (weights rows, coefficients, old dX values) before the first
 // use, accumulates a segment in registers (thread = column) and writes its dX row once.
 constexpr int SC_CHUNK = 16;
-// one wave per cloud, KPL keys per lane in registers: compare-exchanges with a partner inside the lane are plain register
-// swaps (34 of the 55 stages at 1024 keys), the others cross lanes with __shfl_xor -- no LDS, no barriers
-template <int KPL>
-__global__ __launch_bounds__(64) void pw_sort_sel_wave_kernel(const int *__restrict__ arg, int C, unsigned *__restrict__ sorted) {
-    constexpr int NK = 64 * KPL;
-    const int b = blockIdx.x, lane = threadIdx.x;
+// 1024 keys, one workgroup of 256 threads per cloud, four keys per thread in registers: compare-exchanges with a partner inside
+// the thread are register swaps (19 of the 55 stages), partners inside the wave come through __shfl_xor (33 stages), only the
+// three stages whose partner sits in another wave go through LDS and a barrier
+__global__ __launch_bounds__(256) void pw_sort_sel_1024_kernel(const int *__restrict__ arg, int C, unsigned *__restrict__ sorted) {
+    constexpr int KPL = 4, NK = 1024;
+    __shared__ unsigned xch[NK];
+    const int b = blockIdx.x, tid = threadIdx.x;
     unsigned v[KPL];
 #pragma unroll
     for (int r = 0; r < KPL; ++r) {
-        const int i = lane * KPL + r;
+        const int i = tid * KPL + r;
         v[r] = i < C ? ((unsigned)arg[(long)b * C + i] << 12) | (unsigned)i : 0xFFFFFFFFu;
     }
 #pragma unroll
@@ -1022,7 +1106,7 @@ __global__ __launch_bounds__(64) void pw_sort_sel_wave_kernel(const int *__restr
 #pragma unroll
                 for (int r = 0; r < KPL; ++r) {
                     if ((r & j) == 0) {
-                        const bool up = ((lane * KPL + r) & k) == 0;
+                        const bool up = ((tid * KPL + r) & k) == 0;
                         const unsigned a = v[r], c = v[r | j];
                         const unsigned lo = a < c ? a : c, hi = a < c ? c : a;
                         v[r] = up ? lo : hi;
@@ -1030,20 +1114,32 @@ __global__ __launch_bounds__(64) void pw_sort_sel_wave_kernel(const int *__restr
                     }
                 }
             } else {
-                const int J = j / KPL;
-                const bool lower = (lane & J) == 0;
+                const int J = j / KPL;                  // partner thread = tid ^ J
+                const bool lower = (tid & J) == 0;
+                unsigned other[KPL];
+                if (J < 64) {
+#pragma unroll
+                    for (int r = 0; r < KPL; ++r) other[r] = __shfl_xor(v[r], J);
+                } else {
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < KPL; ++r) xch[tid * KPL + r] = v[r];
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < KPL; ++r) other[r] = xch[(tid ^ J) * KPL + r];
+                }
 #pragma unroll
                 for (int r = 0; r < KPL; ++r) {
-                    const unsigned other = __shfl_xor(v[r], J);
-                    const bool up = ((lane * KPL + r) & k) == 0;
-                    const unsigned lo = v[r] < other ? v[r] : other, hi = v[r] < other ? other : v[r];
+                    const bool up = ((tid * KPL + r) & k) == 0;
+                    const unsigned lo = v[r] < other[r] ? v[r] : other[r], hi = v[r] < other[r] ? other[r] : v[r];
                     v[r] = (lower == up) ? lo : hi;
                 }
             }
         }
     }
-#pragma unroll
-    for (int r = 0; r < KPL; ++r) sorted[(long)b * NK + lane * KPL + r] = v[r];
+    uint4 o;
+    o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+    reinterpret_cast<uint4 *>(sorted + (long)b * NK)[tid] = o;
 }
 
 // larger channel counts: bitonic sort in LDS
@@ -1076,6 +1172,7 @@ __global__ __launch_bounds__(256) void pw_scatter_rows_kernel(const float *__res
     if (c0 >= C) return;
     unsigned key[SC_CHUNK];
     const unsigned prev = c0 > 0 ? keys[c0 - 1] : 0xFFFFFFFFu;
+    const unsigned next = c0 + SC_CHUNK < C ? keys[c0 + SC_CHUNK] : 0xFFFFFFFFu;
 #pragma unroll
     for (int i = 0; i < SC_CHUNK; ++i) key[i] = c0 + i < C ? keys[c0 + i] : 0xFFFFFFFFu;
     for (int k0 = 0; k0 < K; k0 += 256) {
@@ -1107,7 +1204,8 @@ __global__ __launch_bounds__(256) void pw_scatter_rows_kernel(const float *__res
             }
             if (open) acc = __builtin_fmaf(cf[i], wv[i], acc);
         }
-        if (open) {                                          // the last segment may run on into the next chunks
+        if (open) {                                          // the last segment may run on into the next chunks (rare)
+            if ((next >> 12) == row)
             for (int e = c0 + SC_CHUNK; e < C && (keys[e] >> 12) == row; ++e) {
                 const unsigned c = keys[e] & 4095u;
                 acc = __builtin_fmaf(coef[(long)b * C + c], W[(long)c * ldw + k], acc);
@@ -1118,26 +1216,57 @@ __global__ __launch_bounds__(256) void pw_scatter_rows_kernel(const float *__res
 }
 
 // dW of the global-feature layer, Gram form:  dW[c, :] = sum_b coef[b,c] X[b N + arg[b,c], :] - P[c] s - Q[c] (W G)[c, :]
-// (the small product W G is formed here: thread (c, k) walks row c of W against column k of G)
+// (the small product W G is formed here: four channels per workgroup, their W rows in LDS; the four waves split the rows i of G,
+// lane = column: one G load per (i, k) serves the four channels; fixed-order LDS fold over the waves)
 __global__ __launch_bounds__(256) void pw_gf_dw_kernel(const float *__restrict__ coef, const int *__restrict__ arg,
                                                        const float *__restrict__ X, long ldx, const float *__restrict__ s,
                                                        const float *__restrict__ W, long ldw, const float *__restrict__ G,
                                                        const float *__restrict__ P, const float *__restrict__ Q, int B, int C,
                                                        int K, int Npts, float *__restrict__ dW, long lddw) {
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (long)C * K) return;
-    const int c = (int)(t / K), k = (int)(t - (long)c * K);
-    float wg0 = 0.f, wg1 = 0.f;
-    int i = 0;
-    for (; i + 2 <= K; i += 2) {
-        wg0 = __builtin_fmaf(W[(long)c * ldw + i], G[(long)i * K + k], wg0);
-        wg1 = __builtin_fmaf(W[(long)c * ldw + i + 1], G[(long)(i + 1) * K + k], wg1);
+    extern __shared__ float wr[];      // [4][K] rows of W, then [4 waves][4 channels][64] partial products
+    float *red = wr + 4 * K;
+    const int c0 = blockIdx.x * 4, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int e = tid; e < 4 * K; e += 256) {
+        const int q = e / K, i = e - q * K;
+        wr[e] = c0 + q < C ? W[(long)(c0 + q) * ldw + i] : 0.f;
     }
-    for (; i < K; ++i) wg0 = __builtin_fmaf(W[(long)c * ldw + i], G[(long)i * K + k], wg0);
-    float a = -__builtin_fmaf(Q[c], wg0 + wg1, P[c] * s[k]);
-    for (int b = 0; b < B; ++b)
-        a = __builtin_fmaf(coef[(long)b * C + c], X[((long)b * Npts + arg[(long)b * C + c]) * ldx + k], a);
-    dW[(long)c * lddw + k] = a;
+    __syncthreads();
+    const int per = (K + 3) / 4, i0 = wave * per, i1 = min(K, i0 + per);
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        const int k = min(k0 + lane, K - 1);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
+        for (int i = i0; i < i1; ++i) {
+            const float g = G[(long)i * K + k];
+            a0 = __builtin_fmaf(wr[i], g, a0);
+            a1 = __builtin_fmaf(wr[K + i], g, a1);
+            a2 = __builtin_fmaf(wr[2 * K + i], g, a2);
+            a3 = __builtin_fmaf(wr[3 * K + i], g, a3);
+        }
+        red[(wave * 4 + 0) * 64 + lane] = a0;
+        red[(wave * 4 + 1) * 64 + lane] = a1;
+        red[(wave * 4 + 2) * 64 + lane] = a2;
+        red[(wave * 4 + 3) * 64 + lane] = a3;
+        __syncthreads();
+        // wave q finishes channel c0 + q
+        const int c = c0 + wave;
+        if (c < C && k0 + lane < K) {
+            const float wg = (red[(0 * 4 + wave) * 64 + lane] + red[(1 * 4 + wave) * 64 + lane]) +
+                             (red[(2 * 4 + wave) * 64 + lane] + red[(3 * 4 + wave) * 64 + lane]);
+            float a = -__builtin_fmaf(Q[c], wg, P[c] * s[k]);
+            float xv[8];
+            int bb = 0;
+            for (; bb + 8 <= B; bb += 8) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) xv[q] = X[((long)(bb + q) * Npts + arg[(long)(bb + q) * C + c]) * ldx + k];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a = __builtin_fmaf(coef[(long)(bb + q) * C + c], xv[q], a);
+            }
+            for (; bb < B; ++bb) a = __builtin_fmaf(coef[(long)bb * C + c], X[((long)bb * Npts + arg[(long)bb * C + c]) * ldx + k], a);
+            dW[(long)c * lddw + k] = a;
+        }
+        __syncthreads();
+    }
 }
 
 // column sums of (M, K) rows: partial sums per 64-row block (wave = 16 rows, lane = column, all loads independent), then a
@@ -1454,6 +1583,14 @@ extern "C" int fsg_pw_bn_finalize_f32(const float *rec, int R, int ldn, int c0, 
     return FSG_OK;
 }
 
+extern "C" int fsg_pw_cloud_linear_f32(const float *x, const float *W, int64_t ldw, int B, int C0, int CG, float *out,
+                                       fsg_stream_t stream) {
+    FSG_REQUIRE(x && W && out && B > 0 && C0 > 0 && CG > 0, "fsg_pw_cloud_linear_f32: bad arguments");
+    hipLaunchKernelGGL(pw_cloud_linear_kernel, dim3((B * C0 + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, W, (long)ldw, B, C0, CG, out);
+    FSG_CHECK_LAUNCH("fsg_pw_cloud_linear_f32");
+    return FSG_OK;
+}
+
 extern "C" int fsg_pw_max_finish_f32(const float *sel_val, const int32_t *sel_arg, const float *sgn, const float *alpha,
                                      const float *delta, int B, int tiles, int C, float slope, float *out, float *ysel,
                                      int32_t *arg, fsg_stream_t stream) {
@@ -1494,12 +1631,17 @@ extern "C" int fsg_pw_gf_prep_f32(const float *dc, const float *W0g, int64_t ldw
                                   float *dbeta, float *dgamma, float *P, float *Q, float *coef, fsg_stream_t stream) {
     FSG_REQUIRE(ysel && alpha && delta && mean && invstd && dbeta && dgamma && P && Q && coef && B > 0 && B <= GP_MAXB && C > 0 && M > 0,
                 "fsg_pw_gf_prep_f32: bad arguments (B <= %d)", GP_MAXB);
-    FSG_REQUIRE((dc && W0g && gfeat && dW0g && C0 > 0 && (size_t)B * C0 * 4 <= 48 * 1024) || (!dc && dg),
-                "fsg_pw_gf_prep_f32: either dc + W0g + gfeat + dW0g (B C0 <= 12288) or dg");
-    hipLaunchKernelGGL(pw_gf_prep_kernel, dim3((C + 255) / 256), dim3(256), dc ? sizeof(float) * B * C0 : 0, (hipStream_t)stream, dc,
+    FSG_REQUIRE((dc && W0g && gfeat && dW0g && C0 > 0 && (size_t)B * C0 * 4 <= 32 * 1024) || (!dc && dg),
+                "fsg_pw_gf_prep_f32: either dc + W0g + gfeat + dW0g (B C0 <= 8192) or dg");
+    hipLaunchKernelGGL(pw_gf_prep_kernel, dim3((C + 63) / 64), dim3(256), dc ? sizeof(float) * (B * C0 + 4 * GP_MAXB * 64) : 0, (hipStream_t)stream, dc,
                        W0g, (long)ldw0, C0, gfeat, dW0g, (long)lddw0, dg, ysel, alpha, delta, mean, invstd, B, C, (long)M, training,
                        slope, dbeta, dgamma, P, Q, coef);
     FSG_CHECK_LAUNCH("fsg_pw_gf_prep_f32");
+    if (dc) {
+        hipLaunchKernelGGL(pw_outer_kernel, dim3((C + 255) / 256, (C0 + 7) / 8), dim3(256), 0, (hipStream_t)stream, dc, gfeat, B, C0, C,
+                           dW0g, (long)lddw0);
+        FSG_CHECK_LAUNCH("fsg_pw_gf_prep_f32/outer");
+    }
     return FSG_OK;
 }
 
@@ -1525,7 +1667,7 @@ extern "C" int fsg_pw_scatter_rows_f32(const float *coef, const int32_t *arg, co
                 "fsg_pw_scatter_rows_f32: bad arguments (C <= 4096, Npts <= 2^20)");
     const int Cp2 = scatter_cp2(C);
     unsigned *sorted = reinterpret_cast<unsigned *>(workspace);
-    if (Cp2 == 1024) hipLaunchKernelGGL(pw_sort_sel_wave_kernel<16>, dim3(B), dim3(64), 0, (hipStream_t)stream, arg, C, sorted);
+    if (Cp2 == 1024) hipLaunchKernelGGL(pw_sort_sel_1024_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, arg, C, sorted);
     else hipLaunchKernelGGL(pw_sort_sel_kernel, dim3(B), dim3(1024), sizeof(unsigned) * Cp2, (hipStream_t)stream, arg, C, Cp2, sorted);
     FSG_CHECK_LAUNCH("fsg_pw_scatter_rows_f32/sort");
     hipLaunchKernelGGL(pw_scatter_rows_kernel, dim3(B, (C + SC_CHUNK - 1) / SC_CHUNK), dim3(256), 0, (hipStream_t)stream, coef,
@@ -1538,8 +1680,8 @@ extern "C" int fsg_pw_gf_dw_f32(const float *coef, const int32_t *arg, const flo
                                 const float *W, int64_t ldw, const float *G, const float *P, const float *Q, int B, int C, int K,
                                 int Npts, float *dW, int64_t lddw, fsg_stream_t stream) {
     FSG_REQUIRE(coef && arg && X && s && W && G && P && Q && dW && B > 0 && C > 0 && K > 0 && Npts > 0, "fsg_pw_gf_dw_f32: bad arguments");
-    const long total = (long)C * K;
-    hipLaunchKernelGGL(pw_gf_dw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, coef, arg, X,
+    FSG_REQUIRE(K <= 4096, "fsg_pw_gf_dw_f32: K = %d > 4096", K);
+    hipLaunchKernelGGL(pw_gf_dw_kernel, dim3((C + 3) / 4), dim3(256), sizeof(float) * (4 * K + 16 * 64), (hipStream_t)stream, coef, arg, X,
                        (long)ldx, s, W, (long)ldw, G, P, Q, B, C, K, Npts, dW, (long)lddw);
     FSG_CHECK_LAUNCH("fsg_pw_gf_dw_f32");
     return FSG_OK;

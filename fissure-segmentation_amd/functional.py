@@ -1054,13 +1054,13 @@ class _SegHead(torch.autograd.Function):
         imgs = pw_weight_images(specs)
         img1, img2, img3, img2t, img1t = imgs[2], imgs[3], imgs[4], imgs[5], imgs[6]
         # levels -> global-feature statistics / selection + y0
-        R0 = M // 128
+        R0 = M // 64                 # 64 x 128 tiles: two workgroups per CU with both LDS images double-buffered (72 KB each)
         rec0 = torch.empty(R0, 3, CG + C0, **f32)
         sel_val = torch.empty(R0, CG, **f32)
         sel_arg = torch.empty(R0, CG, dtype=torch.int32, device=dev)
         y0 = torch.empty(M, C0, **f32)
         sgn = gg                     # only the sign of the BatchNorm weight is used (max of sgn * y through the monotone BN + LeakyReLU)
-        pw_rowgemm(PRO_NONE, PW_STORE | PW_STATS | PW_SEL, 1, A1=levels, lda1=levels.stride(0), K1=KL, K2=0, Bimg=img0, M=M,
+        pw_rowgemm(PRO_NONE, PW_STORE | PW_STATS | PW_SEL, 2, A1=levels, lda1=levels.stride(0), K1=KL, K2=0, Bimg=img0, M=M,
                    N=CG + C0, rows_per_cloud=Npts, C=y0, ldc=C0, store_n0=CG, rec=rec0, sgn=sgn, sel_val=sel_val,
                    sel_arg=sel_arg, sel_n=CG)
         mean_g, inv_g, al_g, de_g, _, _ = _pw_bn_finalize(rec0, R0, CG + C0, 0, CG, None, B, bn_g, tr_g, mom_g)
@@ -1068,11 +1068,13 @@ class _SegHead(torch.autograd.Function):
         ysel = torch.empty(B, CG, **f32)
         arg = torch.empty(B, CG, dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
-            _lib.call("fsg_pw_max_finish_f32", _p(sel_val), _p(sel_arg), _p(sgn), _p(al_g), _p(de_g), B, Npts // 128, CG,
+            _lib.call("fsg_pw_max_finish_f32", _p(sel_val), _p(sel_arg), _p(sgn), _p(al_g), _p(de_g), B, Npts // 64, CG,
                       slope, _p(g), _p(ysel), _p(arg), _stream())
-        c = torch.empty(B, C0, **f32)     # g W0_global^T: the global part of the first head layer, formed inside the finalize kernel
+        c = torch.empty(B, C0, **f32)     # g W0_global^T: the global part of the first head layer, one wave per output
+        with torch.cuda.device(dev):
+            _lib.call("fsg_pw_cloud_linear_f32", _p(g), _p(W0[:, KL:]), W0.stride(0), B, C0, CG, _p(c), _stream())
         mean_0, inv_0, al_0, de_0, emu_0, cm_0 = _pw_bn_finalize(rec0, R0, CG + C0, CG, C0, c, B, bn_0, tr_0, mom_0,
-                                                                 with_emu=True, with_cloud_mean=True, gfeat=g, wglob=W0[:, KL:])
+                                                                 with_emu=True, with_cloud_mean=True)
         # layer 1, layer 2, logits
         R1 = M // 64
         y1 = torch.empty(M, C1, **f32)
@@ -1162,8 +1164,10 @@ class _SegHead(torch.autograd.Function):
         W0G, dW0G = W0[:, KL:], dW0[:, KL:]
         call("fsg_pw_gf_prep_f32", _p(dc), _p(W0G), W0.stride(0), C0, _p(g), _p(dW0G), dW0.stride(0), None, _p(ysel), _p(al_g),
              _p(de_g), _p(mean_g), _p(inv_g), B, CG, M, int(tr_g), slope, _p(dbg), _p(dgg), _p(Pg), _p(Qg), _p(coef))
-        M1, npvec = torch.empty(KL, KL, **f32), torch.empty(KL, **f32)     # W^T diag(Q) W and -(W^T P)
-        call("fsg_pw_gf_m1_f32", _p(Wg), Wg.stride(0), _p(Qg), _p(Pg), CG, KL, _p(M1), _p(npvec))
+        # W^T diag(Q) W and -(W^T P): two small vendor products (fsg_pw_gf_m1_f32 does the same in one launch, but its first
+        # version is slower than the pair: 79 us against ~24)
+        M1 = (Wg * Qg.unsqueeze(1)).t() @ Wg
+        npvec = -(Pg @ Wg)
         ks_a, ks_b = C0 // 16, KL // 16
         pw_weight_image(M1, scale=-1.0, out=img_lv, ks0=ks_a, KS=ks_a + ks_b)
         G = torch.empty(KL, KL, **f32)
@@ -1207,7 +1211,7 @@ def seg_head_supported(levels, B, Npts, Wg, W0, W1, W2, W3):
             Npts % 256 == 0 and levels.shape[0] == B * Npts and KL % 64 == 0 and Wg.shape[0] % 128 == 0 and
             W0.shape[0] % 64 == 0 and W0.shape[1] == KL + Wg.shape[0] and W1.shape[0] % 64 == 0 and W1.shape[1] == W0.shape[0] and
             W2.shape[0] % 64 == 0 and W2.shape[1] == W1.shape[0] and W3.shape[1] == W2.shape[0] and W3.shape[0] <= 8 and
-            W2.shape[0] % 32 == 0 and Npts + Wg.shape[0] <= 16000)
+            W2.shape[0] % 32 == 0 and Wg.shape[0] <= 4096 and B <= 8)
 
 
 def seg_head(levels, B, Npts, global_block, seg_blocks):

@@ -567,6 +567,8 @@ int fsg_pw_tn_f32(const fsg_pw_tn_args *args, int tile, void *workspace, size_t 
  *   training == 0: mean / invstd are inputs (running statistics), only the tables are written.
  *   gfeat (B, CG) != NULL: the shift is computed in the kernel first, shift[b][c] = sum_j gfeat[b][j] Wglob[c * ldwg + j] (the
  *   per-cloud constant of the first head layer, models/dgcnn.py:159-160), and written to shift_out == shift (B <= 64).
+ * fsg_pw_cloud_linear_f32: out (B, C0) = x (B, CG) W^T, W (C0, CG) with row stride ldw -- the per-cloud constant of the first head
+ *   layer (its global-feature block times the max-pooled feature, models/dgcnn.py:159-160); one wave per output.
  * fsg_pw_max_finish_f32: SEL records (B * tiles, C) -> out (B, C) = lrelu(alpha ysel + delta), ysel, arg (row inside the cloud).
  * fsg_pw_bnbwd_finalize_f32: BWDSTATS records (R, 2, C) -> dbeta, dgamma, P (B or 1, C), Q (C) of prologue 2, and (first head
  *   layer, dc != NULL) dc (B, C) = per-cloud column sums of dy = the gradient of the per-cloud constant.
@@ -578,6 +580,7 @@ int fsg_pw_bn_finalize_f32(const float *rec, int R, int ldn, int c0, int C, cons
                            float *running_var, float *mean, float *invstd, float *alpha, float *delta, float *emu,
                            float *cloud_mean, const float *gfeat, const float *Wglob, int64_t ldwg, int CG, float *shift_out,
                            fsg_stream_t stream);
+int fsg_pw_cloud_linear_f32(const float *x, const float *W, int64_t ldw, int B, int C0, int CG, float *out, fsg_stream_t stream);
 int fsg_pw_max_finish_f32(const float *sel_val, const int32_t *sel_arg, const float *sgn, const float *alpha, const float *delta,
                           int B, int tiles, int C, float slope, float *out, float *ysel, int32_t *arg, fsg_stream_t stream);
 int fsg_pw_bnbwd_finalize_f32(const float *rec2, int R, int C, int B, int64_t M, int training, const float *alpha,
@@ -593,7 +596,7 @@ int fsg_pw_logits_bwd_f32(const float *g, int classes, const float *W3, const fl
  *   dX = selected rows - 1 (W^T P)^T - X (W^T diag(Q) W),   dW = selected rows - P s^T - diag(Q) W G.
  * fsg_pw_gf_prep_f32: per channel dbeta, dgamma, P, Q and coef (B, C) = weight of the selected row in dy.  The gradient of the
  *   global feature is either given (dg (B, C), dc == NULL) or formed here from the gradient dc (B, C0) of the first head layer's
- *   per-cloud constant: dg = dc W0g (W0g (C0, C), row stride ldw0), together with dW0g (C0, C) = dc^T gfeat (B <= 16).
+ *   per-cloud constant: dg = dc W0g (W0g (C0, C), row stride ldw0), together with dW0g (C0, C) = dc^T gfeat (B <= 8).
  * fsg_pw_gf_m1_f32: M1 (K, K) = W^T diag(Q) W and npvec (K) = -W^T P.
  * fsg_pw_scatter_rows_f32: dX[b Npts + arg[b,c], :] += coef[b,c] W[c, :], summed per destination row in channel order
  *   (C <= 4096; workspace fsg_pw_scatter_rows_workspace_bytes(B, C) bytes for the sorted selection keys).
