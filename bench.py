@@ -398,14 +398,19 @@ def main():
         # one more fwd/bwd + gradient average through the SAME launch path as the timed steps, without the update
         import numpy as np
         params = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu().numpy()
+        def local_dump():   # every rank's OWN gradient, before the collective: the average must be their mean, exactly
+            loc = opt.flat.grad if flat_sync else torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+            np.save(args.dump_check + f".rank{rank}.npy", loc.detach().cpu().numpy())
         if launch == "hipGraph replay":
             g1.replay()
+            local_dump()
             if world > 1:
                 sync_grads()
         else:
             fwd_bwd()
             if flat_sync:
                 opt.gather_grads()
+            local_dump()
             if world > 1:
                 sync_grads()
         if flat_sync:

@@ -148,15 +148,16 @@ struct RowGemmArgs {
     float *rec2;          // (M / BM, 2, N): sums of h = c f'(u) and h * yhat over the block's rows
 };
 
-template <int WM, int WN, int PRO, int EPI>
+template <int WM, int WN, int PRO, int EPI, int PIPE>
 __global__ __launch_bounds__(256) void pw_rowgemm_kernel(const RowGemmArgs p) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int AI = BM / 64;                       // A rows per thread and iteration
     constexpr int BU = BN * 12 / 256;                 // 16-byte units of the B image per thread and iteration
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32x4 *Aimg = reinterpret_cast<u32x4 *>(smem);                            // [2 buffers][BM/32][2][3][64]
-    u32x4 *Bimg = Aimg + 2 * (BM / 32) * 2 * 3 * 64;                          // [2 buffers][BN/32][2][3][64]
-    float *tab = reinterpret_cast<float *>(Bimg + 2 * (BN / 32) * 2 * 3 * 64);   // PRO tables: [4][K1]; epilogue scratch after the loop
+    constexpr int NBUF = PIPE ? 2 : 1;
+    u32x4 *Aimg = reinterpret_cast<u32x4 *>(smem);                            // [NBUF][BM/32][2][3][64]
+    u32x4 *Bimg = Aimg + NBUF * (BM / 32) * 2 * 3 * 64;                       // [NBUF][BN/32][2][3][64]
+    float *tab = reinterpret_cast<float *>(Bimg + NBUF * (BN / 32) * 2 * 3 * 64);   // PRO tables: [4][K1]; epilogue scratch after the loop
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int MT = (p.M + BM - 1) / BM, NT = (p.N + BN - 1) / BN;
@@ -181,114 +182,6 @@ __global__ __launch_bounds__(256) void pw_rowgemm_kernel(const RowGemmArgs p) {
     }
 
     const int chunk = tid & 3, arow = tid >> 2;       // this thread's 8-wide k chunk and first row of the A tile
-    // Software pipeline (one barrier per iteration, both LDS images double-buffered):
-    //   iteration `it` runs the MFMAs of k-block it from LDS buffer it & 1 while (a) the B image of block it + 1 streams
-    //   global -> LDS by DMA (global_load_lds, no registers, no VALU), (b) the raw A rows of block it + 2 are in flight to
-    //   registers and (c) the raw A rows of block it + 1 (loaded an iteration ago) go through prologue + split into the other
-    //   LDS buffer -- VALU work the scheduler places between this wave's own MFMAs.
-    float4 ra[2][AI][2], ry[2][PRO == PRO_BNBWD ? AI : 1][2];
-    constexpr int ABUF = (BM / 32) * 2 * 3 * 64, BBUF = (BN / 32) * 2 * 3 * 64;    // u32x4 units per buffer
-    auto fetchA = [&](auto Pc, int it) {
-        constexpr int P = decltype(Pc)::value;
-        const int k0 = it * 32;
-        const bool seg2 = k0 >= p.K1;
-        const float *src = seg2 ? p.A2 + (k0 - p.K1) : p.A1 + k0;
-        const long ld = seg2 ? p.lda2 : p.lda1;
-#pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            // rows behind M (a ragged last tile) re-read row M - 1: their products land in output rows that are never stored (a
-            // conditional zero-fill here crashes the ROCm 7.2 backend in Machine Copy Propagation)
-            const int row = min(row0 + arow + 64 * i, p.M - 1);
-            const float4 *g = reinterpret_cast<const float4 *>(src + (long)row * ld + chunk * 8);
-            ra[P][i][0] = g[0];
-            ra[P][i][1] = g[1];
-            if constexpr (PRO == PRO_BNBWD) {
-                if (!seg2) {
-                    const float4 *gy = reinterpret_cast<const float4 *>(p.Y1 + k0 + (long)row * ld + chunk * 8);
-                    ry[P][i][0] = gy[0];
-                    ry[P][i][1] = gy[1];
-                }
-            }
-        }
-    };
-    const int nbl = (p.N + 31) / 32 - col0 / 32;      // 32-column blocks of the image at / behind this tile
-    auto dmaB = [&](int it, int buf) {
-        const u32x4 *bsrc = p.Bimg + ((long)(col0 / 32) * KS + 2 * it) * 192;
-#pragma unroll
-        for (int q = 0; q < BU; ++q) {
-            const int u = tid + 256 * q, jb = min(u / 384, nbl - 1), rem = u % 384;     // blocks behind N: any valid one (never stored)
-            // LDS destination: wave-uniform base, the hardware adds lane * 16
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bsrc + (long)jb * KS * 192 + rem),
-                                             (__attribute__((address_space(3))) void *)(Bimg + buf * BBUF + 256 * q + wave * 64), 16, 0, 0);
-        }
-    };
-    auto transformA = [&](auto Pc, int it, int buf) {
-        constexpr int P = decltype(Pc)::value;
-        const int k0 = it * 32;
-        const bool seg2 = k0 >= p.K1;
-        const int kk = k0 + chunk * 8;                // column of segment 1 (tables)
-#pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            float x[8] = {ra[P][i][0].x, ra[P][i][0].y, ra[P][i][0].z, ra[P][i][0].w,
-                          ra[P][i][1].x, ra[P][i][1].y, ra[P][i][1].z, ra[P][i][1].w};
-            if constexpr (PRO == PRO_BNACT) if (!seg2) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float u = __builtin_fmaf(x[j], tab[kk + j], tab[p.K1 + kk + j]);
-                    x[j] = u > 0.f ? u : u * p.slope;
-                }
-            }
-            if constexpr (PRO == PRO_BNBWD) if (!seg2) {
-                const float y[8] = {ry[P][i][0].x, ry[P][i][0].y, ry[P][i][0].z, ry[P][i][0].w,
-                                    ry[P][i][1].x, ry[P][i][1].y, ry[P][i][1].z, ry[P][i][1].w};
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float al = tab[kk + j], u = __builtin_fmaf(y[j], al, tab[p.K1 + kk + j]);
-                    const float h = x[j] * (u > 0.f ? 1.f : p.slope);
-                    // dy = alpha h - P - Q y
-                    x[j] = __builtin_fmaf(al, h, -__builtin_fmaf(tab[3 * p.K1 + kk + j], y[j], tab[2 * p.K1 + kk + j]));
-                }
-            }
-            u32x4 h, m, l;
-            split8(x, h, m, l);
-            const int r = arow + 64 * i, mt = r >> 5, ks = chunk >> 1;
-            const int slot = ((r & 31) + 32 * (chunk & 1)) ^ (4 * chunk);
-            u32x4 *dst = Aimg + buf * ABUF + ((mt * 2 + ks) * 3) * 64 + slot;
-            dst[0] = h;
-            dst[64] = m;
-            dst[128] = l;
-        }
-    };
-    auto mfma_ks = [&](int ks, int buf, f32x16 (&acc)[WM][WN]) {
-        u32x4 af[WM][3], bf[WN][3];
-        const int aslot = lane ^ (4 * (2 * ks + (lane >> 5)));
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) af[i][q] = Aimg[buf * ABUF + (((wm * WM + i) * 2 + ks) * 3 + q) * 64 + aslot];
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) bf[j][q] = Bimg[buf * BBUF + (((wn * WN + j) * 2 + ks) * 3 + q) * 64 + lane];
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                const bf16x8 ah = __builtin_bit_cast(bf16x8, af[i][0]), am = __builtin_bit_cast(bf16x8, af[i][1]),
-                             al = __builtin_bit_cast(bf16x8, af[i][2]);
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, bf[j][0]), bm = __builtin_bit_cast(bf16x8, bf[j][1]),
-                             bl = __builtin_bit_cast(bf16x8, bf[j][2]);
-                f32x16 c = acc[i][j];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
-                acc[i][j] = c;
-            }
-    };
-
     f32x16 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -296,29 +189,249 @@ __global__ __launch_bounds__(256) void pw_rowgemm_kernel(const RowGemmArgs p) {
         for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    if constexpr (PIPE) {
+        // Software pipeline (one barrier per iteration, both LDS images double-buffered):
+        //   iteration `it` runs the MFMAs of k-block it from LDS buffer it & 1 while (a) the B image of block it + 1 streams
+        //   global -> LDS by DMA (global_load_lds, no registers, no VALU), (b) the raw A rows of block it + 2 are in flight to
+        //   registers and (c) the raw A rows of block it + 1 (loaded an iteration ago) go through prologue + split into the other
+        //   LDS buffer -- VALU work the scheduler places between this wave's own MFMAs.
+        float4 ra[2][AI][2], ry[2][PRO == PRO_BNBWD ? AI : 1][2];
+        constexpr int ABUF = (BM / 32) * 2 * 3 * 64, BBUF = (BN / 32) * 2 * 3 * 64;    // u32x4 units per buffer
+        auto fetchA = [&](auto Pc, int it) {
+            constexpr int P = decltype(Pc)::value;
+            const int k0 = it * 32;
+            const bool seg2 = k0 >= p.K1;
+            const float *src = seg2 ? p.A2 + (k0 - p.K1) : p.A1 + k0;
+            const long ld = seg2 ? p.lda2 : p.lda1;
+    #pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                // rows behind M (a ragged last tile) re-read row M - 1: their products land in output rows that are never stored (a
+                // conditional zero-fill here crashes the ROCm 7.2 backend in Machine Copy Propagation)
+                const int row = min(row0 + arow + 64 * i, p.M - 1);
+                const float4 *g = reinterpret_cast<const float4 *>(src + (long)row * ld + chunk * 8);
+                ra[P][i][0] = g[0];
+                ra[P][i][1] = g[1];
+                if constexpr (PRO == PRO_BNBWD) {
+                    if (!seg2) {
+                        const float4 *gy = reinterpret_cast<const float4 *>(p.Y1 + k0 + (long)row * ld + chunk * 8);
+                        ry[P][i][0] = gy[0];
+                        ry[P][i][1] = gy[1];
+                    }
+                }
+            }
+        };
+        const int nbl = (p.N + 31) / 32 - col0 / 32;      // 32-column blocks of the image at / behind this tile
+        auto dmaB = [&](int it, int buf) {
+            const u32x4 *bsrc = p.Bimg + ((long)(col0 / 32) * KS + 2 * it) * 192;
+    #pragma unroll
+            for (int q = 0; q < BU; ++q) {
+                const int u = tid + 256 * q, jb = min(u / 384, nbl - 1), rem = u % 384;     // blocks behind N: any valid one (never stored)
+                // LDS destination: wave-uniform base, the hardware adds lane * 16
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bsrc + (long)jb * KS * 192 + rem),
+                                                 (__attribute__((address_space(3))) void *)(Bimg + buf * BBUF + 256 * q + wave * 64), 16, 0, 0);
+            }
+        };
+        auto transformA = [&](auto Pc, int it, int buf) {
+            constexpr int P = decltype(Pc)::value;
+            const int k0 = it * 32;
+            const bool seg2 = k0 >= p.K1;
+            const int kk = k0 + chunk * 8;                // column of segment 1 (tables)
+    #pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                float x[8] = {ra[P][i][0].x, ra[P][i][0].y, ra[P][i][0].z, ra[P][i][0].w,
+                              ra[P][i][1].x, ra[P][i][1].y, ra[P][i][1].z, ra[P][i][1].w};
+                if constexpr (PRO == PRO_BNACT) if (!seg2) {
+    #pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float u = __builtin_fmaf(x[j], tab[kk + j], tab[p.K1 + kk + j]);
+                        x[j] = u > 0.f ? u : u * p.slope;
+                    }
+                }
+                if constexpr (PRO == PRO_BNBWD) if (!seg2) {
+                    const float y[8] = {ry[P][i][0].x, ry[P][i][0].y, ry[P][i][0].z, ry[P][i][0].w,
+                                        ry[P][i][1].x, ry[P][i][1].y, ry[P][i][1].z, ry[P][i][1].w};
+    #pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float al = tab[kk + j], u = __builtin_fmaf(y[j], al, tab[p.K1 + kk + j]);
+                        const float h = x[j] * (u > 0.f ? 1.f : p.slope);
+                        // dy = alpha h - P - Q y
+                        x[j] = __builtin_fmaf(al, h, -__builtin_fmaf(tab[3 * p.K1 + kk + j], y[j], tab[2 * p.K1 + kk + j]));
+                    }
+                }
+                u32x4 h, m, l;
+                split8(x, h, m, l);
+                const int r = arow + 64 * i, mt = r >> 5, ks = chunk >> 1;
+                const int slot = ((r & 31) + 32 * (chunk & 1)) ^ (4 * chunk);
+                u32x4 *dst = Aimg + buf * ABUF + ((mt * 2 + ks) * 3) * 64 + slot;
+                dst[0] = h;
+                dst[64] = m;
+                dst[128] = l;
+            }
+        };
+        auto mfma_ks = [&](int ks, int buf, f32x16 (&acc)[WM][WN]) {
+            u32x4 af[WM][3], bf[WN][3];
+            const int aslot = lane ^ (4 * (2 * ks + (lane >> 5)));
+    #pragma unroll
+            for (int i = 0; i < WM; ++i)
+    #pragma unroll
+                for (int q = 0; q < 3; ++q) af[i][q] = Aimg[buf * ABUF + (((wm * WM + i) * 2 + ks) * 3 + q) * 64 + aslot];
+    #pragma unroll
+            for (int j = 0; j < WN; ++j)
+    #pragma unroll
+                for (int q = 0; q < 3; ++q) bf[j][q] = Bimg[buf * BBUF + (((wn * WN + j) * 2 + ks) * 3 + q) * 64 + lane];
+    #pragma unroll
+            for (int i = 0; i < WM; ++i)
+    #pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, af[i][0]), am = __builtin_bit_cast(bf16x8, af[i][1]),
+                                 al = __builtin_bit_cast(bf16x8, af[i][2]);
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, bf[j][0]), bm = __builtin_bit_cast(bf16x8, bf[j][1]),
+                                 bl = __builtin_bit_cast(bf16x8, bf[j][2]);
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        };
 
-    using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
-    fetchA(P0{}, 0);
-    dmaB(0, 0);
-    if (KT > 1) fetchA(P1{}, 1);
-    __syncthreads();                                  // the prologue tables are in LDS
-    transformA(P0{}, 0, 0);
-    __syncthreads();                                  // A and B images of block 0 are in LDS (the barrier drains the DMA)
-    auto step = [&](auto Pc, int it) {
-        constexpr int P = decltype(Pc)::value;
-        if (it + 1 < KT) dmaB(it + 1, P ^ 1);
-        if (it + 2 < KT) fetchA(Pc, it + 2);          // ra[P] is free: block `it` went through transformA an iteration ago
-        mfma_ks(0, P, acc);
-        if (it + 1 < KT) transformA(std::integral_constant<int, P ^ 1>{}, it + 1, P ^ 1);
-        mfma_ks(1, P, acc);
-        __syncthreads();
-    };
-    for (int it = 0; it < KT; it += 2) {
-        step(P0{}, it);
-        if (it + 1 < KT) step(P1{}, it + 1);
+
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        fetchA(P0{}, 0);
+        dmaB(0, 0);
+        if (KT > 1) fetchA(P1{}, 1);
+        __syncthreads();                                  // the prologue tables are in LDS
+        transformA(P0{}, 0, 0);
+        __syncthreads();                                  // A and B images of block 0 are in LDS (the barrier drains the DMA)
+        auto step = [&](auto Pc, int it) {
+            constexpr int P = decltype(Pc)::value;
+            if (it + 1 < KT) dmaB(it + 1, P ^ 1);
+            if (it + 2 < KT) fetchA(Pc, it + 2);          // ra[P] is free: block `it` went through transformA an iteration ago
+            mfma_ks(0, P, acc);
+            if (it + 1 < KT) transformA(std::integral_constant<int, P ^ 1>{}, it + 1, P ^ 1);
+            mfma_ks(1, P, acc);
+            __syncthreads();
+        };
+        for (int it = 0; it < KT; it += 2) {
+            step(P0{}, it);
+            if (it + 1 < KT) step(P1{}, it + 1);
+        }
+
+    } else {
+        // single LDS buffer, two barriers per iteration, A and B through registers (prefetched one iteration ahead): 48 KB of LDS
+        // at 128 x 128 -> two workgroups per CU whose phases overlap -- the better structure for the widest product of the head
+        // (16384 x 1280 x 192: 56 us against 64-69 us for the double-buffered loop, which holds one workgroup per CU there)
+        float4 ra[AI][2], ry[PRO == PRO_BNBWD ? AI : 1][2];
+        u32x4 rb[BU];
+        auto fetch = [&](int it) {
+            const int k0 = it * 32;
+            const bool seg2 = k0 >= p.K1;
+            const float *src = seg2 ? p.A2 + (k0 - p.K1) : p.A1 + k0;
+            const long ld = seg2 ? p.lda2 : p.lda1;
+    #pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                // rows behind M (a ragged last tile) re-read row M - 1: their products land in output rows that are never stored (a
+                // conditional zero-fill here crashes the ROCm 7.2 backend in Machine Copy Propagation)
+                const int row = min(row0 + arow + 64 * i, p.M - 1);
+                const float4 *g = reinterpret_cast<const float4 *>(src + (long)row * ld + chunk * 8);
+                ra[i][0] = g[0];
+                ra[i][1] = g[1];
+                if constexpr (PRO == PRO_BNBWD) {
+                    if (!seg2) {
+                        const float4 *gy = reinterpret_cast<const float4 *>(p.Y1 + k0 + (long)row * ld + chunk * 8);
+                        ry[i][0] = gy[0];
+                        ry[i][1] = gy[1];
+                    }
+                }
+            }
+            const u32x4 *bsrc = p.Bimg + ((long)(col0 / 32) * KS + 2 * it) * 192;
+            const int nbl = (p.N + 31) / 32 - col0 / 32;      // 32-column blocks of the image at / behind this tile
+    #pragma unroll
+            for (int q = 0; q < BU; ++q) {
+                const int u = tid + 256 * q, jb = u / 384, rem = u - jb * 384;
+                rb[q] = jb < nbl ? bsrc[(long)jb * KS * 192 + rem] : u32x4{0u, 0u, 0u, 0u};
+            }
+        };
+
+
+        fetch(0);
+        for (int it = 0; it < KT; ++it) {
+            __syncthreads();   // tables written (first iteration) / the previous iteration's fragments consumed
+            {
+                const int k0 = it * 32;
+                const bool seg2 = k0 >= p.K1;
+                const int kk = k0 + chunk * 8;            // column of segment 1 (tables)
+    #pragma unroll
+                for (int i = 0; i < AI; ++i) {
+                    float x[8] = {ra[i][0].x, ra[i][0].y, ra[i][0].z, ra[i][0].w, ra[i][1].x, ra[i][1].y, ra[i][1].z, ra[i][1].w};
+                    if constexpr (PRO == PRO_BNACT) if (!seg2) {
+    #pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float u = __builtin_fmaf(x[j], tab[kk + j], tab[p.K1 + kk + j]);
+                            x[j] = u > 0.f ? u : u * p.slope;
+                        }
+                    }
+                    if constexpr (PRO == PRO_BNBWD) if (!seg2) {
+                        const float y[8] = {ry[i][0].x, ry[i][0].y, ry[i][0].z, ry[i][0].w, ry[i][1].x, ry[i][1].y, ry[i][1].z, ry[i][1].w};
+    #pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float al = tab[kk + j], u = __builtin_fmaf(y[j], al, tab[p.K1 + kk + j]);
+                            const float h = x[j] * (u > 0.f ? 1.f : p.slope);
+                            // dy = alpha h - P - Q y
+                            x[j] = __builtin_fmaf(al, h, -__builtin_fmaf(tab[3 * p.K1 + kk + j], y[j], tab[2 * p.K1 + kk + j]));
+                        }
+                    }
+                    u32x4 h, m, l;
+                    split8(x, h, m, l);
+                    const int r = arow + 64 * i, mt = r >> 5, ks = chunk >> 1;
+                    const int slot = ((r & 31) + 32 * (chunk & 1)) ^ (4 * chunk);
+                    u32x4 *dst = Aimg + ((mt * 2 + ks) * 3) * 64 + slot;
+                    dst[0] = h;
+                    dst[64] = m;
+                    dst[128] = l;
+                }
+    #pragma unroll
+                for (int q = 0; q < BU; ++q) Bimg[tid + 256 * q] = rb[q];
+            }
+            __syncthreads();
+            if (it + 1 < KT) fetch(it + 1);
+    #pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 af[WM][3], bf[WN][3];
+                const int aslot = lane ^ (4 * (2 * ks + (lane >> 5)));
+    #pragma unroll
+                for (int i = 0; i < WM; ++i)
+    #pragma unroll
+                    for (int q = 0; q < 3; ++q) af[i][q] = Aimg[(((wm * WM + i) * 2 + ks) * 3 + q) * 64 + aslot];
+    #pragma unroll
+                for (int j = 0; j < WN; ++j)
+    #pragma unroll
+                    for (int q = 0; q < 3; ++q) bf[j][q] = Bimg[(((wn * WN + j) * 2 + ks) * 3 + q) * 64 + lane];
+    #pragma unroll
+                for (int i = 0; i < WM; ++i)
+    #pragma unroll
+                    for (int j = 0; j < WN; ++j) {
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, af[i][0]), am = __builtin_bit_cast(bf16x8, af[i][1]),
+                                     al = __builtin_bit_cast(bf16x8, af[i][2]);
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, bf[j][0]), bm = __builtin_bit_cast(bf16x8, bf[j][1]),
+                                     bl = __builtin_bit_cast(bf16x8, bf[j][2]);
+                        f32x16 c = acc[i][j];
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+                        acc[i][j] = c;
+                    }
+            }
+        }
+
     }
-
     // ---------------------------------------------------------------- epilogue: lane holds column (lane & 31) of each of its
     // tiles and rows (e & 3) + 8 (e >> 2) + 4 (lane >> 5), e = 0..15
     const int half = lane >> 5, lc = lane & 31;
@@ -443,24 +556,24 @@ __global__ __launch_bounds__(256) void pw_rowgemm_kernel(const RowGemmArgs p) {
     }
 }
 
-template <int WM, int WN, int PRO, int EPI>
+template <int WM, int WN, int PRO, int EPI, int PIPE = 1>
 int launch_rowgemm(const RowGemmArgs &a, hipStream_t st, const char *name) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
     const int grid = ((MT + 7) / 8) * 8 * NT;
-    size_t lds = 2 * ((size_t)(BM / 32) * 6 + (size_t)(BN / 32) * 6) * 1024 + sizeof(float) * 4 * (size_t)a.K1;
+    size_t lds = (PIPE ? 2 : 1) * ((size_t)(BM / 32) * 6 + (size_t)(BN / 32) * 6) * 1024 + sizeof(float) * 4 * (size_t)a.K1;
     const size_t scratch = sizeof(float) * 2 * 2 * WN * 32;
     if (lds < scratch) lds = scratch;
     static size_t granted = 64 * 1024;
     if (lds > granted) {
-        if (hipFuncSetAttribute((const void *)pw_rowgemm_kernel<WM, WN, PRO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void *)pw_rowgemm_kernel<WM, WN, PRO, EPI, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) {
             fsg_set_error("%s: cannot raise dynamic LDS to %zu", name, lds);
             return FSG_ERR_HIP;
         }
         granted = lds;
     }
-    hipLaunchKernelGGL((pw_rowgemm_kernel<WM, WN, PRO, EPI>), dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((pw_rowgemm_kernel<WM, WN, PRO, EPI, PIPE>), dim3(grid), dim3(256), lds, st, a);
     FSG_CHECK_LAUNCH(name);
     return FSG_OK;
 }
@@ -1481,7 +1594,8 @@ extern "C" int fsg_pw_rowgemm_f32(const fsg_pw_rowgemm_args *a, int pro, int epi
         PW_CASE(PRO_NONE, PW_STORE | PW_BIAS, 4, 2, 1);
         PW_CASE(PRO_NONE, PW_STORE | PW_STATS, 1, 2, 2);
         PW_CASE(PRO_NONE, PW_STORE | PW_STATS, 2, 1, 2);
-        PW_CASE(PRO_NONE, PW_STORE | PW_STATS | PW_SEL, 1, 2, 2);
+        case PRO_NONE * 1000 + (PW_STORE | PW_STATS | PW_SEL) * 10 + 1:      // the widest product: single-buffered loop, 2 workgroups / CU
+            return launch_rowgemm<2, 2, PRO_NONE, PW_STORE | PW_STATS | PW_SEL, 0>(k, st, "fsg_pw_rowgemm_f32");
         PW_CASE(PRO_NONE, PW_STORE | PW_STATS | PW_SEL, 2, 1, 2);
         PW_CASE(PRO_BNACT, PW_STORE | PW_STATS, 1, 2, 2);
         PW_CASE(PRO_BNACT, PW_STORE | PW_STATS, 2, 1, 2);

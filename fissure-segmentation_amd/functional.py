@@ -1054,13 +1054,13 @@ class _SegHead(torch.autograd.Function):
         imgs = pw_weight_images(specs)
         img1, img2, img3, img2t, img1t = imgs[2], imgs[3], imgs[4], imgs[5], imgs[6]
         # levels -> global-feature statistics / selection + y0
-        R0 = M // 64                 # 64 x 128 tiles: two workgroups per CU with both LDS images double-buffered (72 KB each)
+        R0 = M // 128
         rec0 = torch.empty(R0, 3, CG + C0, **f32)
         sel_val = torch.empty(R0, CG, **f32)
         sel_arg = torch.empty(R0, CG, dtype=torch.int32, device=dev)
         y0 = torch.empty(M, C0, **f32)
         sgn = gg                     # only the sign of the BatchNorm weight is used (max of sgn * y through the monotone BN + LeakyReLU)
-        pw_rowgemm(PRO_NONE, PW_STORE | PW_STATS | PW_SEL, 2, A1=levels, lda1=levels.stride(0), K1=KL, K2=0, Bimg=img0, M=M,
+        pw_rowgemm(PRO_NONE, PW_STORE | PW_STATS | PW_SEL, 1, A1=levels, lda1=levels.stride(0), K1=KL, K2=0, Bimg=img0, M=M,
                    N=CG + C0, rows_per_cloud=Npts, C=y0, ldc=C0, store_n0=CG, rec=rec0, sgn=sgn, sel_val=sel_val,
                    sel_arg=sel_arg, sel_n=CG)
         mean_g, inv_g, al_g, de_g, _, _ = _pw_bn_finalize(rec0, R0, CG + C0, 0, CG, None, B, bn_g, tr_g, mom_g)
@@ -1068,7 +1068,7 @@ class _SegHead(torch.autograd.Function):
         ysel = torch.empty(B, CG, **f32)
         arg = torch.empty(B, CG, dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
-            _lib.call("fsg_pw_max_finish_f32", _p(sel_val), _p(sel_arg), _p(sgn), _p(al_g), _p(de_g), B, Npts // 64, CG,
+            _lib.call("fsg_pw_max_finish_f32", _p(sel_val), _p(sel_arg), _p(sgn), _p(al_g), _p(de_g), B, Npts // 128, CG,
                       slope, _p(g), _p(ysel), _p(arg), _stream())
         c = torch.empty(B, C0, **f32)     # g W0_global^T: the global part of the first head layer, one wave per output
         with torch.cuda.device(dev):
