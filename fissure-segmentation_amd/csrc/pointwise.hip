@@ -1520,13 +1520,14 @@ extern "C" int fsg_pw_linear_f32(const float *A, int64_t lda, const void *image,
         const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
         tile = t128 >= 512 ? 1 : ((long)((M + 63) / 64) * ((N + 127) / 128) >= 384 ? 2 : 3);
     }
+    // 128 x 128: the single-buffered loop (two workgroups per CU) is the faster one there, see pw_rowgemm_kernel
     if (bias) {
-        if (tile == 1) return launch_rowgemm<2, 2, PRO_NONE, PW_STORE | PW_BIAS>(a, st, "fsg_pw_linear_f32");
+        if (tile == 1) return launch_rowgemm<2, 2, PRO_NONE, PW_STORE | PW_BIAS, 0>(a, st, "fsg_pw_linear_f32");
         if (tile == 2) return launch_rowgemm<1, 2, PRO_NONE, PW_STORE | PW_BIAS>(a, st, "fsg_pw_linear_f32");
         if (tile == 4) return launch_rowgemm<2, 1, PRO_NONE, PW_STORE | PW_BIAS>(a, st, "fsg_pw_linear_f32");
         return launch_rowgemm<1, 1, PRO_NONE, PW_STORE | PW_BIAS>(a, st, "fsg_pw_linear_f32");
     }
-    if (tile == 1) return launch_rowgemm<2, 2, PRO_NONE, PW_STORE>(a, st, "fsg_pw_linear_f32");
+    if (tile == 1) return launch_rowgemm<2, 2, PRO_NONE, PW_STORE, 0>(a, st, "fsg_pw_linear_f32");
     if (tile == 2) return launch_rowgemm<1, 2, PRO_NONE, PW_STORE>(a, st, "fsg_pw_linear_f32");
     if (tile == 4) return launch_rowgemm<2, 1, PRO_NONE, PW_STORE>(a, st, "fsg_pw_linear_f32");
     return launch_rowgemm<1, 1, PRO_NONE, PW_STORE>(a, st, "fsg_pw_linear_f32");

@@ -136,8 +136,10 @@ _KNN_EXPERIMENT_FLAGS = 8   # the first MFMA design (libfsg_hip_experiments.so):
 
 
 def knn_graph(x, k, c_knn=None, fix_diag=True, drop_first=False, return_dist=False, force_rows_kernel=False,
-              _debug_flags=0):
-    """x: (B,C,N) -> idx (B,N,k) int32 [, dist (B,N,k) fp32].  Channel slices are passed by stride."""
+              _debug_flags=0, out=None):
+    """x: (B,C,N) -> idx (B,N,k) int32 [, dist (B,N,k) fp32].  Channel slices are passed by stride.  `out`: a contiguous
+    (B,N,k) int32 tensor to write the graph into (e.g. a slice of one buffer holding all graphs of a step, so that their
+    reverse graphs can be built in one launch: build_reverse_graphs)."""
     _need_gpu(x)
     if x.dim() != 3:
         raise ValueError(f"expected (B,C,N), got {tuple(x.shape)}")
@@ -148,7 +150,12 @@ def knn_graph(x, k, c_knn=None, fix_diag=True, drop_first=False, return_dist=Fal
         x = x.contiguous()
     B, C, N = x.shape
     c_knn = C if c_knn is None else c_knn
-    idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
+    if out is not None:
+        if out.shape != (B, N, k) or out.dtype != torch.int32 or not out.is_contiguous() or out.device != x.device:
+            raise ValueError("knn_graph: `out` must be a contiguous (B,N,k) int32 tensor on the input's device")
+        idx = out
+    else:
+        idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
     dist = torch.empty(B, N, k, dtype=torch.float32, device=x.device) if return_dist else None
     flags = (_lib.KNN_FIX_DIAG if fix_diag else 0) | (_lib.KNN_DROP_FIRST if drop_first else 0) | \
         (_lib.KNN_FORCE_ROWS if force_rows_kernel else 0) | _debug_flags
@@ -656,6 +663,24 @@ def _build_csr(idx):
     with torch.cuda.device(idx.device):
         _lib.call("fsg_graph_reverse_csr", _p(idx), B, N, k, _p(rowptr), _p(col), _p(ws), _stream())
     return rowptr, col
+
+
+def build_reverse_graphs(graphs):
+    """Reverse graphs (CSR by destination) of several kNN graphs of the same shape in ONE set of launches instead of one per
+    graph: `graphs` are the (B,N,k) slices, in order, of one contiguous (G,B,N,k) buffer (knn_graph(..., out=slice)).  The
+    results are cached on the slice tensors exactly as reverse_graph() would (3 x 3 small launches -> 3 per DGCNN-seg step)."""
+    g0 = graphs[0]
+    G = len(graphs)
+    B, N, k = g0.shape
+    step = B * N * k * g0.element_size()
+    if any(g.shape != g0.shape or g.data_ptr() != g0.data_ptr() + i * step or not g.is_contiguous() for i, g in enumerate(graphs)):
+        return          # not one buffer (e.g. graphs substituted by a test): each is built on first use by reverse_graph()
+    if all(getattr(g, "_fsg_csr", None) is not None for g in graphs):
+        return
+    flat = torch.as_strided(g0, (G * B, N, k), (N * k, k, 1))
+    rowptr, col = _build_csr(flat)
+    for i, g in enumerate(graphs):
+        g._fsg_csr = (rowptr[i * B:(i + 1) * B], col[i * B:(i + 1) * B])
 
 
 def prefetch_reverse_graph(idx):

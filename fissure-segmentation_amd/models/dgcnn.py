@@ -245,9 +245,22 @@ class DGCNNSeg(DGCNNBase):
         # p1 / p2 have two consumers (the next EdgeConv and the concatenation): "twice" hands out an alias for the second,
         # so that their gradients reach the EdgeConv backward kernel separately (summed there, slices taken by stride)
         w1, w2, w3 = EdgeConv.pq_weights([self.ec1, self.ec2, self.ec3])     # one launch for the three weight transforms
-        x1, p1, p1c = self.ec1(x, self.knn_graph, both="twice", w_cat=w1)
-        x2, p2, p2c = self.ec2(x1, self.knn_graph, x_pm=p1, both="twice", w_cat=w2)
-        _, p3 = self.ec3(x2, self.knn_graph, x_pm=p2, both=True, w_cat=w3)
+        if self.dynamic and all(e.fused for e in (self.ec1, self.ec2, self.ec3)):
+            # the three dynamic graphs go into ONE buffer: with a backward pass ahead their reverse graphs (CSR by destination,
+            # what the EdgeConv backward gathers through) are then built by one set of launches instead of three
+            graphs = list(torch.empty(3, B, N, self.k, dtype=torch.int32, device=x.device).unbind(0))
+            g1 = F_hip.knn_graph(x, self.k, c_knn=3, fix_diag=True, out=graphs[0])
+            x1, p1, p1c = self.ec1(x, g1, both="twice", w_cat=w1)
+            g2 = F_hip.knn_graph(x1, self.k, fix_diag=True, out=graphs[1])
+            x2, p2, p2c = self.ec2(x1, g2, x_pm=p1, both="twice", w_cat=w2)
+            g3 = F_hip.knn_graph(x2, self.k, fix_diag=True, out=graphs[2])
+            _, p3 = self.ec3(x2, g3, x_pm=p2, both=True, w_cat=w3)
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                F_hip.build_reverse_graphs([g1, g2, g3])
+        else:
+            x1, p1, p1c = self.ec1(x, self.knn_graph, both="twice", w_cat=w1)
+            x2, p2, p2c = self.ec2(x1, self.knn_graph, x_pm=p1, both="twice", w_cat=w2)
+            _, p3 = self.ec3(x2, self.knn_graph, x_pm=p2, both=True, w_cat=w3)
         levels = torch.cat([p1c, p2c, p3], dim=2).view(B * N, 192)
         gf = self.global_feature[0].layers                                                   # conv, BN, LeakyReLU
         seg0 = self.segmentation[0]
