@@ -197,6 +197,8 @@ def main():
     # bf16 kernel yet, so configs 3 and 5 run -- and are labelled -- fp32.
     dtype = args.dtype or ("bf16" if args.workload == "c4" else "f32")
     fsg.functional.set_mfma_operands(dtype)      # graph build, BatchNorm statistics and stored tensors stay fp32 either way
+    if dtype == "bf16" and args.workload in ("c3", "c3f", "c3b"):
+        fsg.functional.set_bf16_linear(True)     # opt-in: bf16 operands for the nn.Linear products (slower AND less accurate: DESIGN)
     desc = desc.replace("fp32", "bf16 MFMA operands" if dtype == "bf16" else "fp32")
 
     torch.manual_seed(0)

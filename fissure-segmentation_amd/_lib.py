@@ -79,6 +79,9 @@ SIGNATURES = {
     "fsg_pw_weight_image_f32": ([_P, _L, _L, _I, _I, _F, _I, _I, _P, _P], _I),
     "fsg_pw_weight_images_f32": ([_P, _P], _I),
     "fsg_pw_linear_f32": ([_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P], _I),
+    "fsg_pw_weight_image_bf16": ([_P, _L, _L, _I, _I, _P, _P], _I),
+    "fsg_pw_linear_bf16": ([_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P], _I),
+    "fsg_pw_tn_bf16": ([_P, _I, _P, ctypes.c_size_t, _P, _L, _P], _I),
     "fsg_pw_tile_rows": ([_I], _I),
     "fsg_pw_rowgemm_f32": ([_P, _I, _I, _I, _P], _I),
     "fsg_pw_tn_workspace_bytes": ([_I, _I, _I, _I], ctypes.c_size_t),

@@ -61,7 +61,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4 &h, u32x4 &m, 
 // (n = 32 nb + (lane & 31), k = 16 ks + 8 (lane >> 5) + 0..7); rows >= N and columns >= K read as zero.  `ks0`/`KS`: the
 // image may be the concatenation of several matrices along k (this call fills k-steps ks0 .. ks0 + ceil(K/16) - 1 of KS).
 __global__ __launch_bounds__(256) void pw_weight_image_kernel(const float *__restrict__ W, long sn, long sk, int N, int K,
-                                                              float scale, int ks0, int KS, u32x4 *__restrict__ img) {
+                                                              float scale, int ks0, int KS, int pieces, u32x4 *__restrict__ img) {
     const int ksteps = (K + 15) / 16;
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     const int lane = (int)(t & 63);
@@ -74,10 +74,12 @@ __global__ __launch_bounds__(256) void pw_weight_image_kernel(const float *__res
     for (int j = 0; j < 8; ++j) x[j] = (n < N && k0 + j < K) ? W[(long)n * sn + (long)(k0 + j) * sk] * scale : 0.f;
     u32x4 h, m, l;
     split8(x, h, m, l);
-    u32x4 *o = img + (((long)nb * KS + ks0 + ks) * 3) * 64 + lane;
-    o[0] = h;
-    o[64] = m;
-    o[128] = l;
+    u32x4 *o = img + (((long)nb * KS + ks0 + ks) * pieces) * 64 + lane;
+    o[0] = h;                          // pieces == 1: the bf16 operand mode keeps the leading piece only
+    if (pieces == 3) {
+        o[64] = m;
+        o[128] = l;
+    }
 }
 
 // several images in one launch (the weights of a whole head, both orientations): job j owns the 64-thread blocks
@@ -148,16 +150,17 @@ struct RowGemmArgs {
     float *rec2;          // (M / BM, 2, N): sums of h = c f'(u) and h * yhat over the block's rows
 };
 
-template <int WM, int WN, int PRO, int EPI, int PIPE>
+template <int WM, int WN, int PRO, int EPI, int PIPE, int NP = 3>
 __global__ __launch_bounds__(256) void pw_rowgemm_kernel(const RowGemmArgs p) {
+    static_assert(NP == 3 || (NP == 1 && PIPE == 1 && PRO == PRO_NONE), "one-piece (bf16 operand) mode: pipelined plain products only");
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int AI = BM / 64;                       // A rows per thread and iteration
-    constexpr int BU = BN * 12 / 256;                 // 16-byte units of the B image per thread and iteration
+    constexpr int BU = BN * 4 * NP / 256;             // 16-byte units of the B image per thread and iteration
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NBUF = PIPE ? 2 : 1;
     u32x4 *Aimg = reinterpret_cast<u32x4 *>(smem);                            // [NBUF][BM/32][2][3][64]
-    u32x4 *Bimg = Aimg + NBUF * (BM / 32) * 2 * 3 * 64;                       // [NBUF][BN/32][2][3][64]
-    float *tab = reinterpret_cast<float *>(Bimg + NBUF * (BN / 32) * 2 * 3 * 64);   // PRO tables: [4][K1]; epilogue scratch after the loop
+    u32x4 *Bimg = Aimg + NBUF * (BM / 32) * 2 * NP * 64;                      // [NBUF][BN/32][2][NP][64]
+    float *tab = reinterpret_cast<float *>(Bimg + NBUF * (BN / 32) * 2 * NP * 64);  // PRO tables: [4][K1]; epilogue scratch after the loop
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int MT = (p.M + BM - 1) / BM, NT = (p.N + BN - 1) / BN;
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(256) void pw_rowgemm_kernel(const RowGemmArgs p) {
         //   registers and (c) the raw A rows of block it + 1 (loaded an iteration ago) go through prologue + split into the other
         //   LDS buffer -- VALU work the scheduler places between this wave's own MFMAs.
         float4 ra[2][AI][2], ry[2][PRO == PRO_BNBWD ? AI : 1][2];
-        constexpr int ABUF = (BM / 32) * 2 * 3 * 64, BBUF = (BN / 32) * 2 * 3 * 64;    // u32x4 units per buffer
+        constexpr int ABUF = (BM / 32) * 2 * NP * 64, BBUF = (BN / 32) * 2 * NP * 64;  // u32x4 units per buffer
         auto fetchA = [&](auto Pc, int it) {
             constexpr int P = decltype(Pc)::value;
             const int k0 = it * 32;
@@ -222,12 +225,12 @@ __global__ __launch_bounds__(256) void pw_rowgemm_kernel(const RowGemmArgs p) {
         };
         const int nbl = (p.N + 31) / 32 - col0 / 32;      // 32-column blocks of the image at / behind this tile
         auto dmaB = [&](int it, int buf) {
-            const u32x4 *bsrc = p.Bimg + ((long)(col0 / 32) * KS + 2 * it) * 192;
-    #pragma unroll
+            const u32x4 *bsrc = p.Bimg + ((long)(col0 / 32) * KS + 2 * it) * (NP * 64);
+            #pragma unroll
             for (int q = 0; q < BU; ++q) {
-                const int u = tid + 256 * q, jb = min(u / 384, nbl - 1), rem = u % 384;     // blocks behind N: any valid one (never stored)
+                const int u = tid + 256 * q, jb = min(u / (128 * NP), nbl - 1), rem = u % (128 * NP);   // blocks behind N: any valid one (never stored)
                 // LDS destination: wave-uniform base, the hardware adds lane * 16
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bsrc + (long)jb * KS * 192 + rem),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bsrc + (long)jb * KS * (NP * 64) + rem),
                                                  (__attribute__((address_space(3))) void *)(Bimg + buf * BBUF + 256 * q + wave * 64), 16, 0, 0);
             }
         };
@@ -262,10 +265,12 @@ __global__ __launch_bounds__(256) void pw_rowgemm_kernel(const RowGemmArgs p) {
                 split8(x, h, m, l);
                 const int r = arow + 64 * i, mt = r >> 5, ks = chunk >> 1;
                 const int slot = ((r & 31) + 32 * (chunk & 1)) ^ (4 * chunk);
-                u32x4 *dst = Aimg + buf * ABUF + ((mt * 2 + ks) * 3) * 64 + slot;
+                u32x4 *dst = Aimg + buf * ABUF + ((mt * 2 + ks) * NP) * 64 + slot;
                 dst[0] = h;
-                dst[64] = m;
-                dst[128] = l;
+                if constexpr (NP == 3) {
+                    dst[64] = m;
+                    dst[128] = l;
+                }
             }
         };
         auto mfma_ks = [&](int ks, int buf, f32x16 (&acc)[WM][WN]) {
@@ -274,25 +279,26 @@ __global__ __launch_bounds__(256) void pw_rowgemm_kernel(const RowGemmArgs p) {
     #pragma unroll
             for (int i = 0; i < WM; ++i)
     #pragma unroll
-                for (int q = 0; q < 3; ++q) af[i][q] = Aimg[buf * ABUF + (((wm * WM + i) * 2 + ks) * 3 + q) * 64 + aslot];
+                for (int q = 0; q < NP; ++q) af[i][q] = Aimg[buf * ABUF + (((wm * WM + i) * 2 + ks) * NP + q) * 64 + aslot];
     #pragma unroll
             for (int j = 0; j < WN; ++j)
     #pragma unroll
-                for (int q = 0; q < 3; ++q) bf[j][q] = Bimg[buf * BBUF + (((wn * WN + j) * 2 + ks) * 3 + q) * 64 + lane];
+                for (int q = 0; q < NP; ++q) bf[j][q] = Bimg[buf * BBUF + (((wn * WN + j) * 2 + ks) * NP + q) * 64 + lane];
     #pragma unroll
             for (int i = 0; i < WM; ++i)
     #pragma unroll
                 for (int j = 0; j < WN; ++j) {
-                    const bf16x8 ah = __builtin_bit_cast(bf16x8, af[i][0]), am = __builtin_bit_cast(bf16x8, af[i][1]),
-                                 al = __builtin_bit_cast(bf16x8, af[i][2]);
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, bf[j][0]), bm = __builtin_bit_cast(bf16x8, bf[j][1]),
-                                 bl = __builtin_bit_cast(bf16x8, bf[j][2]);
                     f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, af[i][0]), bh = __builtin_bit_cast(bf16x8, bf[j][0]);
+                    if constexpr (NP == 3) {
+                        const bf16x8 am = __builtin_bit_cast(bf16x8, af[i][1]), al = __builtin_bit_cast(bf16x8, af[i][2]);
+                        const bf16x8 bm = __builtin_bit_cast(bf16x8, bf[j][1]), bl = __builtin_bit_cast(bf16x8, bf[j][2]);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+                    }
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
                     acc[i][j] = c;
                 }
@@ -556,24 +562,24 @@ __global__ __launch_bounds__(256) void pw_rowgemm_kernel(const RowGemmArgs p) {
     }
 }
 
-template <int WM, int WN, int PRO, int EPI, int PIPE = 1>
+template <int WM, int WN, int PRO, int EPI, int PIPE = 1, int NP = 3>
 int launch_rowgemm(const RowGemmArgs &a, hipStream_t st, const char *name) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
     const int grid = ((MT + 7) / 8) * 8 * NT;
-    size_t lds = (PIPE ? 2 : 1) * ((size_t)(BM / 32) * 6 + (size_t)(BN / 32) * 6) * 1024 + sizeof(float) * 4 * (size_t)a.K1;
+    size_t lds = (PIPE ? 2 : 1) * ((size_t)(BM / 32) * 2 * NP + (size_t)(BN / 32) * 2 * NP) * 1024 + sizeof(float) * 4 * (size_t)a.K1;
     const size_t scratch = sizeof(float) * 2 * 2 * WN * 32;
     if (lds < scratch) lds = scratch;
     static size_t granted = 64 * 1024;
     if (lds > granted) {
-        if (hipFuncSetAttribute((const void *)pw_rowgemm_kernel<WM, WN, PRO, EPI, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void *)pw_rowgemm_kernel<WM, WN, PRO, EPI, PIPE, NP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) {
             fsg_set_error("%s: cannot raise dynamic LDS to %zu", name, lds);
             return FSG_ERR_HIP;
         }
         granted = lds;
     }
-    hipLaunchKernelGGL((pw_rowgemm_kernel<WM, WN, PRO, EPI, PIPE>), dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((pw_rowgemm_kernel<WM, WN, PRO, EPI, PIPE, NP>), dim3(grid), dim3(256), lds, st, a);
     FSG_CHECK_LAUNCH(name);
     return FSG_OK;
 }
@@ -603,11 +609,11 @@ struct TnArgs {
     float *part;             // (S, N1a + N1b, N2)
 };
 
-template <int T1, int T2>
+template <int T1, int T2, int NP = 3>
 __global__ __launch_bounds__(256) void pw_tn_kernel(const TnArgs p) {
     constexpr int BT1 = 64 * T1, BT2 = 64 * T2;
-    __shared__ __attribute__((aligned(16))) u32x4 Limg[(BT1 / 32) * 2 * 3 * 64];
-    __shared__ __attribute__((aligned(16))) u32x4 Rimg[(BT2 / 32) * 2 * 3 * 64];
+    __shared__ __attribute__((aligned(16))) u32x4 Limg[(BT1 / 32) * 2 * NP * 64];
+    __shared__ __attribute__((aligned(16))) u32x4 Rimg[(BT2 / 32) * 2 * NP * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N1 = p.N1a + p.N1b;
     const int nt2 = (p.N2 + BT2 - 1) / BT2;
@@ -690,10 +696,12 @@ __global__ __launch_bounds__(256) void pw_tn_kernel(const TnArgs p) {
             }
             u32x4 h, m, l;
             split8(x, h, m, l);
-            u32x4 *dst = Limg + (((2 * g + (lane >> 5)) * 2 + ks) * 3) * 64 + (lane & 31) + 32 * hh;
+            u32x4 *dst = Limg + (((2 * g + (lane >> 5)) * 2 + ks) * NP) * 64 + (lane & 31) + 32 * hh;
             dst[0] = h;
-            dst[64] = m;
-            dst[128] = l;
+            if constexpr (NP == 3) {
+                dst[64] = m;
+                dst[128] = l;
+            }
         }
 #pragma unroll
         for (int g = 0; g < T2; ++g) {
@@ -710,10 +718,12 @@ __global__ __launch_bounds__(256) void pw_tn_kernel(const TnArgs p) {
             }
             u32x4 h, m, l;
             split8(x, h, m, l);
-            u32x4 *dst = Rimg + (((2 * g + (lane >> 5)) * 2 + ks) * 3) * 64 + (lane & 31) + 32 * hh;
+            u32x4 *dst = Rimg + (((2 * g + (lane >> 5)) * 2 + ks) * NP) * 64 + (lane & 31) + 32 * hh;
             dst[0] = h;
-            dst[64] = m;
-            dst[128] = l;
+            if constexpr (NP == 3) {
+                dst[64] = m;
+                dst[128] = l;
+            }
         }
         __syncthreads();
         if (mb + 32 < m1) fetch(mb + 32);
@@ -723,25 +733,26 @@ __global__ __launch_bounds__(256) void pw_tn_kernel(const TnArgs p) {
 #pragma unroll
             for (int i = 0; i < T1; ++i)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) af[i][q] = Limg[(((w1 * T1 + i) * 2 + k2) * 3 + q) * 64 + lane];
+                for (int q = 0; q < NP; ++q) af[i][q] = Limg[(((w1 * T1 + i) * 2 + k2) * NP + q) * 64 + lane];
 #pragma unroll
             for (int j = 0; j < T2; ++j)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) bf[j][q] = Rimg[(((w2 * T2 + j) * 2 + k2) * 3 + q) * 64 + lane];
+                for (int q = 0; q < NP; ++q) bf[j][q] = Rimg[(((w2 * T2 + j) * 2 + k2) * NP + q) * 64 + lane];
 #pragma unroll
             for (int i = 0; i < T1; ++i)
 #pragma unroll
                 for (int j = 0; j < T2; ++j) {
-                    const bf16x8 ah = __builtin_bit_cast(bf16x8, af[i][0]), am = __builtin_bit_cast(bf16x8, af[i][1]),
-                                 al = __builtin_bit_cast(bf16x8, af[i][2]);
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, bf[j][0]), bm = __builtin_bit_cast(bf16x8, bf[j][1]),
-                                 bl = __builtin_bit_cast(bf16x8, bf[j][2]);
                     f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, af[i][0]), bh = __builtin_bit_cast(bf16x8, bf[j][0]);
+                    if constexpr (NP == 3) {
+                        const bf16x8 am = __builtin_bit_cast(bf16x8, af[i][1]), al = __builtin_bit_cast(bf16x8, af[i][2]);
+                        const bf16x8 bm = __builtin_bit_cast(bf16x8, bf[j][1]), bl = __builtin_bit_cast(bf16x8, bf[j][2]);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+                    }
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
                     acc[i][j] = c;
                 }
@@ -1454,11 +1465,11 @@ __global__ __launch_bounds__(256) void pw_tn_reduce_many_kernel(const TnReduceJo
     else jobs.C2[j][(long)(r - jobs.N1a[j]) * jobs.ldc2[j] + c] = v;
 }
 
-template <int T1, int T2>
+template <int T1, int T2, int NP = 3>
 int launch_tn(const TnArgs &a, int S, hipStream_t st) {
     const int N1 = a.N1a + a.N1b;
     const dim3 grid(((N1 + 64 * T1 - 1) / (64 * T1)) * ((a.N2 + 64 * T2 - 1) / (64 * T2)), S);
-    hipLaunchKernelGGL((pw_tn_kernel<T1, T2>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((pw_tn_kernel<T1, T2, NP>), grid, dim3(256), 0, st, a);
     FSG_CHECK_LAUNCH("fsg_pw_tn_f32");
     return FSG_OK;
 }
@@ -1470,16 +1481,50 @@ extern "C" size_t fsg_pw_weight_image_bytes(int N, int K) {
     return (size_t)((N + 31) / 32) * ((K + 15) / 16) * 3 * 1024;
 }
 
-extern "C" int fsg_pw_weight_image_f32(const float *W, int64_t stride_n, int64_t stride_k, int N, int K, float scale, int ks0,
-                                       int KS, void *image, fsg_stream_t stream) {
+static int weight_image(const float *W, int64_t stride_n, int64_t stride_k, int N, int K, float scale, int ks0, int KS, int pieces,
+                        void *image, fsg_stream_t stream) {
     FSG_REQUIRE(W && image, "fsg_pw_weight_image_f32: NULL pointer");
     FSG_REQUIRE(N > 0 && K > 0 && ks0 >= 0 && ks0 + (K + 15) / 16 <= KS, "fsg_pw_weight_image_f32: bad shape N=%d K=%d ks0=%d KS=%d",
                 N, K, ks0, KS);
     const long threads = (long)((N + 31) / 32) * ((K + 15) / 16) * 64;
+    FSG_REQUIRE(pieces == 1 || pieces == 3, "fsg_pw_weight_image: pieces = %d", pieces);
     hipLaunchKernelGGL(pw_weight_image_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W,
-                       (long)stride_n, (long)stride_k, N, K, scale, ks0, KS, reinterpret_cast<u32x4 *>(image));
+                       (long)stride_n, (long)stride_k, N, K, scale, ks0, KS, pieces, reinterpret_cast<u32x4 *>(image));
     FSG_CHECK_LAUNCH("fsg_pw_weight_image_f32");
     return FSG_OK;
+}
+
+extern "C" int fsg_pw_weight_image_f32(const float *W, int64_t stride_n, int64_t stride_k, int N, int K, float scale, int ks0,
+                                       int KS, void *image, fsg_stream_t stream) {
+    return weight_image(W, stride_n, stride_k, N, K, scale, ks0, KS, 3, image, stream);
+}
+
+// bf16 operand mode (BASELINE configs 3-5): ONE bf16 piece per operand (round-to-nearest-even), one MFMA product, fp32
+// accumulation -- the same kernels with the two correction pieces compiled out.  Image: a third of the fp32-grade image's bytes.
+extern "C" int fsg_pw_weight_image_bf16(const float *W, int64_t stride_n, int64_t stride_k, int N, int K, void *image,
+                                        fsg_stream_t stream) {
+    return weight_image(W, stride_n, stride_k, N, K, 1.0f, 0, (K + 15) / 16, 1, image, stream);
+}
+
+// C (M, N) = bf16(A) (M, K) . bf16(W)^T (+ bias), fp32 accumulation; W as fsg_pw_weight_image_bf16.  tile: 2 = 64 x 128, 3 = 64 x 64
+extern "C" int fsg_pw_linear_bf16(const float *A, int64_t lda, const void *image, const float *bias, float *C, int64_t ldc, int M,
+                                  int N, int K, int tile, fsg_stream_t stream) {
+    FSG_REQUIRE(A && image && C, "fsg_pw_linear_bf16: NULL pointer");
+    FSG_REQUIRE(M > 0 && N > 0 && K > 0 && K % 32 == 0 && lda % 4 == 0 && ((uintptr_t)A & 15) == 0,
+                "fsg_pw_linear_bf16: bad shape M=%d N=%d K=%d lda=%ld (K %% 32 == 0, lda %% 4 == 0, 16-byte aligned rows)", M, N, K, (long)lda);
+    RowGemmArgs a{};
+    a.A1 = A; a.lda1 = lda; a.K1 = K; a.K2 = 0;
+    a.Bimg = reinterpret_cast<const u32x4 *>(image);
+    a.M = M; a.N = N; a.rows_per_cloud = 0;
+    a.C = C; a.ldc = ldc; a.store_n0 = 0; a.bias = bias;
+    hipStream_t st = (hipStream_t)stream;
+    if (tile == 0) tile = (long)((M + 63) / 64) * ((N + 127) / 128) >= 256 ? 2 : 3;
+    if (bias) {
+        if (tile == 2) return launch_rowgemm<1, 2, PRO_NONE, PW_STORE | PW_BIAS, 1, 1>(a, st, "fsg_pw_linear_bf16");
+        return launch_rowgemm<1, 1, PRO_NONE, PW_STORE | PW_BIAS, 1, 1>(a, st, "fsg_pw_linear_bf16");
+    }
+    if (tile == 2) return launch_rowgemm<1, 2, PRO_NONE, PW_STORE, 1, 1>(a, st, "fsg_pw_linear_bf16");
+    return launch_rowgemm<1, 1, PRO_NONE, PW_STORE, 1, 1>(a, st, "fsg_pw_linear_bf16");
 }
 
 extern "C" int fsg_pw_weight_images_f32(const fsg_pw_image_jobs *jobs, fsg_stream_t stream) {
@@ -1657,6 +1702,29 @@ extern "C" int fsg_pw_tn_f32(const fsg_pw_tn_args *a, int tile, void *workspace,
     hipLaunchKernelGGL(pw_tn_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, k.part, S, N1, a->N2, a->N1a,
                        C1, (long)ldc1, C2, (long)ldc2);
     FSG_CHECK_LAUNCH("fsg_pw_tn_f32/reduce");
+    return FSG_OK;
+}
+
+// bf16 operand mode of the row contraction (plain operands only): dW = bf16(dY)^T bf16(X), fp32 accumulation
+extern "C" int fsg_pw_tn_bf16(const fsg_pw_tn_args *a, int tile, void *workspace, size_t workspace_bytes, float *C1, int64_t ldc1,
+                              fsg_stream_t stream) {
+    FSG_REQUIRE(a && a->L1 && a->R && workspace && C1, "fsg_pw_tn_bf16: NULL pointer");
+    FSG_REQUIRE(a->M > 0 && a->N1a > 0 && a->N1b == 0 && a->N2 > 0 && a->rows_per_slice > 0 && a->rows_per_slice % 32 == 0 &&
+                    a->lpro == PRO_NONE && a->rpro == PRO_NONE, "fsg_pw_tn_bf16: plain single-segment operands only");
+    const int S = (a->M + a->rows_per_slice - 1) / a->rows_per_slice;
+    FSG_REQUIRE(workspace_bytes >= fsg_pw_tn_workspace_bytes(a->N1a, a->N2, a->M, a->rows_per_slice), "fsg_pw_tn_bf16: workspace too small");
+    TnArgs k{};
+    k.L1 = a->L1; k.ldl1 = a->ldl1; k.N1a = a->N1a; k.N1b = 0; k.lpro = PRO_NONE;
+    k.R = a->R; k.ldr = a->ldr; k.N2 = a->N2; k.rpro = PRO_NONE; k.slope = 0.f;
+    k.M = a->M; k.rows_per_cloud = 0; k.rows_per_slice = a->rows_per_slice;
+    k.part = reinterpret_cast<float *>(workspace);
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = tile == 2 ? launch_tn<1, 2, 1>(k, S, st) : launch_tn<1, 1, 1>(k, S, st);
+    if (rc != FSG_OK) return rc;
+    const long total = (long)a->N1a * a->N2;
+    hipLaunchKernelGGL(pw_tn_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, k.part, S, a->N1a, a->N2, a->N1a,
+                       C1, (long)ldc1, (float *)nullptr, 0L);
+    FSG_CHECK_LAUNCH("fsg_pw_tn_bf16/reduce");
     return FSG_OK;
 }
 

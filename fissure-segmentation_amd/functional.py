@@ -267,13 +267,18 @@ class _LinearPM(torch.autograd.Function):
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
-        ctx.bf16 = False
+        ctx.bf16 = ctx.pw16 = False
         x2 = x.reshape(-1, x.shape[-1])
         N, K = w.shape
         M = x2.shape[0]
-        if _small(M, N, K, x2, w):
+        if not (_bf16_linear and bf16_operands()) and _small(M, N, K, x2, w):
             y = gemm_small(x2, K, 1, w, 1, K, b.contiguous() if b is not None else None, M, N, K)
             return y.view(*x.shape[:-1], N)
+        ctx.pw16 = _pw_bf16_ok(x2, w)
+        if ctx.pw16:     # bf16 operand mode on the hand-written kernel: one bf16 piece per operand, fp32 accumulation
+            y = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)      # final shape: no view leaves the Function
+            pw_linear_bf16(x2, w, b, out=y.view(-1, N))
+            return y
         ctx.bf16 = _bf16_gemm() and x.is_cuda
         if ctx.bf16:
             y = _bf16_mm(x2, w.t())
@@ -291,6 +296,14 @@ class _LinearPM(torch.autograd.Function):
         gx = gw = gb = None
         if not g2.is_contiguous():
             g2 = g2.contiguous()
+        if ctx.pw16:     # both gradients on bf16 operands too: dX = bf16(dY) bf16(W), dW = bf16(dY)^T bf16(X)
+            if ctx.needs_input_grad[0]:
+                gx = (pw_linear_bf16(g2, w.t(), None) if w.shape[0] % 32 == 0 else g2 @ w).view_as(x)
+            if ctx.needs_input_grad[1]:
+                gw = pw_tn_bf16(g2, x2 if x2.is_contiguous() else x2.contiguous())
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = _bias_grad(g2)
+            return gx, gw, gb
         if ctx.needs_input_grad[0]:
             gx = _linear_dx(g2, w, bf16=ctx.bf16).view_as(x)
         if ctx.needs_input_grad[1]:
@@ -955,6 +968,63 @@ def pw_weight_images(specs):
     return outs
 
 
+# bf16 operands for the nn.Linear products (forward, dX, dW on fsg_pw_linear_bf16 / fsg_pw_tn_bf16) are a SEPARATE opt-in of the
+# bf16 mode: measured on the PointTransformer (BASELINE config 3, 2 x 2048 points against the fp32 oracle) they cost accuracy --
+# mean |logit error| 0.095, max 0.86, parameter-gradient cosine 0.36 through its 60 BatchNorms and 18 softmax layers -- and time
+# (9.0 vs 8.3 ms per step: three more small launches per Linear).  FSG_BF16_LINEAR=1 / set_bf16_linear(True) /
+# bench.py --workload c3 --dtype bf16 switch them on.
+_bf16_linear = _os.environ.get("FSG_BF16_LINEAR", "0") == "1"
+
+
+def set_bf16_linear(flag):
+    """bf16 operands for nn.Linear products while the bf16 operand mode is on (see above); returns the old value"""
+    global _bf16_linear
+    old, _bf16_linear = _bf16_linear, bool(flag)
+    return old
+
+
+def _pw_bf16_ok(x2, w):
+    """bf16 Linear products requested, and the product inside the envelope of fsg_pw_linear_bf16 (fp32 GPU rows, K % 32 == 0)"""
+    return (_bf16_linear and bf16_operands() and x2.is_cuda and x2.dtype == torch.float32 and w.dtype == torch.float32 and x2.dim() == 2 and
+            x2.stride(1) == 1 and x2.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0 and x2.shape[1] % 32 == 0 and x2.shape[0] > 0)
+
+
+def pw_linear_bf16(x, w, bias=None, tile=0, out=None):
+    """y (M, N) = bf16(x) bf16(w)^T (+ bias), fp32 accumulation: one-piece mode of csrc/pointwise.hip (include/fsg_hip.h:
+    fsg_pw_weight_image_bf16 + fsg_pw_linear_bf16).  w (N, K): any strides (a transposed view gives dX = dY W)."""
+    M, K = x.shape
+    N = w.shape[0]
+    dev = x.device
+    img = torch.empty(((N + 31) // 32) * ((K + 15) // 16) * 1024, dtype=torch.uint8, device=dev)
+    y = torch.empty(M, N, dtype=torch.float32, device=dev) if out is None else out
+    with torch.cuda.device(dev):
+        _lib.call("fsg_pw_weight_image_bf16", _p(w), w.stride(0), w.stride(1), N, K, _p(img), _stream())
+        _lib.call("fsg_pw_linear_bf16", _p(x), x.stride(0), _p(img), _p(bias.contiguous() if bias is not None else None), _p(y), N,
+                  M, N, K, tile, _stream())
+    return y
+
+
+def pw_tn_bf16(g, x, rows_per_slice=None):
+    """dW (N, K) = bf16(g)^T bf16(x) for g (M, N), x (M, K) contiguous rows, fp32 accumulation over the M rows in fixed slice
+    order (include/fsg_hip.h: fsg_pw_tn_bf16)"""
+    M, N = g.shape
+    K = x.shape[1]
+    dev = g.device
+    if rows_per_slice is None:      # enough slices to fill the chip, never below 64 rows
+        tiles = ((N + 63) // 64) * ((K + 63) // 64)
+        rows_per_slice = max(64, min(1024, ((M * tiles // 512) // 32) * 32)) if M * tiles >= 512 * 64 else 64
+    a = _lib.PWTnArgs()
+    a.L1, a.ldl1, a.N1a, a.N1b, a.lpro = g.data_ptr(), g.stride(0), N, 0, 0
+    a.R, a.ldr, a.N2, a.rpro = x.data_ptr(), x.stride(0), K, 0
+    a.M, a.rows_per_cloud, a.rows_per_slice = M, 0, rows_per_slice
+    nbytes = _lib.lib.fsg_pw_tn_workspace_bytes(N, K, M, rows_per_slice)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    out = torch.empty(N, K, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("fsg_pw_tn_bf16", ctypes.byref(a), 3, _p(ws), nbytes, _p(out), K, _stream())
+    return out
+
+
 def pw_linear(x, image, N, bias=None, tile=0):
     """y (M, N) = x (M, K) W^T (+ bias) with W given as pw_weight_image(W): six bf16 MFMA products per fp32 product, fp32
     accumulation (include/fsg_hip.h: fsg_pw_linear_f32)"""
@@ -1229,7 +1299,7 @@ def set_fused_head(flag):
 
 def seg_head_supported(levels, B, Npts, Wg, W0, W1, W2, W3):
     """the fused head needs: fp32 GPU rows, clouds of a multiple of 256 points, channel counts on the 32 / 64 grid"""
-    if not _fused_head or bf16_operands():
+    if not _fused_head:     # (bf16 operand mode keeps the fused head: its products are fp32-grade, above what the mode asks for)
         return False
     KL = levels.shape[1]
     return (levels.is_cuda and levels.dtype == torch.float32 and levels.stride(1) == 1 and levels.stride(0) % 4 == 0 and

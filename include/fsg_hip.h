@@ -472,6 +472,20 @@ int fsg_pw_linear_f32(const float *A, int64_t lda, const void *image, const floa
                       int K, int tile, fsg_stream_t stream);
 
 /*
+ * bf16 operand mode of the same kernels (BASELINE configs 3-5 name bf16; the reference trains under autocast,
+ * model_trainer.py:75-76,157): ONE bf16 piece per fp32 operand (round-to-nearest-even), one v_mfma_f32_32x32x16_bf16 product,
+ * fp32 accumulation, fp32 storage.  Carries the nn.Linear products of models/pointtransformer/seg_model.py (:25-33, :64-69,
+ * :92-99, :128-134, :168-169) when functional.set_mfma_operands("bf16") / an ambient autocast(bfloat16) is on.
+ *   fsg_pw_weight_image_bf16: (N, K) weight -> one-piece image of fsg_pw_weight_image_bytes(N, K) / 3 bytes
+ *   fsg_pw_linear_bf16:       C (M, N) = bf16(A) bf16(W)^T (+ bias), K % 32 == 0; tile 0 = by shape, 2 = 64 x 128, 3 = 64 x 64
+ *   fsg_pw_tn_bf16:           C1 (N1a, N2) = bf16(L1)^T bf16(R) over the M rows (plain single-segment operands of fsg_pw_tn_args),
+ *                             tile 2 = 64 x 128, 3 = 64 x 64
+ */
+int fsg_pw_weight_image_bf16(const float *W, int64_t stride_n, int64_t stride_k, int N, int K, void *image, fsg_stream_t stream);
+int fsg_pw_linear_bf16(const float *A, int64_t lda, const void *image, const float *bias, float *C, int64_t ldc, int M, int N,
+                       int K, int tile, fsg_stream_t stream);
+
+/*
  * The members of the family behind the fused DGCNN head (`functional.seg_head`; models/dgcnn.py:123-162 of the reference).
  * Tile codes: 1 = 128 x 128, 2 = 64 x 128, 3 = 64 x 64, 4 = 128 x 64 (rows x columns of C); fsg_pw_tile_rows(tile) = rows.
  *
@@ -558,6 +572,8 @@ int fsg_pw_tn_reduce_f32(const fsg_pw_tn_reduce_jobs *jobs, fsg_stream_t stream)
 size_t fsg_pw_tn_workspace_bytes(int N1, int N2, int M, int rows_per_slice);
 int fsg_pw_tn_f32(const fsg_pw_tn_args *args, int tile, void *workspace, size_t workspace_bytes, float *C1, int64_t ldc1,
                   float *C2, int64_t ldc2, fsg_stream_t stream);
+int fsg_pw_tn_bf16(const fsg_pw_tn_args *args, int tile, void *workspace, size_t workspace_bytes, float *C1, int64_t ldc1,
+                   fsg_stream_t stream);
 
 /*
  * fsg_pw_bn_finalize_f32: STATS records (R, 3, ldn), columns [c0, c0 + C) -> train-mode BatchNorm statistics (Chan's merge in
