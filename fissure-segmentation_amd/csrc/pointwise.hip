@@ -1573,6 +1573,11 @@ extern "C" int fsg_pw_linear_f32(const float *A, int64_t lda, const void *image,
         return launch_rowgemm<1, 1, PRO_NONE, PW_STORE | PW_BIAS>(a, st, "fsg_pw_linear_f32");
     }
     if (tile == 1) return launch_rowgemm<2, 2, PRO_NONE, PW_STORE, 0>(a, st, "fsg_pw_linear_f32");
+    // tools/bench_pw.py: the other loop structure of each tile (11 = 128 x 128 double-buffered, 12-14 = single-buffered)
+    if (tile == 11) return launch_rowgemm<2, 2, PRO_NONE, PW_STORE, 1>(a, st, "fsg_pw_linear_f32");
+    if (tile == 12) return launch_rowgemm<1, 2, PRO_NONE, PW_STORE, 0>(a, st, "fsg_pw_linear_f32");
+    if (tile == 13) return launch_rowgemm<1, 1, PRO_NONE, PW_STORE, 0>(a, st, "fsg_pw_linear_f32");
+    if (tile == 14) return launch_rowgemm<2, 1, PRO_NONE, PW_STORE, 0>(a, st, "fsg_pw_linear_f32");
     if (tile == 2) return launch_rowgemm<1, 2, PRO_NONE, PW_STORE>(a, st, "fsg_pw_linear_f32");
     if (tile == 4) return launch_rowgemm<2, 1, PRO_NONE, PW_STORE>(a, st, "fsg_pw_linear_f32");
     return launch_rowgemm<1, 1, PRO_NONE, PW_STORE>(a, st, "fsg_pw_linear_f32");

@@ -42,7 +42,8 @@ for (M, N, K) in shapes:
     t_v = replay_us(lambda: torch.nn.functional.linear(a, w))
     t_img = replay_us(lambda: F.pw_weight_image(w))
     row = "%6d x %4d x %3d  vendor fp32 %7.1f us %6.1f TF | image %5.1f us |" % (M, N, K, t_v, flop / t_v * 1e-6, t_img)
-    for tile, name in ((1, "128x128"), (2, "64x128"), (4, "128x64"), (3, "64x64")):
+    for tile, name in ((1, "128x128 sb"), (11, "128x128 db"), (2, "64x128 db"), (12, "64x128 sb"), (4, "128x64 db"), (14, "128x64 sb"),
+                       (3, "64x64 db"), (13, "64x64 sb")):
         t = replay_us(lambda: F.pw_linear(a, img, N, tile=tile))
         row += " %s %6.1f us %6.1f TF |" % (name, t, flop / t * 1e-6)
     print(row, flush=True)
