@@ -92,13 +92,11 @@ SIGNATURES = {
     "fsg_pw_max_finish_f32": ([_P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P], _I),
     "fsg_pw_bnbwd_finalize_f32": ([_P, _I, _I, _I, _L, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P], _I),
     "fsg_pw_logits_bwd_f32": ([_P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _P, _P], _I),
-    "fsg_pw_gf_prep_f32": ([_P, _P, _L, _I, _P, _P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _F, _P, _P, _P, _P, _P, _P], _I),
-    "fsg_pw_gf_m1_f32": ([_P, _L, _P, _P, _I, _I, _P, _P, _P], _I),
+    "fsg_pw_gf_prep_f32": ([_P, _P, _L, _I, _P, _P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _F, _P, _P, _P, _P, _P, _P, _L, _I, _P, _L,
+                            _P], _I),
     "fsg_pw_scatter_rows_workspace_bytes": ([_I, _I], ctypes.c_size_t),
     "fsg_pw_scatter_rows_f32": ([_P, _P, _P, _L, _I, _I, _I, _I, _P, _L, _P, _P], _I),
     "fsg_pw_gf_dw_f32": ([_P, _P, _P, _L, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _P, _L, _P], _I),
-    "fsg_pw_colsum_workspace_bytes": ([_L, _I], ctypes.c_size_t),
-    "fsg_pw_colsum_f32": ([_P, _L, _L, _I, _P, _P, _P], _I),
 }
 for _name, (_args, _res) in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here = header and library out of sync
@@ -170,7 +168,7 @@ class PWTnArgs(ctypes.Structure):
     _fields_ = [("L1", _P), ("LY1", _P), ("L2", _P), ("ldl1", _L), ("ldl2", _L), ("N1a", _I), ("N1b", _I), ("lpro", _I),
                 ("lalpha", _P), ("ldelta", _P), ("lP", _P), ("lQ", _P), ("lts", _I), ("R", _P), ("ldr", _L), ("N2", _I),
                 ("rpro", _I), ("ralpha", _P), ("rdelta", _P), ("rts", _I), ("slope", _F), ("M", _I), ("rows_per_cloud", _I),
-                ("rows_per_slice", _I)]
+                ("rows_per_slice", _I), ("ones", _I)]
 
 
 class PTLayerGrads(ctypes.Structure):

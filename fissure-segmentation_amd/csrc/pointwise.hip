@@ -606,7 +606,8 @@ struct TnArgs {
     int rts;
     float slope;
     int M, rows_per_cloud, rows_per_slice;
-    float *part;             // (S, N1a + N1b, N2)
+    int ones;                // 1: one more left column behind segment 2 that is all ones -> result row N1a + N1b = column sums of R'
+    float *part;             // (S, N1a + N1b + ones, N2)
 };
 
 template <int T1, int T2, int NP = 3>
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(256) void pw_tn_kernel(const TnArgs p) {
     __shared__ __attribute__((aligned(16))) u32x4 Limg[(BT1 / 32) * 2 * NP * 64];
     __shared__ __attribute__((aligned(16))) u32x4 Rimg[(BT2 / 32) * 2 * NP * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int N1 = p.N1a + p.N1b;
+    const int N1 = p.N1a + p.N1b + p.ones;
     const int nt2 = (p.N2 + BT2 - 1) / BT2;
     const int t1 = blockIdx.x / nt2, t2 = blockIdx.x - t1 * nt2, s = blockIdx.y;
     const int c1_0 = t1 * BT1, c2_0 = t2 * BT2;
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(256) void pw_tn_kernel(const TnArgs p) {
     const int cloud = p.rows_per_cloud > 0 ? m0 / p.rows_per_cloud : 0;
     const int ks = wave >> 1, hh = wave & 1;            // this wave's fragment rows: 16 ks + 8 hh + 0..7 of every 32-row step
     // per-column constants of this thread's columns
-    float la[T1], ld_[T1], lp[T1], lq[T1], lmask[T1];
+    float la[T1], ld_[T1], lp[T1], lq[T1], lmask[T1], lone[T1];
     const float *lsrc[T1], *lysrc[T1];
     long lld[T1];
     bool lbwd[T1];
@@ -631,8 +632,9 @@ __global__ __launch_bounds__(256) void pw_tn_kernel(const TnArgs p) {
     for (int g = 0; g < T1; ++g) {
         const int col = c1_0 + 64 * g + lane;
         const bool seg2 = (c1_0 + 64 * g) >= p.N1a && p.N1b > 0;     // 64-column groups never straddle the segments (host check)
-        const int cc = min(col, N1 - 1);
+        const int cc = min(col, p.N1a + p.N1b - 1);
         lmask[g] = col < N1 ? 1.f : 0.f;
+        lone[g] = (p.ones && col == p.N1a + p.N1b) ? 1.f : 0.f;
         lbwd[g] = !seg2 && p.lpro == PRO_BNBWD;
         lsrc[g] = seg2 ? p.L2 + (cc - p.N1a) : p.L1 + cc;
         lysrc[g] = lbwd[g] ? p.LY1 + cc : lsrc[g];
@@ -692,6 +694,7 @@ __global__ __launch_bounds__(256) void pw_tn_kernel(const TnArgs p) {
                     const float h = v * (u > 0.f ? 1.f : p.slope);
                     v = __builtin_fmaf(la[g], h, -__builtin_fmaf(lq[g], y, lp[g]));
                 }
+                v = lone[g] != 0.f ? 1.f : v;
                 x[j] = v * live;
             }
             u32x4 h, m, l;
@@ -855,14 +858,25 @@ __global__ __launch_bounds__(256) void pw_bn_finalize_kernel(const float *__rest
         double a = 0.0, bm = 0.0, cm = 0.0;
         if (live) {
             const int r0 = sl * per, r1 = min(R, r0 + per);
-            for (int r = r0; r < r1; ++r) {
-                const float *pr = rec + (long)r * 3 * ldn + c0 + c;
-                const double n = pr[0];
-                double mu = pr[ldn];
-                if (shift) mu += (double)shift_of(r / rpc);
-                a += n;
-                bm += n * mu;
-                cm += (double)pr[2 * ldn] + n * mu * mu;
+            for (int rb = r0; rb < r1; rb += 8) {           // eight records' loads in flight together (one round trip, not eight)
+                float nv[8], mv[8], qv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float *pr = rec + (long)min(rb + u, r1 - 1) * 3 * ldn + c0 + c;
+                    nv[u] = pr[0];
+                    mv[u] = pr[ldn];
+                    qv[u] = pr[2 * ldn];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (rb + u < r1) {
+                        const double n = nv[u];
+                        double mu = mv[u];
+                        if (shift) mu += (double)shift_of((rb + u) / rpc);
+                        a += n;
+                        bm += n * mu;
+                        cm += (double)qv[u] + n * mu * mu;
+                    }
             }
         }
         red[0][sl][ch] = a;
@@ -990,9 +1004,20 @@ __global__ __launch_bounds__(256) void pw_bnbwd_finalize_kernel(const float *__r
     double sb = 0.0, sg = 0.0;
     if (live) {
         const int r0 = sl * per, r1 = min(R, r0 + per);
-        for (int r = r0; r < r1; ++r) {
-            sb += (double)rec2[(long)r * 2 * C + c];
-            sg += (double)rec2[(long)r * 2 * C + C + c];
+        for (int rb = r0; rb < r1; rb += 8) {               // eight records' loads in flight together
+            float bv[8], gv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long r = min(rb + u, r1 - 1);
+                bv[u] = rec2[r * 2 * C + c];
+                gv[u] = rec2[r * 2 * C + C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (rb + u < r1) {
+                    sb += (double)bv[u];
+                    sg += (double)gv[u];
+                }
         }
     }
     red[0][sl][ch] = sb;
@@ -1098,8 +1123,11 @@ __global__ __launch_bounds__(256) void pw_gf_prep_kernel(const float *__restrict
                                                          const float *__restrict__ mean, const float *__restrict__ invstd,
                                                          int B, int C, long M, int training, float slope,
                                                          float *__restrict__ dbeta, float *__restrict__ dgamma,
-                                                         float *__restrict__ P, float *__restrict__ Q, float *__restrict__ coef) {
+                                                         float *__restrict__ P, float *__restrict__ Q, float *__restrict__ coef,
+                                                         const float *__restrict__ Wgl, long ldwgl, int KL,
+                                                         float *__restrict__ Wq, long ldwq) {
     extern __shared__ float dcs[];     // (B, C0) when dc is given, then [4][GP_MAXB][64] partial dg
+    __shared__ float qs[64], ps[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = min(blockIdx.x * 64 + lane, C - 1);       // 64 channels per workgroup, the four waves split k
     const bool livec = blockIdx.x * 64 + lane < C;
@@ -1133,24 +1161,36 @@ __global__ __launch_bounds__(256) void pw_gf_prep_kernel(const float *__restrict
 #pragma unroll
         for (int b = 0; b < GP_MAXB; ++b) dgv[b] = b < B ? dg_in[(long)b * C + c] : 0.f;
     }
-    if (wave != 0 || !livec) return;
-    const float al = alpha[c], de = delta[c], mu = mean[c], r = invstd[c];
-    float sb = 0.f, sg = 0.f;
+    if (wave == 0 && livec) {
+        const float al = alpha[c], de = delta[c], mu = mean[c], r = invstd[c];
+        float sb = 0.f, sg = 0.f;
 #pragma unroll
-    for (int b = 0; b < GP_MAXB; ++b)
-        if (b < B) {
-            const float ys = ysel[(long)b * C + c], u = __builtin_fmaf(ys, al, de);
-            const float h = dgv[b] * (u > 0.f ? 1.f : slope);
-            coef[(long)b * C + c] = al * h;
-            sb += h;
-            sg = __builtin_fmaf(h, (ys - mu) * r, sg);
-        }
-    dbeta[c] = sb;
-    dgamma[c] = sg;
-    const float invM = 1.0f / (float)M;
-    const float db = training ? sb * invM : 0.f, dgm = training ? sg * invM * r : 0.f;
-    Q[c] = al * dgm;
-    P[c] = al * (db - mu * dgm);
+        for (int b = 0; b < GP_MAXB; ++b)
+            if (b < B) {
+                const float ys = ysel[(long)b * C + c], u = __builtin_fmaf(ys, al, de);
+                const float h = dgv[b] * (u > 0.f ? 1.f : slope);
+                coef[(long)b * C + c] = al * h;
+                sb += h;
+                sg = __builtin_fmaf(h, (ys - mu) * r, sg);
+            }
+        dbeta[c] = sb;
+        dgamma[c] = sg;
+        const float invM = 1.0f / (float)M;
+        const float db = training ? sb * invM : 0.f, dgm = training ? sg * invM * r : 0.f;
+        const float q = al * dgm, pp = al * (db - mu * dgm);
+        Q[c] = q;
+        P[c] = pp;
+        qs[lane] = q;
+        ps[lane] = pp;
+    }
+    if (!Wq) return;
+    __syncthreads();
+    // rows [Q[c] W[c, :] | -P[c]] of this workgroup's 64 channels: the left operand of  [M1 ; npvec] = [Q o W | -P]^T W
+    const int cbase = blockIdx.x * 64;
+    for (int e = threadIdx.x; e < 64 * (KL + 1); e += 256) {
+        const int rr = e / (KL + 1), j = e - rr * (KL + 1);
+        if (cbase + rr < C) Wq[(long)(cbase + rr) * ldwq + j] = j < KL ? qs[rr] * Wgl[(long)(cbase + rr) * ldwgl + j] : -ps[rr];
+    }
 }
 
 // dW0g[k, j] = sum_b dc[b, k] g[b, j]  (C0 x CG outputs, B terms each): thread = column j, eight rows k per workgroup row
@@ -1169,37 +1209,6 @@ __global__ __launch_bounds__(256) void pw_outer_kernel(const float *__restrict__
 #pragma unroll
         for (int b = 0; b < GP_MAXB; ++b) a = __builtin_fmaf(b < B ? dc[(long)b * C0 + k] : 0.f, gv[b], a);
         out[(long)k * ldo + j] = a;
-    }
-}
-
-// M1 = W^T diag(Q) W (K x K) and npvec = -W^T P (K) of the Gram-form backward: output row i (row K = npvec) per workgroup
-// row, lane = column chunk, the four waves split the C channels; fixed-order LDS fold
-__global__ __launch_bounds__(256) void pw_gf_m1_kernel(const float *__restrict__ W, long ldw, const float *__restrict__ Q,
-                                                       const float *__restrict__ P, int C, int K, float *__restrict__ M1,
-                                                       float *__restrict__ npvec) {
-    __shared__ float red[4][64];
-    const int i = blockIdx.x, j = blockIdx.y * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int jj = min(j, K - 1);
-    const int per = (C + 3) / 4, c0 = wave * per, c1 = min(C, c0 + per);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int c = c0;
-    for (; c + 4 <= c1; c += 4) {
-        const float s0 = i < K ? Q[c] * W[(long)c * ldw + i] : -P[c];
-        const float s1 = i < K ? Q[c + 1] * W[(long)(c + 1) * ldw + i] : -P[c + 1];
-        const float s2 = i < K ? Q[c + 2] * W[(long)(c + 2) * ldw + i] : -P[c + 2];
-        const float s3 = i < K ? Q[c + 3] * W[(long)(c + 3) * ldw + i] : -P[c + 3];
-        a0 = __builtin_fmaf(s0, W[(long)c * ldw + jj], a0);
-        a1 = __builtin_fmaf(s1, W[(long)(c + 1) * ldw + jj], a1);
-        a2 = __builtin_fmaf(s2, W[(long)(c + 2) * ldw + jj], a2);
-        a3 = __builtin_fmaf(s3, W[(long)(c + 3) * ldw + jj], a3);
-    }
-    for (; c < c1; ++c) a0 = __builtin_fmaf(i < K ? Q[c] * W[(long)c * ldw + i] : -P[c], W[(long)c * ldw + jj], a0);
-    red[wave][lane] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (wave == 0 && j < K) {
-        const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-        if (i < K) M1[(long)i * K + j] = v;
-        else npvec[j] = v;
     }
 }
 
@@ -1391,78 +1400,6 @@ __global__ __launch_bounds__(256) void pw_gf_dw_kernel(const float *__restrict__
         }
         __syncthreads();
     }
-}
-
-// column sums of (M, K) rows: partial sums per 64-row block (wave = 16 rows, lane = column, all loads independent), then a
-// fixed-order sum in fp64
-constexpr int CS_ROWS = 64;
-__global__ __launch_bounds__(256) void pw_colsum_part_kernel(const float *__restrict__ X, long ldx, long M, int K,
-                                                             float *__restrict__ part) {
-    __shared__ float red[4][64];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long r0 = (long)blockIdx.x * CS_ROWS + wave * 16;
-    for (int k0 = 0; k0 < K; k0 += 64) {
-        const int k = min(k0 + lane, K - 1);
-        float v[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = r0 + i < M ? X[(r0 + i) * ldx + k] : 0.f;
-        float a = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) a += v[i];
-        red[wave][lane] = a;
-        __syncthreads();
-        if (wave == 0 && k0 + lane < K) part[(long)blockIdx.x * K + k0 + lane] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-        __syncthreads();
-    }
-}
-__global__ __launch_bounds__(256) void pw_colsum_fold_kernel(const float *__restrict__ part, int R, int K, float *__restrict__ out) {
-    __shared__ double red[16][16];
-    const int ch = threadIdx.x & 15, sl = threadIdx.x >> 4, k = blockIdx.x * 16 + ch;
-    double a = 0.0;
-    if (k < K)
-        for (int r = sl; r < R; r += 16) a += (double)part[(long)r * K + k];
-    red[sl][ch] = a;
-    __syncthreads();
-    if (sl == 0 && k < K) {
-        a = 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) a += red[q][ch];
-        out[k] = (float)a;
-    }
-}
-
-// several deferred reductions in one launch: job j owns the elements [first[j], first[j + 1])
-struct TnReduceJobs {
-    const float *part[FSG_PW_MAX_REDUCE_JOBS];
-    float *C1[FSG_PW_MAX_REDUCE_JOBS], *C2[FSG_PW_MAX_REDUCE_JOBS];
-    long ldc1[FSG_PW_MAX_REDUCE_JOBS], ldc2[FSG_PW_MAX_REDUCE_JOBS], first[FSG_PW_MAX_REDUCE_JOBS + 1];
-    int S[FSG_PW_MAX_REDUCE_JOBS], N1[FSG_PW_MAX_REDUCE_JOBS], N2[FSG_PW_MAX_REDUCE_JOBS], N1a[FSG_PW_MAX_REDUCE_JOBS];
-    int n;
-};
-__global__ __launch_bounds__(256) void pw_tn_reduce_many_kernel(const TnReduceJobs jobs) {
-    const long g = (long)blockIdx.x * 256 + threadIdx.x;
-    if (g >= jobs.first[jobs.n]) return;
-    int j = 0;
-#pragma unroll
-    for (int q = 1; q < FSG_PW_MAX_REDUCE_JOBS; ++q)
-        if (q < jobs.n && g >= jobs.first[q]) j = q;
-    const long t = g - jobs.first[j];
-    const int S = jobs.S[j], N2 = jobs.N2[j];
-    const long total = (long)jobs.N1[j] * N2;
-    const float *part = jobs.part[j];
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int q = 0;
-    for (; q + 4 <= S; q += 4) {
-        a0 += part[(long)q * total + t];
-        a1 += part[(long)(q + 1) * total + t];
-        a2 += part[(long)(q + 2) * total + t];
-        a3 += part[(long)(q + 3) * total + t];
-    }
-    for (; q < S; ++q) a0 += part[(long)q * total + t];
-    const float v = (a0 + a1) + (a2 + a3);
-    const int r = (int)(t / N2), c = (int)(t - (long)r * N2);
-    if (r < jobs.N1a[j]) jobs.C1[j][(long)r * jobs.ldc1[j] + c] = v;
-    else jobs.C2[j][(long)(r - jobs.N1a[j]) * jobs.ldc2[j] + c] = v;
 }
 
 template <int T1, int T2, int NP = 3>
@@ -1675,7 +1612,7 @@ extern "C" size_t fsg_pw_tn_workspace_bytes(int N1, int N2, int M, int rows_per_
 extern "C" int fsg_pw_tn_f32(const fsg_pw_tn_args *a, int tile, void *workspace, size_t workspace_bytes, float *C1,
                              int64_t ldc1, float *C2, int64_t ldc2, fsg_stream_t stream) {
     FSG_REQUIRE(a && a->L1 && a->R && workspace, "fsg_pw_tn_f32: NULL pointer");
-    const int N1 = a->N1a + a->N1b;
+    const int N1 = a->N1a + a->N1b + (a->ones ? 1 : 0);
     FSG_REQUIRE(a->M > 0 && a->N1a > 0 && a->N1b >= 0 && a->N2 > 0 && a->rows_per_slice > 0 && a->rows_per_slice % 32 == 0,
                 "fsg_pw_tn_f32: bad shape M=%d N1=%d+%d N2=%d rows_per_slice=%d", a->M, a->N1a, a->N1b, a->N2, a->rows_per_slice);
     FSG_REQUIRE(a->N1b == 0 || (a->N1a % 64 == 0 && a->L2 && (C2 || !C1)), "fsg_pw_tn_f32: two left segments need N1a %% 64 == 0, L2 and C2");
@@ -1692,6 +1629,7 @@ extern "C" int fsg_pw_tn_f32(const fsg_pw_tn_args *a, int tile, void *workspace,
     k.lalpha = a->lalpha; k.ldelta = a->ldelta; k.lP = a->lP; k.lQ = a->lQ; k.lts = a->lts;
     k.R = a->R; k.ldr = a->ldr; k.N2 = a->N2; k.rpro = a->rpro; k.ralpha = a->ralpha; k.rdelta = a->rdelta; k.rts = a->rts;
     k.slope = a->slope; k.M = a->M; k.rows_per_cloud = a->rows_per_cloud; k.rows_per_slice = a->rows_per_slice;
+    k.ones = a->ones ? 1 : 0;
     k.part = reinterpret_cast<float *>(workspace);
     hipStream_t st = (hipStream_t)stream;
     int rc;
@@ -1816,28 +1754,22 @@ extern "C" int fsg_pw_logits_bwd_f32(const float *g, int classes, const float *W
 extern "C" int fsg_pw_gf_prep_f32(const float *dc, const float *W0g, int64_t ldw0, int C0, const float *gfeat, float *dW0g,
                                   int64_t lddw0, const float *dg, const float *ysel, const float *alpha, const float *delta,
                                   const float *mean, const float *invstd, int B, int C, int64_t M, int training, float slope,
-                                  float *dbeta, float *dgamma, float *P, float *Q, float *coef, fsg_stream_t stream) {
+                                  float *dbeta, float *dgamma, float *P, float *Q, float *coef, const float *W, int64_t ldw, int K,
+                                  float *Wq, int64_t ldwq, fsg_stream_t stream) {
+    FSG_REQUIRE(!Wq || (W && K > 0 && ldwq >= K + 1), "fsg_pw_gf_prep_f32: Wq needs W, K and ldwq >= K + 1");
     FSG_REQUIRE(ysel && alpha && delta && mean && invstd && dbeta && dgamma && P && Q && coef && B > 0 && B <= GP_MAXB && C > 0 && M > 0,
                 "fsg_pw_gf_prep_f32: bad arguments (B <= %d)", GP_MAXB);
     FSG_REQUIRE((dc && W0g && gfeat && dW0g && C0 > 0 && (size_t)B * C0 * 4 <= 32 * 1024) || (!dc && dg),
                 "fsg_pw_gf_prep_f32: either dc + W0g + gfeat + dW0g (B C0 <= 8192) or dg");
     hipLaunchKernelGGL(pw_gf_prep_kernel, dim3((C + 63) / 64), dim3(256), dc ? sizeof(float) * (B * C0 + 4 * GP_MAXB * 64) : 0, (hipStream_t)stream, dc,
                        W0g, (long)ldw0, C0, gfeat, dW0g, (long)lddw0, dg, ysel, alpha, delta, mean, invstd, B, C, (long)M, training,
-                       slope, dbeta, dgamma, P, Q, coef);
+                       slope, dbeta, dgamma, P, Q, coef, W, (long)ldw, K, Wq, (long)ldwq);
     FSG_CHECK_LAUNCH("fsg_pw_gf_prep_f32");
     if (dc) {
         hipLaunchKernelGGL(pw_outer_kernel, dim3((C + 255) / 256, (C0 + 7) / 8), dim3(256), 0, (hipStream_t)stream, dc, gfeat, B, C0, C,
                            dW0g, (long)lddw0);
         FSG_CHECK_LAUNCH("fsg_pw_gf_prep_f32/outer");
     }
-    return FSG_OK;
-}
-
-extern "C" int fsg_pw_gf_m1_f32(const float *W, int64_t ldw, const float *Q, const float *P, int C, int K, float *M1, float *npvec,
-                                fsg_stream_t stream) {
-    FSG_REQUIRE(W && Q && P && M1 && npvec && C > 0 && K > 0, "fsg_pw_gf_m1_f32: bad arguments");
-    hipLaunchKernelGGL(pw_gf_m1_kernel, dim3(K + 1, (K + 63) / 64), dim3(256), 0, (hipStream_t)stream, W, (long)ldw, Q, P, C, K, M1, npvec);
-    FSG_CHECK_LAUNCH("fsg_pw_gf_m1_f32");
     return FSG_OK;
 }
 
@@ -1872,17 +1804,5 @@ extern "C" int fsg_pw_gf_dw_f32(const float *coef, const int32_t *arg, const flo
     hipLaunchKernelGGL(pw_gf_dw_kernel, dim3((C + 3) / 4), dim3(256), sizeof(float) * (4 * K + 16 * 64), (hipStream_t)stream, coef, arg, X,
                        (long)ldx, s, W, (long)ldw, G, P, Q, B, C, K, Npts, dW, (long)lddw);
     FSG_CHECK_LAUNCH("fsg_pw_gf_dw_f32");
-    return FSG_OK;
-}
-
-extern "C" size_t fsg_pw_colsum_workspace_bytes(int64_t M, int K) { return sizeof(float) * (size_t)((M + CS_ROWS - 1) / CS_ROWS) * K; }
-
-extern "C" int fsg_pw_colsum_f32(const float *X, int64_t ldx, int64_t M, int K, float *out, float *workspace, fsg_stream_t stream) {
-    FSG_REQUIRE(X && out && workspace && M > 0 && K > 0, "fsg_pw_colsum_f32: bad arguments");
-    const int R = (int)((M + CS_ROWS - 1) / CS_ROWS);
-    hipLaunchKernelGGL(pw_colsum_part_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, X, (long)ldx, (long)M, K, workspace);
-    FSG_CHECK_LAUNCH("fsg_pw_colsum_f32/part");
-    hipLaunchKernelGGL(pw_colsum_fold_kernel, dim3((K + 15) / 16), dim3(256), 0, (hipStream_t)stream, workspace, R, K, out);
-    FSG_CHECK_LAUNCH("fsg_pw_colsum_f32/fold");
     return FSG_OK;
 }

@@ -1072,14 +1072,15 @@ def pw_tn(tile, C1, ldc1, C2=None, ldc2=0, defer=None, **kw):
             v = v.data_ptr()
         setattr(a, k, v)
     dev = C1.device
-    nbytes = _lib.lib.fsg_pw_tn_workspace_bytes(a.N1a + a.N1b, a.N2, a.M, a.rows_per_slice)
+    N1 = a.N1a + a.N1b + (1 if a.ones else 0)
+    nbytes = _lib.lib.fsg_pw_tn_workspace_bytes(N1, a.N2, a.M, a.rows_per_slice)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         if defer is None:
             _lib.call("fsg_pw_tn_f32", ctypes.byref(a), tile, _p(ws), nbytes, _p(C1), ldc1, _p(C2), ldc2, _stream())
         else:
             _lib.call("fsg_pw_tn_f32", ctypes.byref(a), tile, _p(ws), nbytes, None, 0, None, 0, _stream())
-            defer.append((ws, C1, ldc1, C2, ldc2, (a.M + a.rows_per_slice - 1) // a.rows_per_slice, a.N1a + a.N1b, a.N2, a.N1a))
+            defer.append((ws, C1, ldc1, C2, ldc2, (a.M + a.rows_per_slice - 1) // a.rows_per_slice, N1, a.N2, a.N1a))
 
 
 def pw_tn_reduce(jobs):
@@ -1260,16 +1261,21 @@ class _SegHead(torch.autograd.Function):
         dbg, dgg = torch.empty(CG, **f32), torch.empty(CG, **f32)
         Pg, Qg, coef = torch.empty(CG, **f32), torch.empty(CG, **f32), torch.empty(B, CG, **f32)
         W0G, dW0G = W0[:, KL:], dW0[:, KL:]
+        ldq = (KL + 4) & ~3
+        Wq = torch.empty(CG, ldq, **f32)                                   # rows [Q o Wg | -P]
         call("fsg_pw_gf_prep_f32", _p(dc), _p(W0G), W0.stride(0), C0, _p(g), _p(dW0G), dW0.stride(0), None, _p(ysel), _p(al_g),
-             _p(de_g), _p(mean_g), _p(inv_g), B, CG, M, int(tr_g), slope, _p(dbg), _p(dgg), _p(Pg), _p(Qg), _p(coef))
-        # W^T diag(Q) W and -(W^T P): two small vendor products (fsg_pw_gf_m1_f32 does the same in one launch, but its first
-        # version is slower than the pair: 79 us against ~24)
-        M1 = (Wg * Qg.unsqueeze(1)).t() @ Wg
-        npvec = -(Pg @ Wg)
+             _p(de_g), _p(mean_g), _p(inv_g), B, CG, M, int(tr_g), slope, _p(dbg), _p(dgg), _p(Pg), _p(Qg), _p(coef), _p(Wg),
+             Wg.stride(0), KL, _p(Wq), ldq)
+        # [M1 ; npvec] = [Q o Wg | -P]^T Wg with M1 = Wg^T diag(Q) Wg: one row contraction over the CG channel rows
+        m1n = torch.empty(KL + 1, KL, **f32)
+        pw_tn(3, m1n, KL, L1=Wq, ldl1=ldq, N1a=KL + 1, N1b=0, lpro=PRO_NONE, R=Wg, ldr=Wg.stride(0), N2=KL, rpro=PRO_NONE, slope=slope,
+              M=CG, rows_per_cloud=0, rows_per_slice=64)
+        M1, npvec = m1n[:KL], m1n[KL]
         ks_a, ks_b = C0 // 16, KL // 16
         pw_weight_image(M1, scale=-1.0, out=img_lv, ks0=ks_a, KS=ks_a + ks_b)
-        G = torch.empty(KL, KL, **f32)
-        pw_tn(5, dW0, KL + CG, G, KL, defer=folds, L1=da0, LY1=y0, L2=levels, ldl1=C0, ldl2=levels.stride(0), N1a=C0, N1b=KL, lpro=PRO_BNBWD,
+        Gs = torch.empty(KL + 1, KL, **f32)          # [X^T X ; column sums of X] (the all-ones column behind the left operand)
+        G, s = Gs[:KL], Gs[KL]
+        pw_tn(5, dW0, KL + CG, Gs, KL, defer=folds, ones=1, L1=da0, LY1=y0, L2=levels, ldl1=C0, ldl2=levels.stride(0), N1a=C0, N1b=KL, lpro=PRO_BNBWD,
               lalpha=al_0, ldelta=de_0, lP=P0, lQ=Q0, lts=C0, R=levels, ldr=levels.stride(0), N2=KL, rpro=PRO_NONE, slope=slope,
               M=M, rows_per_cloud=Npts, rows_per_slice=256)
         pw_tn_reduce(folds)             # dW3, dW2, dW1, [dW0_levels ; G]
@@ -1279,10 +1285,6 @@ class _SegHead(torch.autograd.Function):
                    C=dlv, ldc=KL, store_n0=0, bias=npvec)
         sws = torch.empty(_lib.lib.fsg_pw_scatter_rows_workspace_bytes(B, CG) // 4, dtype=torch.int32, device=dev)
         call("fsg_pw_scatter_rows_f32", _p(coef), _p(arg), _p(Wg), Wg.stride(0), B, CG, KL, Npts, _p(dlv), KL, _p(sws))
-        s = torch.empty(KL, **f32)
-        wsb = _lib.lib.fsg_pw_colsum_workspace_bytes(M, KL)
-        ws = torch.empty(wsb // 4, **f32)
-        call("fsg_pw_colsum_f32", _p(levels), levels.stride(0), M, KL, _p(s), _p(ws))
         dWg = torch.empty(CG, KL, **f32)
         call("fsg_pw_gf_dw_f32", _p(coef), _p(arg), _p(levels), levels.stride(0), _p(s), _p(Wg), Wg.stride(0), _p(G), _p(Pg), _p(Qg),
              B, CG, KL, Npts, _p(dWg), KL)

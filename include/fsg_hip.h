@@ -559,6 +559,7 @@ typedef struct fsg_pw_tn_args {
     int rts;
     float slope;
     int M, rows_per_cloud, rows_per_slice;
+    int ones;      /* 1: one more left column (behind segment 2) that is all ones: result row N1a + N1b = column sums of R' */
 } fsg_pw_tn_args;
 #define FSG_PW_MAX_REDUCE_JOBS 6
 typedef struct fsg_pw_tn_reduce_jobs {
@@ -613,26 +614,24 @@ int fsg_pw_logits_bwd_f32(const float *g, int classes, const float *W3, const fl
  * fsg_pw_gf_prep_f32: per channel dbeta, dgamma, P, Q and coef (B, C) = weight of the selected row in dy.  The gradient of the
  *   global feature is either given (dg (B, C), dc == NULL) or formed here from the gradient dc (B, C0) of the first head layer's
  *   per-cloud constant: dg = dc W0g (W0g (C0, C), row stride ldw0), together with dW0g (C0, C) = dc^T gfeat (B <= 8).
- * fsg_pw_gf_m1_f32: M1 (K, K) = W^T diag(Q) W and npvec (K) = -W^T P.
+ *   Wq != NULL: also the rows [Q[c] W[c, :] | -P[c]] (C, K + 1) with row stride ldwq -- the left operand of the row contraction
+ *   [M1 ; npvec] = [Q o W | -P]^T W (fsg_pw_tn_f32 over the C channel rows).
  * fsg_pw_scatter_rows_f32: dX[b Npts + arg[b,c], :] += coef[b,c] W[c, :], summed per destination row in channel order
  *   (C <= 4096; workspace fsg_pw_scatter_rows_workspace_bytes(B, C) bytes for the sorted selection keys).
  * fsg_pw_gf_dw_f32: dW[c, :] = sum_b coef[b,c] X[b Npts + arg[b,c], :] - P[c] s - Q[c] (W G)[c, :]  (G (K, K) contiguous).
- * fsg_pw_colsum_f32: s = column sums of (M, K) rows (fixed order; workspace fsg_pw_colsum_workspace_bytes(M, K)).
+ *   (s = column sums of X and G come out of ONE row contraction: fsg_pw_tn_f32 with `ones` = 1.)
  */
 int fsg_pw_gf_prep_f32(const float *dc, const float *W0g, int64_t ldw0, int C0, const float *gfeat, float *dW0g, int64_t lddw0,
                        const float *dg, const float *ysel, const float *alpha, const float *delta, const float *mean,
                        const float *invstd, int B, int C, int64_t M, int training, float slope, float *dbeta, float *dgamma,
-                       float *P, float *Q, float *coef, fsg_stream_t stream);
-int fsg_pw_gf_m1_f32(const float *W, int64_t ldw, const float *Q, const float *P, int C, int K, float *M1, float *npvec,
-                     fsg_stream_t stream);
+                       float *P, float *Q, float *coef, const float *W, int64_t ldw, int K, float *Wq, int64_t ldwq,
+                       fsg_stream_t stream);
 size_t fsg_pw_scatter_rows_workspace_bytes(int B, int C);
 int fsg_pw_scatter_rows_f32(const float *coef, const int32_t *arg, const float *W, int64_t ldw, int B, int C, int K, int Npts,
                             float *dX, int64_t ldx, void *workspace, fsg_stream_t stream);
 int fsg_pw_gf_dw_f32(const float *coef, const int32_t *arg, const float *X, int64_t ldx, const float *s, const float *W,
                      int64_t ldw, const float *G, const float *P, const float *Q, int B, int C, int K, int Npts, float *dW,
                      int64_t lddw, fsg_stream_t stream);
-size_t fsg_pw_colsum_workspace_bytes(int64_t M, int K);
-int fsg_pw_colsum_f32(const float *X, int64_t ldx, int64_t M, int K, float *out, float *workspace, fsg_stream_t stream);
 
 #ifdef __cplusplus
 }
