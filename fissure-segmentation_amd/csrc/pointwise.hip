@@ -1402,6 +1402,40 @@ __global__ __launch_bounds__(256) void pw_gf_dw_kernel(const float *__restrict__
     }
 }
 
+// several deferred reductions in one launch: job j owns the elements [first[j], first[j + 1])
+struct TnReduceJobs {
+    const float *part[FSG_PW_MAX_REDUCE_JOBS];
+    float *C1[FSG_PW_MAX_REDUCE_JOBS], *C2[FSG_PW_MAX_REDUCE_JOBS];
+    long ldc1[FSG_PW_MAX_REDUCE_JOBS], ldc2[FSG_PW_MAX_REDUCE_JOBS], first[FSG_PW_MAX_REDUCE_JOBS + 1];
+    int S[FSG_PW_MAX_REDUCE_JOBS], N1[FSG_PW_MAX_REDUCE_JOBS], N2[FSG_PW_MAX_REDUCE_JOBS], N1a[FSG_PW_MAX_REDUCE_JOBS];
+    int n;
+};
+__global__ __launch_bounds__(256) void pw_tn_reduce_many_kernel(const TnReduceJobs jobs) {
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= jobs.first[jobs.n]) return;
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < FSG_PW_MAX_REDUCE_JOBS; ++q)
+        if (q < jobs.n && g >= jobs.first[q]) j = q;
+    const long t = g - jobs.first[j];
+    const int S = jobs.S[j], N2 = jobs.N2[j];
+    const long total = (long)jobs.N1[j] * N2;
+    const float *part = jobs.part[j];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int q = 0;
+    for (; q + 4 <= S; q += 4) {
+        a0 += part[(long)q * total + t];
+        a1 += part[(long)(q + 1) * total + t];
+        a2 += part[(long)(q + 2) * total + t];
+        a3 += part[(long)(q + 3) * total + t];
+    }
+    for (; q < S; ++q) a0 += part[(long)q * total + t];
+    const float v = (a0 + a1) + (a2 + a3);
+    const int r = (int)(t / N2), c = (int)(t - (long)r * N2);
+    if (r < jobs.N1a[j]) jobs.C1[j][(long)r * jobs.ldc1[j] + c] = v;
+    else jobs.C2[j][(long)(r - jobs.N1a[j]) * jobs.ldc2[j] + c] = v;
+}
+
 template <int T1, int T2, int NP = 3>
 int launch_tn(const TnArgs &a, int S, hipStream_t st) {
     const int N1 = a.N1a + a.N1b;
