@@ -375,14 +375,11 @@ def main():
         if not dgcnn:
             raise LookupError("no EdgeConv group in this workload")
 
-        def group():     # the three EdgeConv layers exactly as DGCNNSeg.forward runs them (layouts handed over, no transposes)
+        def group():     # the three EdgeConv layers exactly as DGCNNSeg.forward runs them (DGCNNSeg.edge_levels)
             with torch.no_grad():
-                w1, w2, w3 = type(net.ec1).pq_weights([net.ec1, net.ec2, net.ec3])
-                graph = net.knn_graph if not net.dynamic else None
-                x1, p1, _ = net.ec1(x, graph, both="twice", w_cat=w1)
-                x2, p2, _ = net.ec2(x1, graph, x_pm=p1, both="twice", w_cat=w2)
-                net.ec3(x2, graph, x_pm=p2, both=True, w_cat=w3)
-                return x1
+                if not net.dynamic:
+                    net.knn_graph = fsg.functional.knn_graph(x, net.k, c_knn=3, fix_diag=True, drop_first=True)
+                return net.edge_levels(x)[0].transpose(1, 2).contiguous()
         feat = group()
         group_us = replay_us(group, 20)
         if net.dynamic:   # the dominant kernel on its own: one feature-space graph build (64 channels), 10 launches per replay

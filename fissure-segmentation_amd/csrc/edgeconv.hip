@@ -430,6 +430,102 @@ __global__ __launch_bounds__(256) void ec1_apply_kernel(const float *__restrict_
     }
 }
 
+// The same pass with the next layer's graph build PREPARED on the way (csrc/knn_split.hip, fp16 form, 64 channels): the tile
+// this workgroup has just produced is exactly what knn_split_prep_kernel would read back from HBM, so its products -- the
+// oracle's squared norms, the centred scaled norms, the fp16 operand image; the point-major copy IS out_pm -- are emitted here
+// and the graph build starts at its main kernel (one launch and ~11 us less per feature-space graph).  Centre and scale of
+// the image come from the same fixed sample of 64 points (four runs of 16 at 0, N/4, N/2, 3N/4) that every workgroup of the
+// cloud evaluates identically from ysel -- any centre / scale is correct, a representative one keeps the nominee lists short.
+typedef unsigned ec_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void ec1_apply_prep_kernel(const float *__restrict__ ysel, const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta, const float *__restrict__ mean,
+                                                              const float *__restrict__ invstd, int N, float slope,
+                                                              float *__restrict__ out, float *__restrict__ out_pm,
+                                                              float *__restrict__ xx, float *__restrict__ xs,
+                                                              ec_u32x4 *__restrict__ cand, float *__restrict__ cscale) {
+    constexpr int Co = 64, KS = 4;
+    __shared__ float tile[64][65];
+    __shared__ float red[4][64], mu[64], wmax[4];
+    const int b = blockIdx.x, i0 = blockIdx.y * 64;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane;
+    const float g = gamma[c] * invstd[c], sh = beta[c] - mean[c] * g;
+    // the sample: wave w takes sample points 16 w .. 16 w + 15 (one of the four runs), lane = channel
+    float sv[16], ssum = 0.f;
+    {
+        const int run0 = min((int)(((long)wave * N / 4) & ~15L), N - 16);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sv[u] = lrelu(__builtin_fmaf(ysel[((long)b * N + run0 + u) * Co + c], g, sh), slope);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) ssum += sv[u];
+        red[wave][lane] = ssum;
+    }
+    for (int p = wave; p < 64; p += 4) {
+        const int i = i0 + p;
+        float v = 0.f;
+        if (i < N) {
+            v = lrelu(__builtin_fmaf(ysel[((long)b * N + i) * Co + c], g, sh), slope);
+            out_pm[((long)b * N + i) * Co + c] = v;
+        }
+        tile[lane][p] = v;
+    }
+    __syncthreads();
+    const float m = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) * (1.0f / 64.0f);
+    float dv = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) dv = fmaxf(dv, fabsf(sv[u] - m));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dv = fmaxf(dv, __shfl_xor(dv, off));
+    if (wave == 0) mu[lane] = m;
+    if (lane == 0) wmax[wave] = dv;
+    for (int cc = wave; cc < 64; cc += 4) {
+        const int i = i0 + lane;
+        if (i < N) out[((long)b * Co + cc) * N + i] = tile[cc][lane];
+    }
+    __syncthreads();
+    const float maxdev = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    // power of two that maps the sample's largest deviation into [2^9, 2^10) (as knn_split_prep_kernel)
+    int e2 = 9 - ((int)((__float_as_uint(maxdev) >> 23) & 255u) - 127);
+    e2 = max(-100, min(100, e2));
+    const float sigma = (maxdev > 0.f && maxdev < 3.0e38f) ? __uint_as_float((unsigned)(e2 + 127) << 23) : 1.f;
+    if (blockIdx.y == 0 && threadIdx.x == 0) cscale[b] = sigma;
+    if (threadIdx.x < 64) {
+        // norms of point i0 + tid: the oracle's channel-ordered fma chain and the centred scaled one; a coordinate beyond 2^14
+        // scaled units marks the point (NaN): its cloud takes the exact slow path
+        const int pt = threadIdx.x;
+        float a = 0.f, c2 = 0.f;
+        bool bad = false;
+#pragma unroll 8
+        for (int ch = 0; ch < 64; ++ch) {
+            const float v = tile[ch][pt];
+            a = __builtin_fmaf(v, v, a);
+            const float vs = (v - mu[ch]) * sigma;
+            bad |= !(fabsf(vs) < 16384.0f);
+            c2 = __builtin_fmaf(vs, vs, c2);
+        }
+        const bool in = i0 + pt < N;
+        xx[(long)b * N + i0 + pt] = in ? a : INFINITY;
+        xs[(long)b * N + i0 + pt] = in ? (bad ? __uint_as_float(0x7FC00000u) : c2) : INFINITY;
+    }
+    // fp16 operand image: two 32-point tiles x KS k-steps x 64 lanes of 16 bytes
+    const long T = N / 32;
+    for (int e = threadIdx.x; e < 2 * KS * 64; e += 256) {
+        const int ln = e & 63, s2 = (e >> 6) % KS, half_tile = e / (KS * 64);
+        const int mm = ln & 31, h = ln >> 5;
+        unsigned cw[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ch = 16 * s2 + 8 * h + i, pt = 32 * half_tile + mm;
+            float v = 0.f;
+            if (i0 + pt < N) v = (tile[ch][pt] - mu[ch]) * sigma;
+            const _Float16 hv = (_Float16)v;
+            cw[i] = (unsigned)__builtin_bit_cast(unsigned short, hv);
+        }
+        cand[(((long)b * T + (i0 / 32 + half_tile)) * KS + s2) * 64 + ln] =
+            ec_u32x4{cw[0] | (cw[1] << 16), cw[2] | (cw[3] << 16), cw[4] | (cw[5] << 16), cw[6] | (cw[7] << 16)};
+    }
+}
+
 // ------------------------------------------------------------------ backward
 // h = grad_out * f'(u) on the selected edge (point-major), per-workgroup partial sums of h and h*yhat
 // (the point-major gradient may arrive as up to two tensors with their own row strides -- e.g. one from the next layer and
@@ -598,6 +694,27 @@ int fsg_ec_finalize_launch(const float *partials, int R, int Co, float eps, floa
     return FSG_OK;
 }
 
+int fsg_knn_split_ws_pointers(void *ws, size_t ws_bytes, int B, int N, int c_knn, float **xx, float **xs, void **cand,
+                              float **cscale);       // knn_split.hip
+
+// apply + the next graph build's prep (out_pm required, Co == 64, N % 64 == 0, N inside the coarse-sweep kernel's envelope)
+int fsg_ec_apply_prep_launch(const float *ysel, const float *gamma, const float *beta, const float *mean, const float *invstd,
+                             int B, int N, int Co, float slope, float *out, float *out_pm, void *knn_ws, size_t knn_ws_bytes,
+                             hipStream_t st) {
+    float *xx, *xs, *cscale;
+    void *cand;
+    if (Co != 64 || N % 64 != 0 || !out_pm || !out ||
+        fsg_knn_split_ws_pointers(knn_ws, knn_ws_bytes, B, N, 64, &xx, &xs, &cand, &cscale) != FSG_OK) {
+        fsg_set_error("fsg_edgeconv_apply_f32: the graph-build prep needs Co == 64, N %% 64 == 0, both output layouts and a "
+                      "workspace of fsg_knn_dense_workspace_bytes(B, N, 64) bytes inside the coarse-sweep kernel's envelope");
+        return FSG_ERR_ARG;
+    }
+    hipLaunchKernelGGL(ec1_apply_prep_kernel, dim3(B, N / 64), dim3(256), 0, st, ysel, gamma, beta, mean, invstd, N, slope, out,
+                       out_pm, xx, xs, reinterpret_cast<ec_u32x4 *>(cand), cscale);
+    FSG_CHECK_LAUNCH("fsg_edgeconv_apply_f32/prep");
+    return FSG_OK;
+}
+
 int fsg_ec_apply_launch(const float *ysel, const float *gamma, const float *beta, const float *mean, const float *invstd,
                         int B, int N, int Co, float slope, float *out, float *out_pm, hipStream_t st) {
     hipLaunchKernelGGL(ec1_apply_kernel, dim3(B, fsg_cdiv(N, 64), Co / 64), dim3(256), 0, st, ysel, gamma, beta, mean,
@@ -757,7 +874,7 @@ extern "C" int fsg_edgeconv1_fwd_f32(const float *pq, const int32_t *idx, const 
                                      float momentum, float eps, float slope, float *out, float *out_pm, float *ysel,
                                      uint8_t *arg, float *ssum, float *mean, float *invstd, float *workspace,
                                      fsg_stream_t stream) {
-    FSG_REQUIRE(pq && idx && gamma && beta && out && ysel && arg && mean && invstd, "fsg_edgeconv1_fwd_f32: NULL pointer");
+    FSG_REQUIRE(pq && idx && gamma && beta && ysel && arg && mean && invstd, "fsg_edgeconv1_fwd_f32: NULL pointer");
     FSG_REQUIRE(B > 0 && N > 0 && k > 0 && k <= 64 && Co > 0 && Co % 64 == 0 && B <= 65535,
                 "fsg_edgeconv1_fwd_f32: bad shape B=%d N=%d k=%d Co=%d (Co must be a multiple of 64)", B, N, k, Co);
     FSG_REQUIRE(!training || workspace, "fsg_edgeconv1_fwd_f32: training needs the workspace");
@@ -771,10 +888,26 @@ extern "C" int fsg_edgeconv1_fwd_f32(const float *pq, const int32_t *idx, const 
                                               running_var, st);
         if (rc != FSG_OK) return rc;
     }
+    if (!out) return FSG_OK;      // the caller applies BatchNorm + LeakyReLU itself (fsg_edgeconv_apply_f32)
     hipLaunchKernelGGL(ec1_apply_kernel, dim3(B, fsg_cdiv(N, 64), Co / 64), dim3(256), 0, st, ysel, gamma, beta, mean,
                        invstd, N, Co, slope, out, out_pm);
     FSG_CHECK_LAUNCH("fsg_edgeconv1_fwd_f32/apply");
     return FSG_OK;
+}
+
+// The last pass of the fused EdgeConv forward on its own: out (B,Co,N) [+ out_pm (B,N,Co)] = lrelu(BN(ysel)) from the selected
+// pre-norm values -- for callers that ran fsg_edgeconv{1,2}_fwd_* with out == NULL.  knn_workspace != NULL (Co == 64,
+// N % 64 == 0): the pass also PREPARES the feature-space graph build of the next layer (see ec1_apply_prep_kernel);
+// fsg_knn_dense_prepared_f32 then starts at the main kernel.
+extern "C" int fsg_edgeconv_apply_f32(const float *ysel, const float *gamma, const float *beta, const float *mean,
+                                      const float *invstd, int B, int N, int Co, float slope, float *out, float *out_pm,
+                                      void *knn_workspace, size_t knn_workspace_bytes, fsg_stream_t stream) {
+    FSG_REQUIRE(ysel && gamma && beta && mean && invstd && out, "fsg_edgeconv_apply_f32: NULL pointer");
+    FSG_REQUIRE(B > 0 && N > 0 && Co > 0 && Co % 64 == 0 && B <= 65535, "fsg_edgeconv_apply_f32: bad shape B=%d N=%d Co=%d", B, N, Co);
+    if (knn_workspace)
+        return fsg_ec_apply_prep_launch(ysel, gamma, beta, mean, invstd, B, N, Co, slope, out, out_pm, knn_workspace,
+                                        knn_workspace_bytes, (hipStream_t)stream);
+    return fsg_ec_apply_launch(ysel, gamma, beta, mean, invstd, B, N, Co, slope, out, out_pm, (hipStream_t)stream);
 }
 
 extern "C" int fsg_edgeconv1_bwd_f32(const float *grad_out, const float *grad_out_pm, int64_t ld_pm, const float *grad_out_pm2,

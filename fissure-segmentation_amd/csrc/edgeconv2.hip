@@ -610,7 +610,7 @@ static int ec2_fwd_impl(bool bf16, const float *pq, const int32_t *idx, const fl
                                      float slope, float *out, float *out_pm, float *ssum1, float *mean1, float *invstd1,
                                      float *ysel2, uint8_t *arg2, float *ssum2, float *mean2, float *invstd2,
                                      void *workspace, fsg_stream_t stream) {
-    FSG_REQUIRE(pq && idx && w2 && gamma1 && beta1 && gamma2 && beta2 && out && mean1 && invstd1 && ysel2 && arg2 &&
+    FSG_REQUIRE(pq && idx && w2 && gamma1 && beta1 && gamma2 && beta2 && mean1 && invstd1 && ysel2 && arg2 &&
                     mean2 && invstd2 && workspace,
                 "fsg_edgeconv2_fwd_f32: NULL pointer");
     FSG_REQUIRE(B > 0 && N > 0 && N <= (1 << 21) && k > 0 && k <= 64 && (C2 == 64 || C2 == 128) && B <= 65535,
@@ -655,6 +655,7 @@ static int ec2_fwd_impl(bool bf16, const float *pq, const int32_t *idx, const fl
                                          st)) != FSG_OK)
             return rc;
     }
+    if (!out) return FSG_OK;      // the caller applies BatchNorm + LeakyReLU itself (fsg_edgeconv_apply_f32)
     return fsg_ec_apply_launch(ysel2, gamma2, beta2, mean2, invstd2, B, N, C2, slope, out, out_pm, st);
 }
 

@@ -148,6 +148,25 @@ extern "C" int fsg_knn_dense_ws_f32(const float *x, int B, int N, int64_t stride
                              static_cast<float *>(workspace), stream);
 }
 
+int fsg_knn_split_launch_ex(const float *x, const float *prepared_xt, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn,
+                            int k, int flags, int32_t *idx_out, float *dist_out, void *ws, size_t ws_bytes, hipStream_t st);
+
+// The graph build of fsg_knn_dense_ws_f32 when the producer of the points has already PREPARED it (fsg_edgeconv_apply_f32 with a
+// knn_workspace): x_pm = the point-major (B, N, c_knn) copy of the points, workspace = the one handed to the producer.  Same
+// result bits as fsg_knn_dense_f32 on the same points.  Only the shapes the coarse-sweep kernel takes in its fp16 form:
+// c_knn in {16, 32, 64}, N % 64 == 0, 1024 <= N <= 8192, k + drop <= 64 (FSG_ERR_UNSUPPORTED otherwise: use fsg_knn_dense_ws_f32).
+extern "C" int fsg_knn_dense_prepared_f32(const float *x_pm, int B, int N, int c_knn, int k, int flags, int32_t *idx_out,
+                                          float *dist_out, void *workspace, size_t workspace_bytes, fsg_stream_t stream) {
+    const int drop = (flags & FSG_KNN_DROP_FIRST) ? 1 : 0;
+    FSG_REQUIRE(x_pm && idx_out && workspace, "fsg_knn_dense_prepared_f32: NULL pointer");
+    FSG_REQUIRE(B > 0 && N > 0 && c_knn > 0 && k >= 1 && k + drop <= N && k + drop <= FSG_KNN_MAX_K,
+                "fsg_knn_dense_prepared_f32: bad shape B=%d N=%d c_knn=%d k=%d", B, N, c_knn, k);
+    const int rc = fsg_knn_split_launch_ex(nullptr, x_pm, B, N, 0, 0, c_knn, k, flags, idx_out, dist_out, workspace, workspace_bytes,
+                                           (hipStream_t)stream);
+    if (rc == FSG_ERR_UNSUPPORTED) fsg_set_error("fsg_knn_dense_prepared_f32: shape outside the prepared path's envelope");
+    return rc;
+}
+
 extern "C" int fsg_knn_dense_f32(const float *x, int B, int N, int64_t stride_b, int64_t stride_c,
                                  int c_knn, int k, int flags, int32_t *idx_out, float *dist_out,
                                  float *xx_scratch, fsg_stream_t stream) {

@@ -942,15 +942,40 @@ size_t fsg_knn_split_workspace_bytes(int B, int N, int c_knn) {
     return p.ok ? p.total : 0;
 }
 
+// where the prep products live inside the workspace (fp16 form, for a producer that emits them itself: edgeconv.hip)
+int fsg_knn_split_ws_pointers(void *ws, size_t ws_bytes, int B, int N, int c_knn, float **xx, float **xs, void **cand,
+                              float **cscale) {
+    const SplitPlan p = plan(B, N, c_knn);
+    if (!p.ok || p.pack || ws == nullptr || ws_bytes < p.total || p.Np != N) return FSG_ERR_UNSUPPORTED;
+    unsigned char *w = static_cast<unsigned char *>(ws);
+    *xx = reinterpret_cast<float *>(w + p.off_xx);
+    *cand = w + p.off_cand;
+    *xs = reinterpret_cast<float *>(w + p.off_xs);
+    *cscale = reinterpret_cast<float *>(w + p.off_scale);
+    return FSG_OK;
+}
+
 // returns FSG_ERR_UNSUPPORTED when the shape is outside this kernel's envelope (caller falls back)
+int fsg_knn_split_launch_ex(const float *x, const float *prepared_xt, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn,
+                            int k, int flags, int32_t *idx_out, float *dist_out, void *ws, size_t ws_bytes, hipStream_t st);
+
 int fsg_knn_split_launch(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k, int flags,
                          int32_t *idx_out, float *dist_out, void *ws, size_t ws_bytes, hipStream_t st) {
+    return fsg_knn_split_launch_ex(x, nullptr, B, N, stride_b, stride_c, c_knn, k, flags, idx_out, dist_out, ws, ws_bytes, st);
+}
+
+// prepared_xt != NULL: the workspace already holds the prep products (squared norms, centred norms, fp16 image, scale: written
+// by the producer of the points, ec1_apply_prep_kernel) and prepared_xt is the point-major (B, N, c_knn) copy of the points
+// (c_knn == 16 KS, N % 64 == 0): the prep kernel is skipped
+int fsg_knn_split_launch_ex(const float *x, const float *prepared_xt, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn,
+                            int k, int flags, int32_t *idx_out, float *dist_out, void *ws, size_t ws_bytes, hipStream_t st) {
     const int drop = (flags & FSG_KNN_DROP_FIRST) ? 1 : 0;
     const SplitPlan p = plan(B, N, c_knn);
     if (!p.ok || k + drop > 64 || ws == nullptr || ws_bytes < p.total) return FSG_ERR_UNSUPPORTED;
+    if (prepared_xt && (p.pack || p.CP != c_knn || p.Np != N || (flags & 1073741824))) return FSG_ERR_UNSUPPORTED;
     unsigned char *w = static_cast<unsigned char *>(ws);
     float *xx = reinterpret_cast<float *>(w + p.off_xx);
-    float *xt = reinterpret_cast<float *>(w + p.off_xt);
+    float *xt = prepared_xt ? const_cast<float *>(prepared_xt) : reinterpret_cast<float *>(w + p.off_xt);
     u32x4 *cand = reinterpret_cast<u32x4 *>(w + p.off_cand);
     float *xs = reinterpret_cast<float *>(w + p.off_xs);
     float *cscale = reinterpret_cast<float *>(w + p.off_scale);
@@ -979,8 +1004,9 @@ int fsg_knn_split_launch(const float *x, int B, int N, int64_t stride_b, int64_t
             }                                                                                                          \
             granted = true;                                                                                            \
         }                                                                                                              \
-        hipLaunchKernelGGL((knn_split_prep_kernel<KSV, PK, HF>), pgrid, dim3(256), 0, st, x, N, p.Np, (long)stride_b,   \
-                           (long)stride_c, c_knn, xx, xt, cand, xs, cscale);                                           \
+        if (!prepared_xt)                                                                                              \
+            hipLaunchKernelGGL((knn_split_prep_kernel<KSV, PK, HF>), pgrid, dim3(256), 0, st, x, N, p.Np,              \
+                               (long)stride_b, (long)stride_c, c_knn, xx, xt, cand, xs, cscale);                       \
         hipLaunchKernelGGL((knn_split_kernel<KSV, PK, HF>), grid, dim3(WAVES * 64), lds, st, xx, xt, cand, xs, cscale,  \
                            N, p.Np, k, flags, PC, idx_out, dist_out);                                                  \
     } while (0)

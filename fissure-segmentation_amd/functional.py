@@ -136,10 +136,12 @@ _KNN_EXPERIMENT_FLAGS = 8   # the first MFMA design (libfsg_hip_experiments.so):
 
 
 def knn_graph(x, k, c_knn=None, fix_diag=True, drop_first=False, return_dist=False, force_rows_kernel=False,
-              _debug_flags=0, out=None):
+              _debug_flags=0, out=None, prepared=None):
     """x: (B,C,N) -> idx (B,N,k) int32 [, dist (B,N,k) fp32].  Channel slices are passed by stride.  `out`: a contiguous
     (B,N,k) int32 tensor to write the graph into (e.g. a slice of one buffer holding all graphs of a step, so that their
-    reverse graphs can be built in one launch: build_reverse_graphs)."""
+    reverse graphs can be built in one launch: build_reverse_graphs).  `prepared` = (workspace, x_pm): the producer of x has
+    already emitted the build's prep products into `workspace` (edgeconv1 / edgeconv2 with knn_ws=) and x_pm is its point-major
+    copy (B,N,C): the build starts at its main kernel (include/fsg_hip.h: fsg_knn_dense_prepared_f32)."""
     _need_gpu(x)
     if x.dim() != 3:
         raise ValueError(f"expected (B,C,N), got {tuple(x.shape)}")
@@ -159,6 +161,12 @@ def knn_graph(x, k, c_knn=None, fix_diag=True, drop_first=False, return_dist=Fal
     dist = torch.empty(B, N, k, dtype=torch.float32, device=x.device) if return_dist else None
     flags = (_lib.KNN_FIX_DIAG if fix_diag else 0) | (_lib.KNN_DROP_FIRST if drop_first else 0) | \
         (_lib.KNN_FORCE_ROWS if force_rows_kernel else 0) | _debug_flags
+    if prepared is not None and c_knn == C and not return_dist and not force_rows_kernel and not _debug_flags:
+        ws, x_pm = prepared
+        with torch.cuda.device(x.device):
+            _lib.call("fsg_knn_dense_prepared_f32", _p(x_pm), B, N, C, k, flags, _p(idx), None, _p(ws), ws.numel() * ws.element_size(),
+                      _stream())
+        return idx
     ws_bytes = _lib.lib.fsg_knn_dense_workspace_bytes(B, N, c_knn)
     xx = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
@@ -681,6 +689,14 @@ def _build_csr(idx):
     return rowptr, col
 
 
+def knn_prep_workspace(B, N, C, device):
+    """workspace for a graph build over (B, C, N) points whose PRODUCER prepares it (edgeconv1 / edgeconv2 with knn_ws=, then
+    knn_graph(..., prepared=(ws, x_pm))); None when the shape is outside the prepared path (then build the graph as usual)"""
+    if C != 64 or N % 64 != 0 or not (1024 <= N <= 8192):
+        return None
+    return torch.empty(_lib.lib.fsg_knn_dense_workspace_bytes(B, N, C), dtype=torch.uint8, device=device)
+
+
 def build_reverse_graphs(graphs):
     """Reverse graphs (CSR by destination) of several kNN graphs of the same shape in ONE set of launches instead of one per
     graph: `graphs` are the (B,N,k) slices, in order, of one contiguous (G,B,N,k) buffer (knn_graph(..., out=slice)).  The
@@ -748,7 +764,7 @@ def _pm_grad(g, B, N, C):
 class _EdgeConv1(torch.autograd.Function):
     @staticmethod
     @_amp_fwd
-    def forward(ctx, pq, idx, gamma, beta, running_mean, running_var, training, momentum, eps, slope):
+    def forward(ctx, pq, idx, gamma, beta, running_mean, running_var, training, momentum, eps, slope, knn_ws=None):
         pq = _f32c(pq)
         B, N, two_co = pq.shape
         Co, k, dev = two_co // 2, idx.shape[2], pq.device
@@ -769,8 +785,11 @@ class _EdgeConv1(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.call("fsg_edgeconv1_fwd_f32", _p(pq), _p(idx), _p(gamma), _p(beta),
                       _p(running_mean if training else None), _p(running_var if training else None), B, N, k, Co,
-                      int(training), momentum, eps, slope, _p(out), _p(out_pm), _p(ysel), _p(arg), _p(ssum), _p(mean),
-                      _p(invstd), _p(ws), _stream())
+                      int(training), momentum, eps, slope, _p(None if knn_ws is not None else out), _p(out_pm), _p(ysel), _p(arg),
+                      _p(ssum), _p(mean), _p(invstd), _p(ws), _stream())
+            if knn_ws is not None:     # BatchNorm + LeakyReLU pass that also prepares the next layer's graph build
+                _lib.call("fsg_edgeconv_apply_f32", _p(ysel), _p(gamma), _p(beta), _p(mean), _p(invstd), B, N, Co, slope, _p(out),
+                          _p(out_pm), _p(knn_ws), knn_ws.numel() * knn_ws.element_size(), _stream())
         ctx.save_for_backward(pq, idx, gamma, beta, mean, invstd, ysel, arg, ssum)
         ctx.meta = (B, N, k, Co, bool(training), slope)
         ctx.set_materialize_grads(False)   # the layout that only feeds the next graph build gets None, not a zero tensor
@@ -798,14 +817,14 @@ class _EdgeConv1(torch.autograd.Function):
                       _p(beta), _p(mean),
                       _p(invstd), _p(ysel), _p(arg), _p(ssum), B, N, k, Co, int(training), slope, _p(gpq), _p(dgamma),
                       _p(dbeta), _p(h), _p(ws), _stream())
-        return gpq, None, dgamma, dbeta, None, None, None, None, None, None
+        return gpq, None, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 def edgeconv1_supported(out_channels, k):
     return out_channels % 64 == 0 and k <= 64
 
 
-def edgeconv1(x, idx, conv_weight, bn, slope, x_pm=None, both=False, w_cat=None):
+def edgeconv1(x, idx, conv_weight, bn, slope, x_pm=None, both=False, w_cat=None, knn_ws=None):
     """Fused single-layer EdgeConv: x (B,C,N), idx (B,N,k) int32, conv_weight (Co,2C,1,1), bn a BatchNorm2d module
     (its running statistics are updated in place like nn.BatchNorm2d does) -> (B,Co,N); with both=True also the
     point-major copy (B,N,Co).  x_pm: optional point-major (B,N,C) copy of x (saves the transpose for the GEMM)."""
@@ -830,7 +849,7 @@ def edgeconv1(x, idx, conv_weight, bn, slope, x_pm=None, both=False, w_cat=None)
     out, out_pm, out_pm2 = _EdgeConv1.apply(pq, idx, bn.weight, bn.bias,
                                             bn.running_mean if (track or not training) else None,
                                             bn.running_var if (track or not training) else None, training, float(momentum),
-                                            float(bn.eps), float(slope))
+                                            float(bn.eps), float(slope), knn_ws)
     if both == "twice":      # (B,Co,N), (B,N,Co) and an alias of the latter for a second consumer (see _EdgeConv1)
         return out, out_pm, out_pm2
     return (out, out_pm) if both else out
@@ -839,7 +858,7 @@ def edgeconv1(x, idx, conv_weight, bn, slope, x_pm=None, both=False, w_cat=None)
 class _EdgeConv2(torch.autograd.Function):
     @staticmethod
     @_amp_fwd
-    def forward(ctx, pq, idx, w2, g1, b1, rm1, rv1, g2, b2, rm2, rv2, training, mom1, mom2, eps1, eps2, slope):
+    def forward(ctx, pq, idx, w2, g1, b1, rm1, rv1, g2, b2, rm2, rv2, training, mom1, mom2, eps1, eps2, slope, knn_ws=None):
         pq, w2 = _f32c(pq), _f32c(w2)
         g1, b1, g2, b2 = _f32c(g1), _f32c(b1), _f32c(g2), _f32c(b2)
         B, N, _ = pq.shape
@@ -863,8 +882,11 @@ class _EdgeConv2(torch.autograd.Function):
             _lib.call("fsg_edgeconv2_fwd_bf16" if ctx.bf16 else "fsg_edgeconv2_fwd_f32", _p(pq), _p(idx), _p(w2), _p(g1), _p(b1),
                       _p(rm1 if t else None),
                       _p(rv1 if t else None), _p(g2), _p(b2), _p(rm2 if t else None), _p(rv2 if t else None), B, N, k, C2,
-                      int(t), mom1, mom2, eps1, eps2, slope, _p(out), _p(out_pm), _p(ssum1), _p(mean1), _p(invstd1),
-                      _p(ysel2), _p(arg2), _p(ssum2), _p(mean2), _p(invstd2), _p(ws), _stream())
+                      int(t), mom1, mom2, eps1, eps2, slope, _p(None if knn_ws is not None else out), _p(out_pm), _p(ssum1), _p(mean1),
+                      _p(invstd1), _p(ysel2), _p(arg2), _p(ssum2), _p(mean2), _p(invstd2), _p(ws), _stream())
+            if knn_ws is not None:     # BatchNorm + LeakyReLU pass that also prepares the next layer's graph build
+                _lib.call("fsg_edgeconv_apply_f32", _p(ysel2), _p(g2), _p(b2), _p(mean2), _p(invstd2), B, N, C2, slope, _p(out),
+                          _p(out_pm), _p(knn_ws), knn_ws.numel() * knn_ws.element_size(), _stream())
         ctx.save_for_backward(pq, idx, w2, g1, b1, mean1, invstd1, ssum1, g2, b2, mean2, invstd2, ysel2, arg2)
         ctx.meta = (B, N, k, C2, t, slope)
         ctx.set_materialize_grads(False)
@@ -891,7 +913,7 @@ class _EdgeConv2(torch.autograd.Function):
                       _p(b1), _p(mean1), _p(invstd1), _p(ssum1), _p(g2), _p(b2), _p(mean2), _p(invstd2), _p(ysel2),
                       _p(arg2), B, N, k, C2, int(training), slope, _p(gpq), _p(gw2), _p(dg1), _p(db1), _p(dg2), _p(db2),
                       _p(ws), _stream())
-        return (gpq, None, gw2, dg1, db1, None, None, dg2, db2) + (None,) * 8
+        return (gpq, None, gw2, dg1, db1, None, None, dg2, db2) + (None,) * 9
 
 
 def edgeconv2_supported(c_mid, c_out, k):
@@ -907,7 +929,7 @@ def _bn_step(bn):
     return training, float(momentum)
 
 
-def edgeconv2(x, idx, conv1_weight, bn1, conv2_weight, bn2, slope, x_pm=None, both=False, w_cat=None):
+def edgeconv2(x, idx, conv1_weight, bn1, conv2_weight, bn2, slope, x_pm=None, both=False, w_cat=None, knn_ws=None):
     """Fused two-layer EdgeConv (2C -> 64 -> 64|128): see csrc/edgeconv2.hip."""
     _need_gpu(x, idx, conv1_weight, conv2_weight)
     C1, CC = conv1_weight.shape[0], conv1_weight.shape[1]
@@ -929,7 +951,7 @@ def edgeconv2(x, idx, conv1_weight, bn1, conv2_weight, bn2, slope, x_pm=None, bo
         prefetch_reverse_graph(idx)
     out, out_pm, out_pm2 = _EdgeConv2.apply(pq, idx, w2, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
                                             bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, t1, m1, m2,
-                                            float(bn1.eps), float(bn2.eps), float(slope))
+                                            float(bn1.eps), float(bn2.eps), float(slope), knn_ws)
     if both == "twice":
         return out, out_pm, out_pm2
     return (out, out_pm) if both else out

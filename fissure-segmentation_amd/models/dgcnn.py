@@ -93,10 +93,11 @@ class EdgeConv(nn.Module):
         it = iter(ws)
         return [next(it) if b.fused else None for b in blocks]
 
-    def forward(self, x, fixed_knn_graph=None, x_pm=None, both=False, w_cat=None):
+    def forward(self, x, fixed_knn_graph=None, x_pm=None, both=False, w_cat=None, knn_ws=None):
         """x (B,C,N) -> (B,Cout,N) like the reference; `both=True` additionally returns the point-major copy
         (B,N,Cout) that the point-wise head consumes (`both="twice"`: that copy twice, for two consumers), `x_pm` is an
-        optional point-major copy of the input."""
+        optional point-major copy of the input, `knn_ws` a workspace in which the last pass of a fused block prepares the
+        NEXT layer's graph build over this block's output (functional.knn_prep_workspace)."""
         if len(self.shared_mlp) == 1 and len(self.shared_mlp[0].layers) == 3 and \
                 F_hip.edgeconv1_supported(self.shared_mlp[0].layers[0].out_channels, self.k):
             # fused path: no (B,2C,N,k) / (B,Cout,N,k) tensor is ever written (csrc/edgeconv.hip)
@@ -104,7 +105,8 @@ class EdgeConv(nn.Module):
             if graph is None:
                 graph = F_hip.knn_graph(x, self.k, c_knn=3 if self.first_layer else None, fix_diag=True)
             conv, bn, act = self.shared_mlp[0].layers
-            return F_hip.edgeconv1(x, graph, conv.weight, bn, act.negative_slope, x_pm=x_pm, both=both, w_cat=w_cat)
+            return F_hip.edgeconv1(x, graph, conv.weight, bn, act.negative_slope, x_pm=x_pm, both=both, w_cat=w_cat,
+                                   knn_ws=knn_ws)
         if len(self.shared_mlp) == 2 and all(len(m.layers) == 3 for m in self.shared_mlp) and \
                 F_hip.edgeconv2_supported(self.shared_mlp[0].layers[0].out_channels,
                                           self.shared_mlp[1].layers[0].out_channels, self.k):
@@ -113,7 +115,7 @@ class EdgeConv(nn.Module):
                 graph = F_hip.knn_graph(x, self.k, c_knn=3 if self.first_layer else None, fix_diag=True)
             (conv1, bn1, act), (conv2, bn2, _) = self.shared_mlp[0].layers, self.shared_mlp[1].layers
             return F_hip.edgeconv2(x, graph, conv1.weight, bn1, conv2.weight, bn2, act.negative_slope, x_pm=x_pm,
-                                   both=both, w_cat=w_cat)
+                                   both=both, w_cat=w_cat, knn_ws=knn_ws)
         e = create_neighbor_features(x, self.k, fixed_knn_graph, knn_only_over_coords=self.first_layer)
         for layer in self.shared_mlp:
             e = layer(e)
@@ -240,27 +242,7 @@ class DGCNNSeg(DGCNNBase):
     def forward(self, x):
         x = super().forward(x)
         B, _, N = x.shape
-        # EdgeConvs hand over both layouts: channel-major (B,C,N) feeds the next graph build, point-major (B,N,C)
-        # feeds the GEMMs; the head runs point-major, so every 1x1 conv is ONE GEMM over the B*N points
-        # p1 / p2 have two consumers (the next EdgeConv and the concatenation): "twice" hands out an alias for the second,
-        # so that their gradients reach the EdgeConv backward kernel separately (summed there, slices taken by stride)
-        w1, w2, w3 = EdgeConv.pq_weights([self.ec1, self.ec2, self.ec3])     # one launch for the three weight transforms
-        if self.dynamic and all(e.fused for e in (self.ec1, self.ec2, self.ec3)):
-            # the three dynamic graphs go into ONE buffer: with a backward pass ahead their reverse graphs (CSR by destination,
-            # what the EdgeConv backward gathers through) are then built by one set of launches instead of three
-            graphs = list(torch.empty(3, B, N, self.k, dtype=torch.int32, device=x.device).unbind(0))
-            g1 = F_hip.knn_graph(x, self.k, c_knn=3, fix_diag=True, out=graphs[0])
-            x1, p1, p1c = self.ec1(x, g1, both="twice", w_cat=w1)
-            g2 = F_hip.knn_graph(x1, self.k, fix_diag=True, out=graphs[1])
-            x2, p2, p2c = self.ec2(x1, g2, x_pm=p1, both="twice", w_cat=w2)
-            g3 = F_hip.knn_graph(x2, self.k, fix_diag=True, out=graphs[2])
-            _, p3 = self.ec3(x2, g3, x_pm=p2, both=True, w_cat=w3)
-            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-                F_hip.build_reverse_graphs([g1, g2, g3])
-        else:
-            x1, p1, p1c = self.ec1(x, self.knn_graph, both="twice", w_cat=w1)
-            x2, p2, p2c = self.ec2(x1, self.knn_graph, x_pm=p1, both="twice", w_cat=w2)
-            _, p3 = self.ec3(x2, self.knn_graph, x_pm=p2, both=True, w_cat=w3)
+        p1c, p2c, p3 = self.edge_levels(x)
         levels = torch.cat([p1c, p2c, p3], dim=2).view(B * N, 192)
         gf = self.global_feature[0].layers                                                   # conv, BN, LeakyReLU
         seg0 = self.segmentation[0]
@@ -278,6 +260,37 @@ class DGCNNSeg(DGCNNBase):
         # strided input; its gradient then arrives point-major, no transposing copies either way); inference keeps the
         # reference's contiguous layout
         return out if self.training and torch.is_grad_enabled() else out.contiguous()
+
+    def edge_levels(self, x):
+        """the three EdgeConv blocks (graph build + neighbour gather + shared MLP + max over the neighbours, models/dgcnn.py:
+        130-132,150-154 of the reference) -> their point-major outputs (B,N,64) each; also what bench.py times as the
+        forward "kNN + gather" group of the north star"""
+        B, _, N = x.shape
+        # EdgeConvs hand over both layouts: channel-major (B,C,N) feeds the next graph build, point-major (B,N,C)
+        # feeds the GEMMs; the head runs point-major, so every 1x1 conv is ONE GEMM over the B*N points
+        # p1 / p2 have two consumers (the next EdgeConv and the concatenation): "twice" hands out an alias for the second,
+        # so that their gradients reach the EdgeConv backward kernel separately (summed there, slices taken by stride)
+        w1, w2, w3 = EdgeConv.pq_weights([self.ec1, self.ec2, self.ec3])     # one launch for the three weight transforms
+        if self.dynamic and all(e.fused for e in (self.ec1, self.ec2, self.ec3)):
+            # the three dynamic graphs go into ONE buffer: with a backward pass ahead their reverse graphs (CSR by destination,
+            # what the EdgeConv backward gathers through) are then built by one set of launches instead of three
+            graphs = list(torch.empty(3, B, N, self.k, dtype=torch.int32, device=x.device).unbind(0))
+            # the feature-space graph builds are PREPARED by the block that produces their points: its last pass emits the
+            # norms and the coarse operand image of its output on the way (one launch less per build)
+            ws2, ws3 = F_hip.knn_prep_workspace(B, N, 64, x.device), F_hip.knn_prep_workspace(B, N, 64, x.device)
+            g1 = F_hip.knn_graph(x, self.k, c_knn=3, fix_diag=True, out=graphs[0])
+            x1, p1, p1c = self.ec1(x, g1, both="twice", w_cat=w1, knn_ws=ws2)
+            g2 = F_hip.knn_graph(x1, self.k, fix_diag=True, out=graphs[1], prepared=None if ws2 is None else (ws2, p1))
+            x2, p2, p2c = self.ec2(x1, g2, x_pm=p1, both="twice", w_cat=w2, knn_ws=ws3)
+            g3 = F_hip.knn_graph(x2, self.k, fix_diag=True, out=graphs[2], prepared=None if ws3 is None else (ws3, p2))
+            _, p3 = self.ec3(x2, g3, x_pm=p2, both=True, w_cat=w3)
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                F_hip.build_reverse_graphs([g1, g2, g3])
+        else:
+            x1, p1, p1c = self.ec1(x, self.knn_graph, both="twice", w_cat=w1)
+            x2, p2, p2c = self.ec2(x1, self.knn_graph, x_pm=p1, both="twice", w_cat=w2)
+            _, p3 = self.ec3(x2, self.knn_graph, x_pm=p2, both=True, w_cat=w3)
+        return p1c, p2c, p3
 
     def _head_unfused(self, levels, B, N):
         """the round-2 head: vendor GEMMs + fsg_bn_act_* stages (shapes outside the fused kernels' envelope, bf16 operand

@@ -71,6 +71,17 @@ int fsg_knn_dense_ws_f32(const float *x, int B, int N, int64_t stride_b, int64_t
                          size_t workspace_bytes, fsg_stream_t stream);
 
 /*
+ * The same graph build when the PRODUCER of the points has already prepared it: fsg_edgeconv_apply_f32 (below) with a
+ * knn_workspace emits the squared norms, the centred norms and the fp16 operand image of its output on the way, so the build
+ * starts at its main kernel (one launch and ~11 us less per feature-space graph of DGCNN-seg).  x_pm = the point-major
+ * (B, N, c_knn) copy of the points (the producer's out_pm), workspace = the one handed to the producer
+ * (fsg_knn_dense_workspace_bytes(B, N, c_knn) bytes).  Same result bits as fsg_knn_dense_f32 on the same points.
+ * c_knn in {16, 32, 64}, N % 64 == 0, 1024 <= N <= 8192, k + drop <= 64; FSG_ERR_UNSUPPORTED otherwise.
+ */
+int fsg_knn_dense_prepared_f32(const float *x_pm, int B, int N, int c_knn, int k, int flags, int32_t *idx_out, float *dist_out,
+                               void *workspace, size_t workspace_bytes, fsg_stream_t stream);
+
+/*
  * Edge features: replaces models/dgcnn.py:31-36 (create_neighbor_features: take_along_dim, repeat,
  * cat) and models/dgcnn_opensrc.py:43-66 (get_graph_feature).
  *   x (B,C,N) fp32, idx (B,N,k) int32 -> edge (B,2C,N,k): [x_j - x_i ; x_i]
@@ -127,6 +138,16 @@ typedef struct fsg_edge_weight_jobs {
     int n;
 } fsg_edge_weight_jobs;
 int fsg_edge_weights_many_f32(const fsg_edge_weight_jobs *jobs, int backward, fsg_stream_t stream);
+
+/*
+ * Last pass of the fused EdgeConv forward on its own: out (B,Co,N) [+ out_pm (B,N,Co)] = LeakyReLU(BatchNorm(ysel)) from the
+ * selected pre-norm values, for callers that ran fsg_edgeconv{1,2}_fwd_* with out == NULL (those then stop after the
+ * statistics).  knn_workspace != NULL (Co == 64, N % 64 == 0, both layouts): the pass also prepares the feature-space graph
+ * build of the NEXT layer over its own output -- see fsg_knn_dense_prepared_f32.
+ */
+int fsg_edgeconv_apply_f32(const float *ysel, const float *gamma, const float *beta, const float *mean, const float *invstd,
+                           int B, int N, int Co, float slope, float *out, float *out_pm, void *knn_workspace,
+                           size_t knn_workspace_bytes, fsg_stream_t stream);
 
 /*
  * Fused EdgeConv with ONE shared-MLP layer: replaces models/dgcnn.py:234-241 (gather, 1x1 Conv2d, BatchNorm2d,

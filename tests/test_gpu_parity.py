@@ -2662,3 +2662,38 @@ def test_pointtransformer_bf16_mode_vs_fp32_oracle(fsg, device):
           "(fp32 mode:", cos32, ")")
     assert cos32 >= 0.999
     assert float(d.mean()) <= 0.15 and float(d.max()) <= 1.5 and cos >= 0.25
+
+
+@pytest.mark.parametrize("B,Np,k,two_layer", [(2, 2048, 20, True), (3, 1024, 20, False), (1, 8192, 40, False)])
+def test_knn_prepared_by_edgeconv_equals_plain_build(fsg, device, B, Np, k, two_layer):
+    """The feature-space graph build prepared by its producer (fsg_edgeconv_apply_f32 with a knn_workspace, then
+    fsg_knn_dense_prepared_f32) against the plain build (fsg_knn_dense_ws_f32) of the same features and against the C oracle:
+    the block's outputs are bit-identical with and without the prep, the graphs are bit-identical (reference:
+    models/dgcnn.py:212-243 EdgeConv -> utils/general_utils.py:315-327 knn of its output)."""
+    from fissure_segmentation_amd.models.dgcnn import EdgeConv
+    F_hip = fsg.functional
+    C = 3 if two_layer else 64
+    ec = fill_state_dict(EdgeConv(C, [64, 64] if two_layer else [64], k, first_layer=two_layer), 91).to(device).train()
+    x = G(cloud(9100 + Np, B, C, Np), device)
+    g0 = F_hip.knn_graph(x, k, c_knn=3 if two_layer else None)
+    with torch.no_grad():
+        ws = F_hip.knn_prep_workspace(B, Np, 64, device)
+        assert ws is not None
+        out_a, pm_a = ec(x, g0, both=True)
+        out_b, pm_b = ec(x, g0, both=True, knn_ws=ws)
+    assert torch.equal(out_a, out_b) and torch.equal(pm_a, pm_b)
+    plain = F_hip.knn_graph(out_a, k)
+    prepared = F_hip.knn_graph(out_b, k, prepared=(ws, pm_b))
+    assert torch.equal(plain, prepared)
+    if Np <= 2048:
+        want, _ = c_api.knn_dense(N(out_a), k, fix_diag=True)
+        assert np.array_equal(N(prepared), want)
+    # a cloud with a far outlier in the features: the marked cloud takes the exact slow path in both builds
+    if not two_layer and Np == 1024:
+        x2 = x.clone()
+        x2[0, :, 7] *= 1.0e4
+        with torch.no_grad():
+            o_a, p_a = ec(x2, g0, both=True)
+            o_b, p_b = ec(x2, g0, both=True, knn_ws=ws)
+        assert torch.equal(F_hip.knn_graph(o_a, k), F_hip.knn_graph(o_b, k, prepared=(ws, p_b)))
+    assert F_hip.knn_prep_workspace(B, 1000, 64, device) is None and F_hip.knn_prep_workspace(B, Np, 32, device) is None
