@@ -1127,7 +1127,6 @@ __global__ __launch_bounds__(256) void pw_gf_prep_kernel(const float *__restrict
                                                          const float *__restrict__ Wgl, long ldwgl, int KL,
                                                          float *__restrict__ Wq, long ldwq) {
     extern __shared__ float dcs[];     // (B, C0) when dc is given, then [4][GP_MAXB][64] partial dg
-    __shared__ float qs[64], ps[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = min(blockIdx.x * 64 + lane, C - 1);       // 64 channels per workgroup, the four waves split k
     const bool livec = blockIdx.x * 64 + lane < C;
@@ -1180,22 +1179,25 @@ __global__ __launch_bounds__(256) void pw_gf_prep_kernel(const float *__restrict
         const float q = al * dgm, pp = al * (db - mu * dgm);
         Q[c] = q;
         P[c] = pp;
-        qs[lane] = q;
-        ps[lane] = pp;
-    }
-    if (!Wq) return;
-    __syncthreads();
-    // rows [Q[c] W[c, :] | -P[c]] of this workgroup's 64 channels: the left operand of  [M1 ; npvec] = [Q o W | -P]^T W
-    const int cbase = blockIdx.x * 64;
-    for (int e = threadIdx.x; e < 64 * (KL + 1); e += 256) {
-        const int rr = e / (KL + 1), j = e - rr * (KL + 1);
-        if (cbase + rr < C) Wq[(long)(cbase + rr) * ldwq + j] = j < KL ? qs[rr] * Wgl[(long)(cbase + rr) * ldwgl + j] : -ps[rr];
     }
 }
 
 // dW0g[k, j] = sum_b dc[b, k] g[b, j]  (C0 x CG outputs, B terms each): thread = column j, eight rows k per workgroup row
 __global__ __launch_bounds__(256) void pw_outer_kernel(const float *__restrict__ dc, const float *__restrict__ g, int B, int C0,
-                                                       int CG, float *__restrict__ out, long ldo) {
+                                                       int CG, float *__restrict__ out, long ldo, const float *__restrict__ Q,
+                                                       const float *__restrict__ P, const float *__restrict__ Wgl, long ldwgl,
+                                                       int KL, float *__restrict__ Wq, long ldwq) {
+    if (Wq) {
+        // rows [Q[c] W[c, :] | -P[c]] of the CG channels: the left operand of [M1 ; npvec] = [Q o W | -P]^T W, spread over the
+        // whole grid (thread = column, workgroup = a run of channel rows)
+        const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
+        const int per = (CG + nwg - 1) / nwg;
+        for (int c = wg * per; c < min(CG, (wg + 1) * per); ++c) {
+            const float q = Q[c], pp = P[c];
+            for (int jj = threadIdx.x; jj <= KL; jj += 256)
+                Wq[(long)c * ldwq + jj] = jj < KL ? q * Wgl[(long)c * ldwgl + jj] : -pp;
+        }
+    }
     const int j = blockIdx.x * 256 + threadIdx.x, k0 = blockIdx.y * 8;
     if (j >= CG) return;
     float gv[GP_MAXB];
@@ -1790,7 +1792,7 @@ extern "C" int fsg_pw_gf_prep_f32(const float *dc, const float *W0g, int64_t ldw
                                   const float *mean, const float *invstd, int B, int C, int64_t M, int training, float slope,
                                   float *dbeta, float *dgamma, float *P, float *Q, float *coef, const float *W, int64_t ldw, int K,
                                   float *Wq, int64_t ldwq, fsg_stream_t stream) {
-    FSG_REQUIRE(!Wq || (W && K > 0 && ldwq >= K + 1), "fsg_pw_gf_prep_f32: Wq needs W, K and ldwq >= K + 1");
+    FSG_REQUIRE(!Wq || (W && K > 0 && ldwq >= K + 1 && dc), "fsg_pw_gf_prep_f32: Wq needs W, K, ldwq >= K + 1 and the dc form");
     FSG_REQUIRE(ysel && alpha && delta && mean && invstd && dbeta && dgamma && P && Q && coef && B > 0 && B <= GP_MAXB && C > 0 && M > 0,
                 "fsg_pw_gf_prep_f32: bad arguments (B <= %d)", GP_MAXB);
     FSG_REQUIRE((dc && W0g && gfeat && dW0g && C0 > 0 && (size_t)B * C0 * 4 <= 32 * 1024) || (!dc && dg),
@@ -1801,7 +1803,7 @@ extern "C" int fsg_pw_gf_prep_f32(const float *dc, const float *W0g, int64_t ldw
     FSG_CHECK_LAUNCH("fsg_pw_gf_prep_f32");
     if (dc) {
         hipLaunchKernelGGL(pw_outer_kernel, dim3((C + 255) / 256, (C0 + 7) / 8), dim3(256), 0, (hipStream_t)stream, dc, gfeat, B, C0, C,
-                           dW0g, (long)lddw0);
+                           dW0g, (long)lddw0, Q, P, W, (long)ldw, K, Wq, (long)ldwq);
         FSG_CHECK_LAUNCH("fsg_pw_gf_prep_f32/outer");
     }
     return FSG_OK;
