@@ -370,7 +370,7 @@ def main():
         torch.cuda.synchronize()
         return 1e3 * e0.elapsed_time(e1) / reps
 
-    group_us, knn64_us = None, None
+    group_us, knn64_us, knn_prepared = None, None, False
     try:
         if not dgcnn:
             raise LookupError("no EdgeConv group in this workload")
@@ -383,9 +383,25 @@ def main():
         feat = group()
         group_us = replay_us(group, 20)
         if net.dynamic:   # the dominant kernel on its own: one feature-space graph build (64 channels), 10 launches per replay
-            def knn10():
-                for _ in range(10):
-                    fsg.functional.knn_graph(feat, k)
+            F_ = fsg.functional
+            ws_k = F_.knn_prep_workspace(B, N, 64, device)
+            if ws_k is not None and net.ec1.fused:
+                # as inside the step: prepared by the EdgeConv that produces the features (its apply pass emits the prep
+                # products), the build itself = the main kernel
+                with torch.no_grad():
+                    g0 = F_.knn_graph(x, k, c_knn=3, fix_diag=True)
+                    feat, feat_pm = net.ec1(x, g0, both=True, knn_ws=ws_k)
+                knn_prepared = True
+
+                def knn10():
+                    for _ in range(10):
+                        F_.knn_graph(feat, k, prepared=(ws_k, feat_pm))
+            else:
+                knn_prepared = False
+
+                def knn10():
+                    for _ in range(10):
+                        F_.knn_graph(feat, k)
             knn64_us = replay_us(knn10, 20) / 10
     except LookupError:
         pass
@@ -449,6 +465,7 @@ def main():
                 traffic_all = json.load(f)
         roofline, roofline_group = None, None
         knn_calls = kernel_ms.get("fsg_knn_dense_ws_f32", [])
+        knn_prep_calls = kernel_ms.get("fsg_knn_dense_prepared_f32", [])   # feature-space builds prepared by their producer
         if knn_calls and args.workload != "c2s":
             # DOMINANT KERNEL GROUP of the DGCNN-type workloads: the feature-space graph build (fsg_knn_dense_ws_f32: prep +
             # knn_split_kernel, csrc/knn_split.hip).  Its compulsory HBM traffic is tiny (4C + 4k bytes per point), so the
@@ -460,16 +477,23 @@ def main():
             #   refine_f32  exact fp32 fma chains of the nominated candidates (B N x nominees x 2C) / 157.3 TFLOP/s
             # `frac` is the largest of the three and `bound` names it.  candidates_per_s (B N^2 / t) is a throughput figure, not
             # a fraction of anything.
-            per_step = len(knn_calls) // n_timed                 # graph builds per step (3 for DGCNN-seg, 4 for the PC-AE)
             chans = {"c5": (3, 64, 64, 128)}.get(args.workload, EDGE_LAYERS_C)
-            by_layer = [[v for i, v in enumerate(knn_calls) if i % per_step == li] for li in range(per_step)]
-            li = max(range(per_step), key=lambda q: sum(by_layer[q]))        # the most expensive build of the step
+            if knn_prep_calls:     # DGCNN-seg: build 1 (coordinates) through the plain entry, builds 2 and 3 prepared
+                pp = len(knn_prep_calls) // n_timed
+                by_layer = [knn_calls] + [[v for i, v in enumerate(knn_prep_calls) if i % pp == q] for q in range(pp)]
+                per_step = 1 + pp
+            else:
+                per_step = len(knn_calls) // n_timed             # graph builds per step (3 for DGCNN-seg, 4 for the PC-AE)
+                by_layer = [[v for i, v in enumerate(knn_calls) if i % per_step == li] for li in range(per_step)]
+            li = max(range(per_step), key=lambda q: sum(by_layer[q]) / max(len(by_layer[q]), 1))   # the most expensive build
             avg_ms = sum(by_layer[li]) / len(by_layer[li])
             timed_as = "HIP events around the C-ABI entry point on its stream (eager steps of the same workload)"
             if knn64_us is not None and chans[li] == 64:
                 avg_ms = knn64_us * 1e-3
                 timed_as = ("HIP events around hipGraph replays of 10 back-to-back launches of the entry point on the replay "
-                            "stream (prep kernel included, no Python launch gaps); eager per-call timing: "
+                            "stream (" + ("fsg_knn_dense_prepared_f32: the prep products come out of the producing EdgeConv's "
+                                          "apply pass, as inside the step" if knn_prepared else "prep kernel included") +
+                            ", no Python launch gaps); eager per-call timing: "
                             f"{1e3 * sum(by_layer[li]) / len(by_layer[li]):.1f} us")
             t_s = avg_ms * 1e-3
             cpad = 4 if chans[li] <= 4 else 16 * -(-chans[li] // 16)
@@ -505,7 +529,8 @@ def main():
                         "traffic": knn_traffic,
                         "traffic_source": "profiles/hbm_traffic.json (PMC passes of an earlier run of the same command), not measured in this run",
                         "counters_source": pmc.get("file"),
-                        "kernel": f"fsg_knn_dense_ws_f32 on {chans[li]} channels (knn_split_prep_kernel + knn_split_kernel): two "
+                        "kernel": f"feature-space graph build on {chans[li]} channels (knn_split_kernel, csrc/knn_split.hip; its prep "
+                                  "products are emitted by the producing EdgeConv's apply pass): two "
                                   "coarse sweeps on the matrix cores nominate candidates under a rigorous error bound; exact fp32 "
                                   "fma chains + ranking for the nominees (bit-identical to the fp32 oracle)",
                         "issued_matrix_flops_per_launch": issued, "avg_us": round(1e3 * avg_ms, 1), "launches_per_step": per_step,
@@ -513,7 +538,8 @@ def main():
                         "timed_as": timed_as}
         if dgcnn:
             # the north-star HBM view of the forward "kNN + gather" group, against BOTH byte counts of SURVEY 8(d)
-            grp = ["fsg_knn_dense_ws_f32", "fsg_edge_gather_fwd_f32", "fsg_edgeconv1_fwd_f32", "fsg_edgeconv2_fwd_f32"]
+            grp = ["fsg_knn_dense_ws_f32", "fsg_knn_dense_prepared_f32", "fsg_edge_gather_fwd_f32", "fsg_edgeconv1_fwd_f32",
+                   "fsg_edgeconv2_fwd_f32", "fsg_edgeconv_apply_f32"]
             grp_ms = sum(sum(kernel_ms.get(n, [])) for n in grp) / n_timed
             ref_bytes = knn_gather_bytes_per_point(k) * B * N
             min_bytes = knn_gather_min_bytes_per_point(k) * B * N
@@ -521,9 +547,9 @@ def main():
             tr = traffic_all.get(args.workload)
             roofline_group = {
                 "bound": "mfma+latency (graph builds: %.0f of %.0f us); the gather/MLP stages alone are L2/HBM-bound" % (
-                    1e3 * sum(knn_calls) / n_timed, 1e3 * grp_ms),
+                    1e3 * (sum(knn_calls) + sum(knn_prep_calls)) / n_timed, 1e3 * grp_ms),
                 "kernel": "forward kNN graph + neighbour gather (+ fused edge MLP / BN / max) of the 3 EdgeConv layers: "
-                          "fsg_knn_dense_ws_f32 + fsg_edgeconv{1,2}_fwd_f32",
+                          "fsg_knn_dense_ws_f32 / fsg_knn_dense_prepared_f32 + fsg_edgeconv{1,2}_fwd_f32 + fsg_edgeconv_apply_f32",
                 "unit": "GB/s", "peak": HBM_PEAK_GBS,
                 "us_per_step_hip_events": round(1e3 * grp_ms, 1),
                 "us_per_step_graph_replay": None if group_us is None else round(group_us, 1),
