@@ -565,6 +565,599 @@ __global__ __launch_bounds__(256) void ec2_bwd_gather_kernel(
     gp[C1 + c] = coef * dq;
 }
 
+
+// =====================================================================================================================
+// Split-bf16 kernels for C2 = 64 (every two-layer EdgeConv of DGCNN-seg): the per-edge products run on
+// v_mfma_f32_32x32x16_bf16 at fp32 grade -- each fp32 operand is three bf16 pieces, a product six MFMAs (see pointwise.hip
+// for the error analysis), 2.7x the rate of v_mfma_f32_32x32x2_f32 -- or, NP = 1, with plain bf16 operands (the bf16 entry
+// points).  What changed against the kernels above:
+//   * a thread gathers 32 bytes (eight channels) of a [P | Q] row instead of one channel, transforms and splits them ONCE on
+//     their way into LDS; the MFMA phases read ready operand fragments (the old bf16 mode converted on every read);
+//   * the activations live in ONE row-major bf16 image per piece, [row][64 channels] with 128-byte rows, XOR-swizzled so
+//     that both the row reads (ds_read_b128: eight channels of a row, contraction over channels) and the hardware
+//     transposed reads (ds_read_b64_tr_b16: four rows of a channel, contraction over edge rows, the dW2 product) are free of
+//     bank conflicts;
+//   * the weights are loop invariants of a wave (it keeps its column tile): their fragments stay in registers;
+//   * the gathers of tile t + 1 (and the neighbour indices of tile t + 2) are in flight while tile t is computed.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {   // (a, b) -> packed bf16 pair, a in the low half, RNE
+    bf16x2 v;
+    v[0] = (__bf16)a;
+    v[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// two fp32 values -> their three bf16 pieces, packed pairwise
+__device__ __forceinline__ void split2(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
+    h = pk_bf16(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    m = pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+    l = pk_bf16(sa, sb);
+}
+
+template <int NP>
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4 (&p)[NP]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if constexpr (NP == 3) {
+            unsigned h, m, l;
+            split2(x[2 * q], x[2 * q + 1], h, m, l);
+            p[0][q] = h;
+            p[1][q] = m;
+            p[2][q] = l;
+        } else {
+            p[0][q] = pk_bf16(x[2 * q], x[2 * q + 1]);
+        }
+    }
+}
+
+// byte offset of the 16-byte chunk c (eight channels) of row `row` in a [rows][64 x bf16] dual-use image.  Bank row = 256
+// bytes = two image rows.  Row reads: the 16-lane groups of ds_read_b128 ({0-3,12-15,20-27}, ...) take one chunk index of 16
+// rows -- 8 even, 8 odd; the XOR value 4 ((row >> 1) & 1) + ((row >> 2) & 3) is distinct over the 8 rows of either parity.
+// Transposed reads: a 32-lane half takes 4 consecutive rows x 4 consecutive chunks; rows r, r + 1 fill the two halves of a
+// bank row, rows r + 2, r + 3 the other chunk quad (XOR bit 2).
+__device__ __forceinline__ int img_off(int row, int c) {
+    return 128 * row + 16 * (c ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)));
+}
+
+template <int NP>
+__device__ __forceinline__ f32x16 mfma_split(const u32x4 (&a)[NP], const u32x4 (&b)[NP], f32x16 c) {
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, a[0]), bh = __builtin_bit_cast(bf16x8, b[0]);
+    if constexpr (NP == 3) {
+        const bf16x8 am = __builtin_bit_cast(bf16x8, a[1]), al = __builtin_bit_cast(bf16x8, a[2]);
+        const bf16x8 bm = __builtin_bit_cast(bf16x8, b[1]), bl = __builtin_bit_cast(bf16x8, b[2]);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+}
+
+// operand fragment for a contraction over CHANNELS: lane (ql, half) takes channels 16 ks + 8 half .. + 7 of row rt * 32 + ql
+template <int NP>
+__device__ __forceinline__ void row_frag(const unsigned char *img, int piece_bytes, int rt, int ks, int ql, int half,
+                                         u32x4 (&f)[NP]) {
+    const int off = img_off(rt * 32 + ql, 2 * ks + half);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) f[q] = *reinterpret_cast<const u32x4 *>(img + q * piece_bytes + off);
+}
+
+// operand fragment for a contraction over ROWS: lane (ql, half) takes rows 16 ks + 8 half .. + 7 of channel ctile * 32 + ql.
+// ds_read_b64_tr_b16: lane 4 q + p of a 16-lane group supplies the address of channels 4 p .. 4 p + 3 of the block's row q and
+// receives channel (lane % 16) of the four rows; EXEC must be all ones (callers are wave-uniform)
+template <int NP>
+__device__ __forceinline__ void tr_frag(const unsigned char *img, int piece_bytes, int ctile, int ks, int lane, u32x4 (&f)[NP]) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, h = lane >> 5;
+    const int row = 16 * ks + 8 * h + q, c = 4 * ctile + 2 * (g & 1) + (p >> 1);
+    const int o0 = img_off(row, c) + 8 * (p & 1), o1 = img_off(row + 4, c) + 8 * (p & 1);
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) {
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4 *)(img + pc * piece_bytes + o0));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4 *)(img + pc * piece_bytes + o1));
+        const u32x2 a = __builtin_bit_cast(u32x2, v0), b = __builtin_bit_cast(u32x2, v1);
+        f[pc] = u32x4{a[0], a[1], b[0], b[1]};
+    }
+}
+
+// 16-byte gathers with a per-lane byte offset into the [P | Q] rows of a cloud; !ok -> an offset outside the resource (0)
+struct ChunkGather {
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned oob;
+    __device__ __forceinline__ ChunkGather(const float *base, long bytes) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(base);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        const int n = __builtin_amdgcn_readfirstlane((int)bytes);
+        rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), 0, n, 0x00020000);
+        oob = (unsigned)n;
+    }
+    __device__ __forceinline__ float4 load(bool ok, unsigned byte_off) const {
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? byte_off : oob, 0, 0));
+    }
+};
+
+// the gather state of one tile: RT items per thread, item `it` = (row irow + 32 it, chunk) of the tile
+template <int RT>
+struct TileRows {
+    float4 p[RT][2], q[RT][2];
+};
+
+template <int NP, int RT>
+__global__ __launch_bounds__(256) void ec2s_fwd_kernel(const float *__restrict__ pq, const int32_t *__restrict__ idx,
+                                                        const float *__restrict__ w2, const float *__restrict__ gamma1,
+                                                        const float *__restrict__ beta1, const float *__restrict__ mean1,
+                                                        const float *__restrict__ invstd1,
+                                                        const float *__restrict__ gamma2, int N, int k, int TP,
+                                                        int training, float slope, float *__restrict__ ysel,
+                                                        uint8_t *__restrict__ arg, float *__restrict__ ssum,
+                                                        float *__restrict__ partials) {
+    constexpr int C2 = 64, LD2 = C2 + 1, Rpad = 32 * RT, PB = Rpad * 128;   // PB: bytes of one piece image
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *Z = smem;                                            // [NP][Rpad][128]  z1 pieces
+    float *Y = reinterpret_cast<float *>(Z + NP * PB);                  // [Rpad][LD2]      y2
+    float *red = Y + Rpad * LD2;                                        // [3][4][C2]
+
+    const int b = blockIdx.x, G = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql = lane & 31, half = lane >> 5;
+    const int ld = 2 * C1;
+    const ChunkGather rows_pq(pq + (long)b * N * ld, (long)N * ld * 4);
+    const int R = TP * k;
+    const int ntiles = (N + TP - 1) / TP;
+    const int chunk = tid & 7, irow = tid >> 3;
+
+    float a1[8], b1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = chunk * 8 + j;
+        a1[j] = gamma1[c] * invstd1[c];
+        b1[j] = beta1[c] - mean1[c] * a1[j];
+    }
+    // W2 fragments of this wave's column tile (B operand: column c2, eight consecutive c1)
+    const int ct = wave & 1;
+    u32x4 wf[C1 / 16][NP];
+#pragma unroll
+    for (int ks = 0; ks < C1 / 16; ++ks) {
+        float x[8];
+        const float4 *src = reinterpret_cast<const float4 *>(w2 + (ct * 32 + ql) * C1 + 16 * ks + 8 * half);
+        const float4 x0 = src[0], x1 = src[1];
+        x[0] = x0.x; x[1] = x0.y; x[2] = x0.z; x[3] = x0.w; x[4] = x1.x; x[5] = x1.y; x[6] = x1.z; x[7] = x1.w;
+        split8<NP>(x, wf[ks]);
+    }
+    int prow[RT];      // point of an item's row within the tile (the same for every tile)
+#pragma unroll
+    for (int it = 0; it < RT; ++it) prow[it] = (irow + 32 * it) / k;
+
+    const float sgn = gamma2[lane] >= 0.f ? 1.f : -1.f;
+    float shift = 0.f, s1 = 0.f, s2 = 0.f, cnt = 0.f;
+    bool first = true;
+
+    auto load_idx = [&](int tile, int (&j)[RT]) {
+        const int i0 = tile * TP;
+        const long ebase = ((long)b * N + i0) * k;
+#pragma unroll
+        for (int it = 0; it < RT; ++it) {
+            const int row = irow + 32 * it;
+            const bool ok = tile < ntiles && row < R && i0 + prow[it] < N;
+            j[it] = ok ? idx[ebase + row] : -1;
+        }
+    };
+    auto load_rows = [&](int tile, const int (&j)[RT], TileRows<RT> &t) {
+        const int i0 = tile * TP;
+#pragma unroll
+        for (int it = 0; it < RT; ++it) {
+            const bool ok = j[it] >= 0;
+            const unsigned po = (unsigned)j[it] * (unsigned)(ld * 4) + chunk * 32u;
+            const unsigned qo = (unsigned)(i0 + prow[it]) * (unsigned)(ld * 4) + C1 * 4u + chunk * 32u;
+            t.p[it][0] = rows_pq.load(ok, po);
+            t.p[it][1] = rows_pq.load(ok, po + 16u);
+            t.q[it][0] = rows_pq.load(ok, qo);
+            t.q[it][1] = rows_pq.load(ok, qo + 16u);
+        }
+    };
+
+    int jc[RT], jn[RT];
+    TileRows<RT> cur;
+    load_idx(blockIdx.y, jc);
+    load_rows(blockIdx.y, jc, cur);
+    load_idx(blockIdx.y + G, jn);
+
+    for (int tile = blockIdx.y; tile < ntiles; tile += G) {
+        const int i0 = tile * TP;
+        // ---- phase 1: z1 = LeakyReLU(BN1(P_j + Q_i)) -> pieces -> image
+#pragma unroll
+        for (int it = 0; it < RT; ++it) {
+            const bool ok = jc[it] >= 0;
+            const float y[8] = {cur.p[it][0].x + cur.q[it][0].x, cur.p[it][0].y + cur.q[it][0].y, cur.p[it][0].z + cur.q[it][0].z,
+                                cur.p[it][0].w + cur.q[it][0].w, cur.p[it][1].x + cur.q[it][1].x, cur.p[it][1].y + cur.q[it][1].y,
+                                cur.p[it][1].z + cur.q[it][1].z, cur.p[it][1].w + cur.q[it][1].w};
+            float z[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] = ok ? lrelu(__builtin_fmaf(y[j], a1[j], b1[j]), slope) : 0.f;
+            u32x4 pc[NP];
+            split8<NP>(z, pc);
+            const int off = img_off(irow + 32 * it, chunk);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x4 *>(Z + q * PB + off) = pc[q];
+        }
+        __syncthreads();   // the image is complete; every wave is past the previous tile's selection pass (Y is free)
+#pragma unroll
+        for (int it = 0; it < RT; ++it) jc[it] = jn[it];
+        load_rows(tile + G, jc, cur);      // behind the last tile: every index is -1, the loads touch nothing
+        load_idx(tile + 2 * G, jn);
+
+        // ---- phase 2 + 3: y2 = z1 W2^T; wave takes row tiles (wave >> 1) + 2 pi of its column tile; accumulators -> Y
+#pragma unroll
+        for (int pi = 0; pi < RT / 2; ++pi) {
+            const int rt = (wave >> 1) + 2 * pi;
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < C1 / 16; ++ks) {
+                u32x4 af[NP];
+                row_frag<NP>(Z, PB, rt, ks, ql, half, af);
+                acc = mfma_split<NP>(af, wf[ks], acc);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                Y[row * LD2 + ct * 32 + ql] = acc[e];
+            }
+        }
+        __syncthreads();
+        // ---- phase 4: statistics + selection (lanes = layer-2 channels)
+        for (int p = wave; p < TP; p += 4) {
+            const int i = i0 + p;
+            if (i >= N) break;
+            float best = -INFINITY, tot = 0.f;
+            int barg = 0;
+            for (int s = 0; s < k; ++s) {
+                const float y = Y[(p * k + s) * LD2 + lane];
+                tot += y;
+                const float v = sgn * y;
+                if (v > best) { best = v; barg = s; }
+                if (training) {
+                    if (first) { shift = y; first = false; }
+                    const float d = y - shift;
+                    s1 += d;
+                    s2 = __builtin_fmaf(d, d, s2);
+                }
+            }
+            const long o = ((long)b * N + i) * C2 + lane;
+            ysel[o] = sgn * best;
+            arg[o] = (uint8_t)barg;
+            if (ssum) ssum[o] = tot;
+            cnt += (float)k;
+        }
+    }
+    if (!training) return;
+    {
+        float mean = 0.f, m2 = 0.f;
+        if (cnt > 0.f) {
+            mean = shift + s1 / cnt;
+            m2 = fmaxf(s2 - s1 * s1 / cnt, 0.f);
+        }
+        __syncthreads();
+        red[(0 * 4 + wave) * C2 + lane] = cnt;
+        red[(1 * 4 + wave) * C2 + lane] = mean;
+        red[(2 * 4 + wave) * C2 + lane] = m2;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C2; c += 256) {
+        float n = red[(0 * 4 + 0) * C2 + c], mu = red[(1 * 4 + 0) * C2 + c], M2 = red[(2 * 4 + 0) * C2 + c];
+        for (int w = 1; w < 4; ++w) {
+            const float nb = red[(0 * 4 + w) * C2 + c];
+            if (nb > 0.f) {
+                const float tot = n + nb, delta = red[(1 * 4 + w) * C2 + c] - mu;
+                mu += delta * (nb / tot);
+                M2 += red[(2 * 4 + w) * C2 + c] + delta * delta * (n * nb / tot);
+                n = tot;
+            }
+        }
+        const long rec = (long)b * gridDim.y + blockIdx.y;
+        float *pr = partials + rec * 3 * C2;
+        pr[c] = n;
+        pr[C2 + c] = mu;
+        pr[2 * C2 + c] = M2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward (split-bf16)
+// Per tile: y2^T = W2 z1^T (A = W2 fragments in registers, B = row reads of the z1 image) -> dy2 in registers with lanes = edge
+// rows -> dy2 image (row-major, 8-byte stores);  dz1 = dy2 W2 (A = row reads of the dy2 image, B = W2 fragments in registers)
+// -> du1 rows to HBM + the dbeta1/dgamma1 sums;  dW2 += dy2^T z1 (both operands by transposed reads of the two images).
+template <int NP, int RT>
+__global__ __launch_bounds__(256, 2) void ec2s_bwd_kernel(
+    const float *__restrict__ pq, const int32_t *__restrict__ idx, const float *__restrict__ w2,
+    const float *__restrict__ gamma1, const float *__restrict__ beta1, const float *__restrict__ mean1,
+    const float *__restrict__ invstd1, const float *__restrict__ gamma2, const float *__restrict__ mean2,
+    const float *__restrict__ invstd2, const float *__restrict__ dbeta2, const float *__restrict__ dgamma2,
+    const float *__restrict__ h2, const uint8_t *__restrict__ arg2, int N, int k, int TP, int training,
+    float invM, float slope, float *__restrict__ du1, float *__restrict__ dw2_part, float *__restrict__ part1) {
+    constexpr int C2 = 64, Rpad = 32 * RT, PB = Rpad * 128, LDY = C1 + 4;   // LDY: 16-byte aligned fp32 rows, 4 banks apart
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *Z = smem;                                       // [NP][Rpad][128]  z1 pieces
+    unsigned char *D = Z + NP * PB;                                // [NP][Rpad][128]  dy2 pieces
+    float *Y1 = reinterpret_cast<float *>(D + NP * PB);            // [Rpad][LDY]      y1 (fp32, for f'(u1) and yhat1)
+    float *BcA = Y1 + Rpad * LDY;                                  // [C2][2]          dy2 = Bc y2 + A (+ selected-edge term)
+    float *A2s = BcA + 2 * C2;                                     // [C2]             gamma2 * invstd2
+    float *A1s = A2s + C2;                                         // [2][C1]          a1, b1
+    float *HT = A1s + 2 * C1;                                      // [TP][C2][2]      (a2 h2, slot of the selected edge)
+
+    const int b = blockIdx.x, G = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql = lane & 31, half = lane >> 5;
+    const int ld = 2 * C1;
+    const ChunkGather rows_pq(pq + (long)b * N * ld, (long)N * ld * 4);
+    const int R = TP * k;
+    const int ntiles = (N + TP - 1) / TP;
+    const int chunk = tid & 7, irow = tid >> 3;
+
+    if (tid < C2) {
+        const float r2 = invstd2[tid], a2 = gamma2[tid] * r2, mu2 = mean2[tid];
+        const float db2 = training ? dbeta2[tid] * invM : 0.f, dg2 = training ? dgamma2[tid] * invM : 0.f;
+        BcA[2 * tid] = -(a2 * r2) * dg2;
+        BcA[2 * tid + 1] = a2 * (mu2 * r2 * dg2 - db2);
+        A2s[tid] = a2;
+        const float a = gamma1[tid] * invstd1[tid];
+        A1s[tid] = a;
+        A1s[C1 + tid] = beta1[tid] - mean1[tid] * a;
+    }
+    float a1[8], b1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = chunk * 8 + j;
+        a1[j] = gamma1[c] * invstd1[c];
+        b1[j] = beta1[c] - mean1[c] * a1[j];
+    }
+    // W2 fragments: wfa = rows c2 of the wave's layer-2 tile, eight consecutive c1 (A operand of y2^T = W2 z1^T);
+    //               wfb = columns c1 of the wave's layer-1 tile, eight consecutive c2 (B operand of dz1 = dy2 W2)
+    const int ctw = wave & 1;
+    u32x4 wfa[C1 / 16][NP], wfb[C2 / 16][NP];
+#pragma unroll
+    for (int ks = 0; ks < C1 / 16; ++ks) {
+        float x[8];
+        const float4 *src = reinterpret_cast<const float4 *>(w2 + (ctw * 32 + ql) * C1 + 16 * ks + 8 * half);
+        const float4 x0 = src[0], x1 = src[1];
+        x[0] = x0.x; x[1] = x0.y; x[2] = x0.z; x[3] = x0.w; x[4] = x1.x; x[5] = x1.y; x[6] = x1.z; x[7] = x1.w;
+        split8<NP>(x, wfa[ks]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < C2 / 16; ++ks) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = w2[(16 * ks + 8 * half + j) * C1 + ctw * 32 + ql];
+        split8<NP>(x, wfb[ks]);
+    }
+    int prow[RT];      // point of an item's row within the tile (gather mapping), the same for every tile
+#pragma unroll
+    for (int it = 0; it < RT; ++it) prow[it] = (irow + 32 * it) / k;
+    int pmf[RT / 2], smf[RT / 2];   // point and slot of row rt * 32 + ql (lanes = rows in the dy2 epilogue)
+#pragma unroll
+    for (int pi = 0; pi < RT / 2; ++pi) {
+        const int row = ((wave >> 1) + 2 * pi) * 32 + ql;
+        const int p = row / k;
+        smf[pi] = row - p * k;
+        pmf[pi] = min(p, TP - 1);
+    }
+
+    f32x16 accw;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accw[e] = 0.f;
+    float sb_acc = 0.f, sg_acc = 0.f;
+
+    auto load_idx = [&](int tile, int (&j)[RT]) {
+        const int i0 = tile * TP;
+        const long ebase = ((long)b * N + i0) * k;
+#pragma unroll
+        for (int it = 0; it < RT; ++it) {
+            const int row = irow + 32 * it;
+            const bool ok = tile < ntiles && row < R && i0 + prow[it] < N;
+            j[it] = ok ? idx[ebase + row] : -1;
+        }
+    };
+    auto load_rows = [&](int tile, const int (&j)[RT], TileRows<RT> &t) {
+        const int i0 = tile * TP;
+#pragma unroll
+        for (int it = 0; it < RT; ++it) {
+            const bool ok = j[it] >= 0;
+            const unsigned po = (unsigned)j[it] * (unsigned)(ld * 4) + chunk * 32u;
+            const unsigned qo = (unsigned)(i0 + prow[it]) * (unsigned)(ld * 4) + C1 * 4u + chunk * 32u;
+            t.p[it][0] = rows_pq.load(ok, po);
+            t.p[it][1] = rows_pq.load(ok, po + 16u);
+            t.q[it][0] = rows_pq.load(ok, qo);
+            t.q[it][1] = rows_pq.load(ok, qo + 16u);
+        }
+    };
+    // h2 / arg2 of the tile's points: one (point, channel) per thread while TP <= 4 (prefetched), a loop otherwise
+    const bool ht_reg = TP <= 4;
+    float hn = 0.f;
+    int an = 255;
+    auto load_ht = [&](int tile) {
+        const int p = tid >> 6, i = tile * TP + p;
+        const bool ok = tile < ntiles && p < TP && i < N;
+        hn = ok ? h2[((long)b * N + i) * C2 + lane] : 0.f;
+        an = ok ? (int)arg2[((long)b * N + i) * C2 + lane] : 255;
+    };
+
+    int jc[RT], jn[RT];
+    TileRows<RT> cur;
+    load_idx(blockIdx.y, jc);
+    load_rows(blockIdx.y, jc, cur);
+    load_idx(blockIdx.y + G, jn);
+    if (ht_reg) load_ht(blockIdx.y);
+    __syncthreads();   // the constant tables
+
+    for (int tile = blockIdx.y; tile < ntiles; tile += G) {
+        const int i0 = tile * TP;
+        const int pvalid = min(TP, N - i0);   // valid points of this tile
+        const int rvalid = pvalid * k;        // valid rows
+        // ---- phase 1: y1 -> Y1 (fp32), z1 = LeakyReLU(BN1(y1)) -> pieces -> Z; rows beyond the tile: zeros
+#pragma unroll
+        for (int it = 0; it < RT; ++it) {
+            const bool ok = jc[it] >= 0;
+            const float y[8] = {cur.p[it][0].x + cur.q[it][0].x, cur.p[it][0].y + cur.q[it][0].y, cur.p[it][0].z + cur.q[it][0].z,
+                                cur.p[it][0].w + cur.q[it][0].w, cur.p[it][1].x + cur.q[it][1].x, cur.p[it][1].y + cur.q[it][1].y,
+                                cur.p[it][1].z + cur.q[it][1].z, cur.p[it][1].w + cur.q[it][1].w};
+            float z[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] = ok ? lrelu(__builtin_fmaf(y[j], a1[j], b1[j]), slope) : 0.f;
+            u32x4 pc[NP];
+            split8<NP>(z, pc);
+            const int row = irow + 32 * it;
+            const int off = img_off(row, chunk);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x4 *>(Z + q * PB + off) = pc[q];
+            float4 *yd = reinterpret_cast<float4 *>(Y1 + row * LDY + chunk * 8);
+            yd[0] = float4{y[0], y[1], y[2], y[3]};      // rows beyond the tile: 0 + 0
+            yd[1] = float4{y[4], y[5], y[6], y[7]};
+        }
+        if (ht_reg) {
+            if (tid < TP * C2) {
+                HT[2 * tid] = A2s[lane] * hn;
+                HT[2 * tid + 1] = __int_as_float(an);
+            }
+        } else {
+            for (int t = tid; t < TP * C2; t += 256) {
+                const int p = t >> 6, c = t & 63, i = i0 + p;
+                HT[2 * t] = i < N ? A2s[c] * h2[((long)b * N + i) * C2 + c] : 0.f;
+                HT[2 * t + 1] = __int_as_float(i < N ? (int)arg2[((long)b * N + i) * C2 + c] : 255);
+            }
+        }
+        __syncthreads();   // (1) Z, Y1, HT complete
+#pragma unroll
+        for (int it = 0; it < RT; ++it) jc[it] = jn[it];
+        load_rows(tile + G, jc, cur);      // behind the last tile: every index is -1, the loads touch nothing
+        load_idx(tile + 2 * G, jn);
+        if (ht_reg) load_ht(tile + G);
+
+        // ---- phase 2 + 3: y2^T = W2 z1^T; lanes = edge rows; dy2 = Bc y2 + A (+ a2 h2 on the selected edge) -> D
+#pragma unroll
+        for (int pi = 0; pi < RT / 2; ++pi) {
+            const int rt = (wave >> 1) + 2 * pi;
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < C1 / 16; ++ks) {
+                u32x4 zf[NP];
+                row_frag<NP>(Z, PB, rt, ks, ql, half, zf);
+                acc = mfma_split<NP>(wfa[ks], zf, acc);
+            }
+            const int row = rt * 32 + ql;
+            const bool valid = row < rvalid;
+            const float *ht = HT + (pmf[pi] * C2 + ctw * 32 + 4 * half) * 2;
+            const float *bc = BcA + (ctw * 32 + 4 * half) * 2;
+            const int sl = smf[pi];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {     // channels c2 = ctw * 32 + 8 g + 4 half + 0..3 = accumulator elements 4 g + 0..3
+                const float4 c0 = *reinterpret_cast<const float4 *>(bc + 16 * g), c1 = *reinterpret_cast<const float4 *>(bc + 16 * g + 4);
+                const float4 t0 = *reinterpret_cast<const float4 *>(ht + 16 * g), t1 = *reinterpret_cast<const float4 *>(ht + 16 * g + 4);
+                float dy[4];
+                dy[0] = __builtin_fmaf(c0.x, acc[4 * g + 0], c0.y) + (__float_as_int(t0.y) == sl ? t0.x : 0.f);
+                dy[1] = __builtin_fmaf(c0.z, acc[4 * g + 1], c0.w) + (__float_as_int(t0.w) == sl ? t0.z : 0.f);
+                dy[2] = __builtin_fmaf(c1.x, acc[4 * g + 2], c1.y) + (__float_as_int(t1.y) == sl ? t1.x : 0.f);
+                dy[3] = __builtin_fmaf(c1.z, acc[4 * g + 3], c1.w) + (__float_as_int(t1.w) == sl ? t1.z : 0.f);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dy[j] = valid ? dy[j] : 0.f;
+                unsigned hh[2], mm[2] = {0u, 0u}, ll[2] = {0u, 0u};
+                if constexpr (NP == 3) {
+                    split2(dy[0], dy[1], hh[0], mm[0], ll[0]);
+                    split2(dy[2], dy[3], hh[1], mm[1], ll[1]);
+                } else {
+                    hh[0] = pk_bf16(dy[0], dy[1]);
+                    hh[1] = pk_bf16(dy[2], dy[3]);
+                }
+                const int off = img_off(row, 4 * ctw + g) + 8 * half;
+                *reinterpret_cast<u32x2 *>(D + off) = u32x2{hh[0], hh[1]};
+                if constexpr (NP == 3) {
+                    *reinterpret_cast<u32x2 *>(D + PB + off) = u32x2{mm[0], mm[1]};
+                    *reinterpret_cast<u32x2 *>(D + 2 * PB + off) = u32x2{ll[0], ll[1]};
+                }
+            }
+        }
+        __syncthreads();   // (2) D complete
+
+        // ---- phase 4: dz1 = dy2 W2 -> du1 = dz1 f'(u1); sums for dbeta1 / dgamma1; du1 rows to HBM
+#pragma unroll
+        for (int pi = 0; pi < RT / 2; ++pi) {
+            const int rt = (wave >> 1) + 2 * pi;
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < C2 / 16; ++ks) {
+                u32x4 df[NP];
+                row_frag<NP>(D, PB, rt, ks, ql, half, df);
+                acc = mfma_split<NP>(df, wfb[ks], acc);
+            }
+            const int c1 = ctw * 32 + ql;
+            const float a1c = A1s[c1], b1c = A1s[C1 + c1], mu1 = mean1[c1], r1 = invstd1[c1];
+            float sb = 0.f, sg = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (row < rvalid) {
+                    const float y1 = Y1[row * LDY + c1];
+                    const float u1 = __builtin_fmaf(y1, a1c, b1c);
+                    const float du = acc[e] * (u1 > 0.f ? 1.f : slope);
+                    du1[(((long)b * N + i0) * k + row) * C1 + c1] = du;
+                    sb += du;
+                    sg = __builtin_fmaf(du, (y1 - mu1) * r1, sg);
+                }
+            }
+            sb_acc += sb;
+            sg_acc += sg;
+        }
+        // ---- phase 5: dW2 += dy2^T z1 (contraction over the tile's rows, transposed reads of both images); the wave owns
+        // the (c2 tile wave >> 1, c1 tile wave & 1) block across every tile of the workgroup
+#pragma unroll
+        for (int ks = 0; ks < Rpad / 16; ++ks) {
+            u32x4 df[NP], zf[NP];
+            tr_frag<NP>(D, PB, wave >> 1, ks, lane, df);
+            tr_frag<NP>(Z, PB, wave & 1, ks, lane, zf);
+            accw = mfma_split<NP>(df, zf, accw);
+        }
+        __syncthreads();   // (3) Z / D / Y1 / HT are rewritten by the next tile
+    }
+    // ---- epilogue: dW2 partial block and the dbeta1/dgamma1 partial sums of this workgroup
+    const long rec = (long)b * gridDim.y + blockIdx.y;
+    {
+        const int ct2 = wave >> 1, ct1 = wave & 1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int c2 = ct2 * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+            dw2_part[(rec * C2 + c2) * C1 + ct1 * 32 + ql] = accw[e];
+        }
+    }
+    {
+        float *redw = reinterpret_cast<float *>(D);   // [4 waves][2][C1]; the tiles are done (barrier 3)
+        for (int t = threadIdx.x; t < 4 * 2 * C1; t += 256) redw[t] = 0.f;
+        __syncthreads();
+        const float sbw = sb_acc + __shfl_xor(sb_acc, 32), sgw = sg_acc + __shfl_xor(sg_acc, 32);   // the two k-halves
+        if (half == 0) {
+            const int c1 = ctw * 32 + ql;
+            redw[(wave * 2) * C1 + c1] = sbw;
+            redw[(wave * 2 + 1) * C1 + c1] = sgw;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * C1) {
+            const int which = threadIdx.x / C1, c = threadIdx.x % C1;
+            part1[rec * 2 * C1 + threadIdx.x] = redw[(0 * 2 + which) * C1 + c] + redw[(1 * 2 + which) * C1 + c] +
+                                                redw[(2 * 2 + which) * C1 + c] + redw[(3 * 2 + which) * C1 + c];
+        }
+    }
+}
+
 }  // namespace
 
 // shared with edgeconv.hip
@@ -576,6 +1169,45 @@ int fsg_ec_apply_launch(const float *ysel, const float *gamma, const float *beta
                         int B, int N, int Co, float slope, float *out, float *out_pm, hipStream_t st);
 int fsg_ec_stats1_records(int B, int N);
 size_t fsg_ec_finalize_stage_floats(int Co);
+
+static int ec2_env_int(const char *name) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : 0;
+}
+
+// C2 = 64 runs on the split-bf16 kernels (FSG_EC2_OLD=1: the fp32-MFMA kernels above, kept for C2 = 128 and as a cross-check)
+static bool ec2_split(int C2) {
+    static int old_env = -1;
+    if (old_env < 0) old_env = ec2_env_int("FSG_EC2_OLD") > 0 ? 1 : 0;
+    return C2 == 64 && !old_env;
+}
+
+// tiles of the split kernels: RT * 32 edge rows = TP points; 128 rows when that cuts the padding by more than 15 % (k = 40:
+// 40 of 64 rows against 120 of 128), 64 rows otherwise; `wgs` workgroups over the B clouds
+static void ec2s_tiling(int k, int B, int N, bool bwd, int &RT, int &TP, int &G) {
+    static int rt_env = -1, fwd_wgs = -1, bwd_wgs = -1;
+    if (rt_env < 0) {
+        rt_env = ec2_env_int("FSG_EC2S_RT");
+        fwd_wgs = ec2_env_int("FSG_EC2S_FWD_WGS");
+        bwd_wgs = ec2_env_int("FSG_EC2S_BWD_WGS");
+    }
+    const int tp2 = 64 / k, tp4 = 128 / k;
+    const float u2 = tp2 * k / 64.f, u4 = tp4 * k / 128.f;
+    RT = u4 > 1.15f * u2 ? 4 : 2;
+    if (rt_env == 2 || rt_env == 4) RT = rt_env;
+    TP = RT == 4 ? tp4 : tp2;
+    if (TP < 1) TP = 1;
+    const int ntiles = (N + TP - 1) / TP;
+    const int wgs = bwd ? (bwd_wgs > 0 ? bwd_wgs : 512) : (fwd_wgs > 0 ? fwd_wgs : 768);
+    G = wgs / (B > 0 ? B : 1);
+    if (G < 1) G = 1;
+    if (G > ntiles) G = ntiles;
+}
+
+static size_t ec2s_fwd_lds(int NP, int RT) { return (size_t)NP * RT * 32 * 128 + sizeof(float) * ((size_t)RT * 32 * 65 + 3 * 4 * 64); }
+static size_t ec2s_bwd_lds(int NP, int RT, int TP) {
+    return (size_t)2 * NP * RT * 32 * 128 + sizeof(float) * ((size_t)RT * 32 * (C1 + 4) + 2 * 64 + 64 + 2 * C1 + (size_t)TP * 64 * 2);
+}
 
 static void ec2_tiling(int k, int C2, int &TP, int &Rpad, int &G, int B, int N) {
     static int rmax_env = -1;
@@ -596,6 +1228,11 @@ static void ec2_tiling(int k, int C2, int &TP, int &Rpad, int &G, int B, int N) 
 extern "C" size_t fsg_edgeconv2_workspace_bytes(int B, int N, int k, int C2) {
     int TP, Rpad, G;
     ec2_tiling(k, C2, TP, Rpad, G, B, N);
+    if (ec2_split(C2)) {
+        int RT, TPs, Gs;
+        ec2s_tiling(k, B, N, false, RT, TPs, Gs);
+        if (Gs > G) G = Gs;
+    }
     const size_t rec1 = (size_t)fsg_ec_stats1_records(B, N) * 3 * C1 + fsg_ec_finalize_stage_floats(C1);
     const size_t rec2 = (size_t)B * G * 3 * C2 + fsg_ec_finalize_stage_floats(C2);
     // layer-1 scratch: ysel1 (unused output of the shared stats kernel), arg1
@@ -619,10 +1256,15 @@ static int ec2_fwd_impl(bool bf16, const float *pq, const int32_t *idx, const fl
     hipStream_t st = (hipStream_t)stream;
     int TP, Rpad, G;
     ec2_tiling(k, C2, TP, Rpad, G, B, N);
+    int RTs = 0, TPs = 0, Gs = 0, Gws = G;     // Gws: the record count the workspace layout is sized for
+    if (ec2_split(C2)) {
+        ec2s_tiling(k, B, N, false, RTs, TPs, Gs);
+        if (Gs > Gws) Gws = Gs;
+    }
     const int rec1 = fsg_ec_stats1_records(B, N);
     float *part1 = (float *)workspace;
     float *part2 = part1 + (size_t)rec1 * 3 * C1 + fsg_ec_finalize_stage_floats(C1);
-    float *ysel1 = part2 + (size_t)B * G * 3 * C2 + fsg_ec_finalize_stage_floats(C2);
+    float *ysel1 = part2 + (size_t)B * Gws * 3 * C2 + fsg_ec_finalize_stage_floats(C2);
     uint8_t *arg1 = (uint8_t *)(ysel1 + (size_t)B * N * C1);
     int rc;
     if (training) {  // BN1 statistics over all edges of y1 = P_j + Q_i (shared kernel; its selection output is unused)
@@ -646,9 +1288,28 @@ static int ec2_fwd_impl(bool bf16, const float *pq, const int32_t *idx, const fl
         hipLaunchKernelGGL((ec2_fwd_kernel<CC, BFX>), dim3(B, G), dim3(256), lds, st, pq, idx, w2, gamma1, beta1, mean1,    \
                            invstd1, gamma2, N, k, TP, Rpad, training, slope, ysel2, arg2, ssum2, part2);                 \
     } while (0)
-    if (C2 == 64) { if (bf16) FSG_EC2_FWD(64, true); else FSG_EC2_FWD(64, false); }
+#define FSG_EC2S_FWD(NPX, RTX)                                                                                            \
+    do {                                                                                                                 \
+        static bool granted = false;                                                                                     \
+        if (!granted) {                                                                                                  \
+            if (hipFuncSetAttribute((const void *)ec2s_fwd_kernel<NPX, RTX>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                    160 * 1024 - 512) != hipSuccess) {                                                   \
+                fsg_set_error("fsg_edgeconv2_fwd: cannot raise dynamic LDS");                                            \
+                return FSG_ERR_HIP;                                                                                      \
+            }                                                                                                            \
+            granted = true;                                                                                              \
+        }                                                                                                                \
+        hipLaunchKernelGGL((ec2s_fwd_kernel<NPX, RTX>), dim3(B, G), dim3(256), ec2s_fwd_lds(NPX, RTX), st, pq, idx, w2,    \
+                           gamma1, beta1, mean1, invstd1, gamma2, N, k, TPs, training, slope, ysel2, arg2, ssum2, part2); \
+    } while (0)
+    if (ec2_split(C2)) {
+        G = Gs;
+        if (bf16) { if (RTs == 4) FSG_EC2S_FWD(1, 4); else FSG_EC2S_FWD(1, 2); }
+        else { if (RTs == 4) FSG_EC2S_FWD(3, 4); else FSG_EC2S_FWD(3, 2); }
+    } else if (C2 == 64) { if (bf16) FSG_EC2_FWD(64, true); else FSG_EC2_FWD(64, false); }
     else { if (bf16) FSG_EC2_FWD(128, true); else FSG_EC2_FWD(128, false); }
 #undef FSG_EC2_FWD
+#undef FSG_EC2S_FWD
     FSG_CHECK_LAUNCH("fsg_edgeconv2_fwd_f32/mlp");
     if (training) {
         if ((rc = fsg_ec_finalize_launch(part2, B * G, C2, eps2, momentum2, mean2, invstd2, running_mean2, running_var2,
@@ -708,6 +1369,11 @@ static void ec2_bwd_tiling(int k, int C2, int &TP, int &Rpad, int &G, int B, int
 extern "C" size_t fsg_edgeconv2_bwd_workspace_bytes(int B, int N, int k, int C2) {
     int TP, Rpad, G;
     ec2_bwd_tiling(k, C2, TP, Rpad, G, B, N);
+    if (ec2_split(C2)) {
+        int RT, TPs, Gs;
+        ec2s_tiling(k, B, N, true, RT, TPs, Gs);
+        if (Gs > G) G = Gs;
+    }
     const size_t point_rec = (size_t)B * fsg_cdiv(N, 64) * 2 * C2;       // ec1_bwd_point partials
     const size_t dw = (size_t)B * G * C2 * C1, p1 = (size_t)B * G * 2 * C1;
     const size_t du = (size_t)B * N * k * C1;
@@ -734,10 +1400,15 @@ static int ec2_bwd_impl(bool bf16, const float *grad_out, const float *grad_out_
     hipStream_t st = (hipStream_t)stream;
     int TP, Rpad, G;
     ec2_bwd_tiling(k, C2, TP, Rpad, G, B, N);
+    int RTs = 0, TPs = 0, Gs = 0, Gws = G;     // Gws: the record count the workspace layout is sized for
+    if (ec2_split(C2)) {
+        ec2s_tiling(k, B, N, true, RTs, TPs, Gs);
+        if (Gs > Gws) Gws = Gs;
+    }
     float *point_part = (float *)workspace;
     float *dw_part = point_part + (size_t)B * fsg_cdiv(N, 64) * 2 * C2;
-    float *p1_part = dw_part + (size_t)B * G * C2 * C1;
-    float *du1 = p1_part + (size_t)B * G * 2 * C1;
+    float *p1_part = dw_part + (size_t)B * Gws * C2 * C1;
+    float *du1 = p1_part + (size_t)B * Gws * 2 * C1;
     float *h2 = du1 + (size_t)B * N * k * C1;
     int rc;
     // h2 = grad_out f'(u2) on the selected edge, dbeta2 / dgamma2
@@ -763,9 +1434,30 @@ static int ec2_bwd_impl(bool bf16, const float *grad_out, const float *grad_out_
                            gamma2, mean2, invstd2, grad_beta2, grad_gamma2, h2, arg2, N, k, TP, Rpad, training, invM,    \
                            slope, du1, dw_part, p1_part);                                                                \
     } while (0)
-    if (C2 == 64) { if (bf16) FSG_EC2_BWD(64, true); else FSG_EC2_BWD(64, false); }
+#define FSG_EC2S_BWD(NPX, RTX)                                                                                            \
+    do {                                                                                                                 \
+        static bool granted = false;                                                                                     \
+        if (!granted) {                                                                                                  \
+            if (hipFuncSetAttribute((const void *)ec2s_bwd_kernel<NPX, RTX>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                    160 * 1024 - 512) != hipSuccess) {                                                   \
+                fsg_set_error("fsg_edgeconv2_bwd_f32: cannot raise dynamic LDS");                                        \
+                return FSG_ERR_HIP;                                                                                      \
+            }                                                                                                            \
+            granted = true;                                                                                              \
+        }                                                                                                                \
+        hipLaunchKernelGGL((ec2s_bwd_kernel<NPX, RTX>), dim3(B, G), dim3(256), ec2s_bwd_lds(NPX, RTX, TPs), st, pq, idx,   \
+                           w2, gamma1, beta1, mean1, invstd1, gamma2, mean2, invstd2, grad_beta2, grad_gamma2, h2, arg2, \
+                           N, k, TPs, training, invM, slope, du1, dw_part, p1_part);                                     \
+    } while (0)
+    if (ec2_split(C2)) {
+        G = Gs;
+        FSG_REQUIRE(ec2s_bwd_lds(bf16 ? 1 : 3, RTs, TPs) <= 160 * 1024 - 512, "fsg_edgeconv2_bwd: k=%d needs too much LDS", k);
+        if (bf16) { if (RTs == 4) FSG_EC2S_BWD(1, 4); else FSG_EC2S_BWD(1, 2); }
+        else { if (RTs == 4) FSG_EC2S_BWD(3, 4); else FSG_EC2S_BWD(3, 2); }
+    } else if (C2 == 64) { if (bf16) FSG_EC2_BWD(64, true); else FSG_EC2_BWD(64, false); }
     else { if (bf16) FSG_EC2_BWD(128, true); else FSG_EC2_BWD(128, false); }
 #undef FSG_EC2_BWD
+#undef FSG_EC2S_BWD
     FSG_CHECK_LAUNCH("fsg_edgeconv2_bwd_f32/mlp");
     if ((rc = fsg_ec_sum_launch(dw_part, B * G, C2 * C1, 1, grad_w2, nullptr, st)) != FSG_OK) return rc;
     if ((rc = fsg_ec_sum_launch(p1_part, B * G, C1, 2, grad_beta1, grad_gamma1, st)) != FSG_OK) return rc;
