@@ -687,7 +687,7 @@ struct ChunkGather {
 // the gather state of one tile: RT items per thread, item `it` = (row irow + 32 it, chunk) of the tile
 template <int RT>
 struct TileRows {
-    float4 p[RT][2], q[RT][2];
+    float4 p[RT][2];
 };
 
 template <int NP, int RT>
@@ -704,6 +704,8 @@ __global__ __launch_bounds__(256) void ec2s_fwd_kernel(const float *__restrict__
     unsigned char *Z = smem;                                            // [NP][Rpad][128]  z1 pieces
     float *Y = reinterpret_cast<float *>(Z + NP * PB);                  // [Rpad][LD2]      y2
     float *red = Y + Rpad * LD2;                                        // [3][4][C2]
+    float *A1s = red + 3 * 4 * C2;                                      // [2][C1]          a1, b1 of BatchNorm 1
+    float *QS = A1s + 2 * C1;                                           // [2][TP][C1]      Q rows of the tile's points (double buffer)
 
     const int b = blockIdx.x, G = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -714,12 +716,10 @@ __global__ __launch_bounds__(256) void ec2s_fwd_kernel(const float *__restrict__
     const int ntiles = (N + TP - 1) / TP;
     const int chunk = tid & 7, irow = tid >> 3;
 
-    float a1[8], b1[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int c = chunk * 8 + j;
-        a1[j] = gamma1[c] * invstd1[c];
-        b1[j] = beta1[c] - mean1[c] * a1[j];
+    if (tid < C1) {
+        const float a = gamma1[tid] * invstd1[tid];
+        A1s[tid] = a;
+        A1s[C1 + tid] = beta1[tid] - mean1[tid] * a;
     }
     // W2 fragments of this wave's column tile (B operand: column c2, eight consecutive c1)
     const int ct = wave & 1;
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(256) void ec2s_fwd_kernel(const float *__restrict__
     }
     int prow[RT];      // point of an item's row within the tile (the same for every tile)
 #pragma unroll
-    for (int it = 0; it < RT; ++it) prow[it] = (irow + 32 * it) / k;
+    for (int it = 0; it < RT; ++it) prow[it] = min((irow + 32 * it) / k, TP - 1);   // rows behind the tile: any valid row
 
     const float sgn = gamma2[lane] >= 0.f ? 1.f : -1.f;
     float shift = 0.f, s1 = 0.f, s2 = 0.f, cnt = 0.f;
@@ -751,17 +751,19 @@ __global__ __launch_bounds__(256) void ec2s_fwd_kernel(const float *__restrict__
         }
     };
     auto load_rows = [&](int tile, const int (&j)[RT], TileRows<RT> &t) {
-        const int i0 = tile * TP;
-#pragma unroll
+    #pragma unroll
         for (int it = 0; it < RT; ++it) {
             const bool ok = j[it] >= 0;
             const unsigned po = (unsigned)j[it] * (unsigned)(ld * 4) + chunk * 32u;
-            const unsigned qo = (unsigned)(i0 + prow[it]) * (unsigned)(ld * 4) + C1 * 4u + chunk * 32u;
             t.p[it][0] = rows_pq.load(ok, po);
             t.p[it][1] = rows_pq.load(ok, po + 16u);
-            t.q[it][0] = rows_pq.load(ok, qo);
-            t.q[it][1] = rows_pq.load(ok, qo + 16u);
         }
+    };
+    // Q rows of a tile's points: one 16-byte piece per thread (TP <= 16), prefetched two tiles ahead and parked in QS
+    auto load_q = [&](int tile) {
+        const int p = tid >> 4, i = tile * TP + p;
+        const bool ok = tile < ntiles && p < TP && i < N;
+        return rows_pq.load(ok, (unsigned)i * (unsigned)(ld * 4) + C1 * 4u + (tid & 15) * 16u);
     };
 
     int jc[RT], jn[RT];
@@ -769,16 +771,25 @@ __global__ __launch_bounds__(256) void ec2s_fwd_kernel(const float *__restrict__
     load_idx(blockIdx.y, jc);
     load_rows(blockIdx.y, jc, cur);
     load_idx(blockIdx.y + G, jn);
+    if (tid < TP * 16) *reinterpret_cast<float4 *>(QS + tid * 4) = load_q(blockIdx.y);
+    float4 qn = load_q(blockIdx.y + G);
+    __syncthreads();   // the BatchNorm table and the first tile's Q rows
 
-    for (int tile = blockIdx.y; tile < ntiles; tile += G) {
+    int par = 0;       // parity of the tile within this workgroup: its Q rows are in QS[par]
+    for (int tile = blockIdx.y; tile < ntiles; tile += G, par ^= 1) {
         const int i0 = tile * TP;
         // ---- phase 1: z1 = LeakyReLU(BN1(P_j + Q_i)) -> pieces -> image
+        const float4 *ab = reinterpret_cast<const float4 *>(A1s + chunk * 8);
+        const float4 a1l = ab[0], a1h = ab[1], b1l = ab[C1 / 4], b1h = ab[C1 / 4 + 1];
+        const float a1[8] = {a1l.x, a1l.y, a1l.z, a1l.w, a1h.x, a1h.y, a1h.z, a1h.w};
+        const float b1[8] = {b1l.x, b1l.y, b1l.z, b1l.w, b1h.x, b1h.y, b1h.z, b1h.w};
 #pragma unroll
         for (int it = 0; it < RT; ++it) {
             const bool ok = jc[it] >= 0;
-            const float y[8] = {cur.p[it][0].x + cur.q[it][0].x, cur.p[it][0].y + cur.q[it][0].y, cur.p[it][0].z + cur.q[it][0].z,
-                                cur.p[it][0].w + cur.q[it][0].w, cur.p[it][1].x + cur.q[it][1].x, cur.p[it][1].y + cur.q[it][1].y,
-                                cur.p[it][1].z + cur.q[it][1].z, cur.p[it][1].w + cur.q[it][1].w};
+            const float4 *qs = reinterpret_cast<const float4 *>(QS + (par * TP + prow[it]) * C1 + chunk * 8);
+            const float4 q0 = qs[0], q1 = qs[1];
+            const float y[8] = {cur.p[it][0].x + q0.x, cur.p[it][0].y + q0.y, cur.p[it][0].z + q0.z, cur.p[it][0].w + q0.w,
+                                cur.p[it][1].x + q1.x, cur.p[it][1].y + q1.y, cur.p[it][1].z + q1.z, cur.p[it][1].w + q1.w};
             float z[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) z[j] = ok ? lrelu(__builtin_fmaf(y[j], a1[j], b1[j]), slope) : 0.f;
@@ -793,6 +804,8 @@ __global__ __launch_bounds__(256) void ec2s_fwd_kernel(const float *__restrict__
         for (int it = 0; it < RT; ++it) jc[it] = jn[it];
         load_rows(tile + G, jc, cur);      // behind the last tile: every index is -1, the loads touch nothing
         load_idx(tile + 2 * G, jn);
+        if (tid < TP * 16) *reinterpret_cast<float4 *>(QS + ((par ^ 1) * TP * C1) + tid * 4) = qn;   // the next tile's Q rows
+        qn = load_q(tile + 2 * G);
 
         // ---- phase 2 + 3: y2 = z1 W2^T; wave takes row tiles (wave >> 1) + 2 pi of its column tile; accumulators -> Y
 #pragma unroll
@@ -820,16 +833,25 @@ __global__ __launch_bounds__(256) void ec2s_fwd_kernel(const float *__restrict__
             if (i >= N) break;
             float best = -INFINITY, tot = 0.f;
             int barg = 0;
-            for (int s = 0; s < k; ++s) {
-                const float y = Y[(p * k + s) * LD2 + lane];
-                tot += y;
-                const float v = sgn * y;
-                if (v > best) { best = v; barg = s; }
-                if (training) {
-                    if (first) { shift = y; first = false; }
-                    const float d = y - shift;
-                    s1 += d;
-                    s2 = __builtin_fmaf(d, d, s2);
+            const float *yp = Y + p * k * LD2 + lane;
+            for (int s0 = 0; s0 < k; s0 += 8) {     // eight rows per round: the LDS reads are in flight together
+                float yv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) yv[u] = yp[min(s0 + u, k - 1) * LD2];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (s0 + u < k) {
+                        const float y = yv[u];
+                        tot += y;
+                        const float v = sgn * y;
+                        if (v > best) { best = v; barg = s0 + u; }
+                        if (training) {
+                            if (first) { shift = y; first = false; }
+                            const float d = y - shift;
+                            s1 += d;
+                            s2 = __builtin_fmaf(d, d, s2);
+                        }
+                    }
                 }
             }
             const long o = ((long)b * N + i) * C2 + lane;
@@ -876,7 +898,7 @@ __global__ __launch_bounds__(256) void ec2s_fwd_kernel(const float *__restrict__
 // rows -> dy2 image (row-major, 8-byte stores);  dz1 = dy2 W2 (A = row reads of the dy2 image, B = W2 fragments in registers)
 // -> du1 rows to HBM + the dbeta1/dgamma1 sums;  dW2 += dy2^T z1 (both operands by transposed reads of the two images).
 template <int NP, int RT>
-__global__ __launch_bounds__(256, 2) void ec2s_bwd_kernel(
+__global__ __launch_bounds__(256, (NP == 3 && RT == 4) ? 1 : 2) void ec2s_bwd_kernel(
     const float *__restrict__ pq, const int32_t *__restrict__ idx, const float *__restrict__ w2,
     const float *__restrict__ gamma1, const float *__restrict__ beta1, const float *__restrict__ mean1,
     const float *__restrict__ invstd1, const float *__restrict__ gamma2, const float *__restrict__ mean2,
@@ -892,6 +914,7 @@ __global__ __launch_bounds__(256, 2) void ec2s_bwd_kernel(
     float *A2s = BcA + 2 * C2;                                     // [C2]             gamma2 * invstd2
     float *A1s = A2s + C2;                                         // [2][C1]          a1, b1
     float *HT = A1s + 2 * C1;                                      // [TP][C2][2]      (a2 h2, slot of the selected edge)
+    float *QS = HT + TP * C2 * 2;                                  // [2][TP][C1]      Q rows of the tile's points (double buffer)
 
     const int b = blockIdx.x, G = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -911,13 +934,6 @@ __global__ __launch_bounds__(256, 2) void ec2s_bwd_kernel(
         const float a = gamma1[tid] * invstd1[tid];
         A1s[tid] = a;
         A1s[C1 + tid] = beta1[tid] - mean1[tid] * a;
-    }
-    float a1[8], b1[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int c = chunk * 8 + j;
-        a1[j] = gamma1[c] * invstd1[c];
-        b1[j] = beta1[c] - mean1[c] * a1[j];
     }
     // W2 fragments: wfa = rows c2 of the wave's layer-2 tile, eight consecutive c1 (A operand of y2^T = W2 z1^T);
     //               wfb = columns c1 of the wave's layer-1 tile, eight consecutive c2 (B operand of dz1 = dy2 W2)
@@ -940,7 +956,7 @@ __global__ __launch_bounds__(256, 2) void ec2s_bwd_kernel(
     }
     int prow[RT];      // point of an item's row within the tile (gather mapping), the same for every tile
 #pragma unroll
-    for (int it = 0; it < RT; ++it) prow[it] = (irow + 32 * it) / k;
+    for (int it = 0; it < RT; ++it) prow[it] = min((irow + 32 * it) / k, TP - 1);   // rows behind the tile: any valid row
     int pmf[RT / 2], smf[RT / 2];   // point and slot of row rt * 32 + ql (lanes = rows in the dy2 epilogue)
 #pragma unroll
     for (int pi = 0; pi < RT / 2; ++pi) {
@@ -966,17 +982,19 @@ __global__ __launch_bounds__(256, 2) void ec2s_bwd_kernel(
         }
     };
     auto load_rows = [&](int tile, const int (&j)[RT], TileRows<RT> &t) {
-        const int i0 = tile * TP;
-#pragma unroll
+    #pragma unroll
         for (int it = 0; it < RT; ++it) {
             const bool ok = j[it] >= 0;
             const unsigned po = (unsigned)j[it] * (unsigned)(ld * 4) + chunk * 32u;
-            const unsigned qo = (unsigned)(i0 + prow[it]) * (unsigned)(ld * 4) + C1 * 4u + chunk * 32u;
             t.p[it][0] = rows_pq.load(ok, po);
             t.p[it][1] = rows_pq.load(ok, po + 16u);
-            t.q[it][0] = rows_pq.load(ok, qo);
-            t.q[it][1] = rows_pq.load(ok, qo + 16u);
         }
+    };
+    // Q rows of a tile's points: one 16-byte piece per thread (TP <= 16), prefetched two tiles ahead and parked in QS
+    auto load_q = [&](int tile) {
+        const int p = tid >> 4, i = tile * TP + p;
+        const bool ok = tile < ntiles && p < TP && i < N;
+        return rows_pq.load(ok, (unsigned)i * (unsigned)(ld * 4) + C1 * 4u + (tid & 15) * 16u);
     };
     // h2 / arg2 of the tile's points: one (point, channel) per thread while TP <= 4 (prefetched), a loop otherwise
     const bool ht_reg = TP <= 4;
@@ -995,19 +1013,29 @@ __global__ __launch_bounds__(256, 2) void ec2s_bwd_kernel(
     load_rows(blockIdx.y, jc, cur);
     load_idx(blockIdx.y + G, jn);
     if (ht_reg) load_ht(blockIdx.y);
-    __syncthreads();   // the constant tables
+    if (tid < TP * 16) *reinterpret_cast<float4 *>(QS + tid * 4) = load_q(blockIdx.y);
+    float4 qn = load_q(blockIdx.y + G);
+    __syncthreads();   // the constant tables and the first tile's Q rows
 
-    for (int tile = blockIdx.y; tile < ntiles; tile += G) {
+    int par = 0;       // parity of the tile within this workgroup: its Q rows are in QS[par]
+    for (int tile = blockIdx.y; tile < ntiles; tile += G, par ^= 1) {
         const int i0 = tile * TP;
         const int pvalid = min(TP, N - i0);   // valid points of this tile
         const int rvalid = pvalid * k;        // valid rows
         // ---- phase 1: y1 -> Y1 (fp32), z1 = LeakyReLU(BN1(y1)) -> pieces -> Z; rows beyond the tile: zeros
+        const float4 *ab = reinterpret_cast<const float4 *>(A1s + chunk * 8);
+        const float4 a1l = ab[0], a1h = ab[1], b1l = ab[C1 / 4], b1h = ab[C1 / 4 + 1];
+        const float a1[8] = {a1l.x, a1l.y, a1l.z, a1l.w, a1h.x, a1h.y, a1h.z, a1h.w};
+        const float b1[8] = {b1l.x, b1l.y, b1l.z, b1l.w, b1h.x, b1h.y, b1h.z, b1h.w};
 #pragma unroll
         for (int it = 0; it < RT; ++it) {
             const bool ok = jc[it] >= 0;
-            const float y[8] = {cur.p[it][0].x + cur.q[it][0].x, cur.p[it][0].y + cur.q[it][0].y, cur.p[it][0].z + cur.q[it][0].z,
-                                cur.p[it][0].w + cur.q[it][0].w, cur.p[it][1].x + cur.q[it][1].x, cur.p[it][1].y + cur.q[it][1].y,
-                                cur.p[it][1].z + cur.q[it][1].z, cur.p[it][1].w + cur.q[it][1].w};
+            const float4 *qs = reinterpret_cast<const float4 *>(QS + (par * TP + prow[it]) * C1 + chunk * 8);
+            const float4 q0 = qs[0], q1 = qs[1];
+            float y[8] = {cur.p[it][0].x + q0.x, cur.p[it][0].y + q0.y, cur.p[it][0].z + q0.z, cur.p[it][0].w + q0.w,
+                          cur.p[it][1].x + q1.x, cur.p[it][1].y + q1.y, cur.p[it][1].z + q1.z, cur.p[it][1].w + q1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = ok ? y[j] : 0.f;      // rows beyond the tile: zeros
             float z[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) z[j] = ok ? lrelu(__builtin_fmaf(y[j], a1[j], b1[j]), slope) : 0.f;
@@ -1018,7 +1046,7 @@ __global__ __launch_bounds__(256, 2) void ec2s_bwd_kernel(
 #pragma unroll
             for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x4 *>(Z + q * PB + off) = pc[q];
             float4 *yd = reinterpret_cast<float4 *>(Y1 + row * LDY + chunk * 8);
-            yd[0] = float4{y[0], y[1], y[2], y[3]};      // rows beyond the tile: 0 + 0
+            yd[0] = float4{y[0], y[1], y[2], y[3]};
             yd[1] = float4{y[4], y[5], y[6], y[7]};
         }
         if (ht_reg) {
@@ -1039,6 +1067,8 @@ __global__ __launch_bounds__(256, 2) void ec2s_bwd_kernel(
         load_rows(tile + G, jc, cur);      // behind the last tile: every index is -1, the loads touch nothing
         load_idx(tile + 2 * G, jn);
         if (ht_reg) load_ht(tile + G);
+        if (tid < TP * 16) *reinterpret_cast<float4 *>(QS + ((par ^ 1) * TP * C1) + tid * 4) = qn;   // the next tile's Q rows
+        qn = load_q(tile + 2 * G);
 
         // ---- phase 2 + 3: y2^T = W2 z1^T; lanes = edge rows; dy2 = Bc y2 + A (+ a2 h2 on the selected edge) -> D
 #pragma unroll
@@ -1197,6 +1227,7 @@ static void ec2s_tiling(int k, int B, int N, bool bwd, int &RT, int &TP, int &G)
     if (rt_env == 2 || rt_env == 4) RT = rt_env;
     TP = RT == 4 ? tp4 : tp2;
     if (TP < 1) TP = 1;
+    if (TP > 16) TP = 16;      // the kernels stage a tile's Q rows with one 16-byte piece per thread
     const int ntiles = (N + TP - 1) / TP;
     const int wgs = bwd ? (bwd_wgs > 0 ? bwd_wgs : 512) : (fwd_wgs > 0 ? fwd_wgs : 768);
     G = wgs / (B > 0 ? B : 1);
@@ -1204,9 +1235,12 @@ static void ec2s_tiling(int k, int B, int N, bool bwd, int &RT, int &TP, int &G)
     if (G > ntiles) G = ntiles;
 }
 
-static size_t ec2s_fwd_lds(int NP, int RT) { return (size_t)NP * RT * 32 * 128 + sizeof(float) * ((size_t)RT * 32 * 65 + 3 * 4 * 64); }
+static size_t ec2s_fwd_lds(int NP, int RT, int TP) {
+    return (size_t)NP * RT * 32 * 128 + sizeof(float) * ((size_t)RT * 32 * 65 + 3 * 4 * 64 + 2 * C1 + 2 * (size_t)TP * C1);
+}
 static size_t ec2s_bwd_lds(int NP, int RT, int TP) {
-    return (size_t)2 * NP * RT * 32 * 128 + sizeof(float) * ((size_t)RT * 32 * (C1 + 4) + 2 * 64 + 64 + 2 * C1 + (size_t)TP * 64 * 2);
+    return (size_t)2 * NP * RT * 32 * 128 +
+           sizeof(float) * ((size_t)RT * 32 * (C1 + 4) + 2 * 64 + 64 + 2 * C1 + (size_t)TP * 64 * 2 + 2 * (size_t)TP * C1);
 }
 
 static void ec2_tiling(int k, int C2, int &TP, int &Rpad, int &G, int B, int N) {
@@ -1299,7 +1333,7 @@ static int ec2_fwd_impl(bool bf16, const float *pq, const int32_t *idx, const fl
             }                                                                                                            \
             granted = true;                                                                                              \
         }                                                                                                                \
-        hipLaunchKernelGGL((ec2s_fwd_kernel<NPX, RTX>), dim3(B, G), dim3(256), ec2s_fwd_lds(NPX, RTX), st, pq, idx, w2,    \
+        hipLaunchKernelGGL((ec2s_fwd_kernel<NPX, RTX>), dim3(B, G), dim3(256), ec2s_fwd_lds(NPX, RTX, TPs), st, pq, idx, w2,    \
                            gamma1, beta1, mean1, invstd1, gamma2, N, k, TPs, training, slope, ysel2, arg2, ssum2, part2); \
     } while (0)
     if (ec2_split(C2)) {
