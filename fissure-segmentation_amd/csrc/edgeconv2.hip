@@ -1133,17 +1133,22 @@ __global__ __launch_bounds__(256, (NP == 3 && RT == 4) ? 1 : 2) void ec2s_bwd_ke
             const int c1 = ctw * 32 + ql;
             const float a1c = A1s[c1], b1c = A1s[C1 + c1], mu1 = mean1[c1], r1 = invstd1[c1];
             float sb = 0.f, sg = 0.f;
+            // the tile's du1 rows as a buffer resource of exactly rvalid rows: rows behind it (dy2 = 0, so du1 = 0 and nothing is
+            // added to the sums) fall outside and are dropped by the hardware -- sixteen unconditional stores, no branches, and a
+            // store count the compiler can subtract when it waits for the prefetched gathers
+            const uintptr_t da = reinterpret_cast<uintptr_t>(du1 + (((long)b * N + i0) * k) * C1);
+            const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)da), dhi = __builtin_amdgcn_readfirstlane((unsigned)(da >> 32));
+            const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<void *>(((uintptr_t)dhi << 32) | dlo), 0, __builtin_amdgcn_readfirstlane(rvalid * C1 * 4), 0x00020000);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                if (row < rvalid) {
-                    const float y1 = Y1[row * LDY + c1];
-                    const float u1 = __builtin_fmaf(y1, a1c, b1c);
-                    const float du = acc[e] * (u1 > 0.f ? 1.f : slope);
-                    du1[(((long)b * N + i0) * k + row) * C1 + c1] = du;
-                    sb += du;
-                    sg = __builtin_fmaf(du, (y1 - mu1) * r1, sg);
-                }
+                const float y1 = Y1[row * LDY + c1];
+                const float u1 = __builtin_fmaf(y1, a1c, b1c);
+                const float du = acc[e] * (u1 > 0.f ? 1.f : slope);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, du), drs, (unsigned)(row * C1 + c1) * 4u, 0, 0);
+                sb += du;
+                sg = __builtin_fmaf(du, (y1 - mu1) * r1, sg);
             }
             sb_acc += sb;
             sg_acc += sg;
