@@ -1558,7 +1558,7 @@ extern "C" int fsg_pw_linear_f32(const float *A, int64_t lda, const void *image,
 
 // ---- generic members of the family behind the fused DGCNN head (functional.py composes them; include/fsg_hip.h documents
 //      every argument).  Tile codes: 1 = 128 x 128, 2 = 64 x 128, 3 = 64 x 64, 4 = 128 x 64 (rows x columns of C).
-extern "C" int fsg_pw_tile_rows(int tile) { return (tile == 1 || tile == 4) ? 128 : 64; }
+extern "C" int fsg_pw_tile_rows(int tile) { return (tile == 1 || tile == 4) ? 128 : 64; }     // tiles 2, 3, 5, 6: 64 rows
 
 static int check_rowgemm(const fsg_pw_rowgemm_args *a, int pro, int epi, int BM) {
     FSG_REQUIRE(a && a->A1 && a->Bimg, "fsg_pw_rowgemm_f32: NULL pointer");
@@ -1599,7 +1599,7 @@ static RowGemmArgs to_kernel_args(const fsg_pw_rowgemm_args *a) {
 }
 
 extern "C" int fsg_pw_rowgemm_f32(const fsg_pw_rowgemm_args *a, int pro, int epi, int tile, fsg_stream_t stream) {
-    FSG_REQUIRE(tile >= 1 && tile <= 4, "fsg_pw_rowgemm_f32: tile %d not in 1..4", tile);
+    FSG_REQUIRE(tile >= 1 && tile <= 6, "fsg_pw_rowgemm_f32: tile %d not in 1..6", tile);
     const int rc = check_rowgemm(a, pro, epi, fsg_pw_tile_rows(tile));
     if (rc != FSG_OK) return rc;
     const RowGemmArgs k = to_kernel_args(a);
@@ -1633,6 +1633,10 @@ extern "C" int fsg_pw_rowgemm_f32(const fsg_pw_rowgemm_args *a, int pro, int epi
         PW_CASE(PRO_BNBWD, PW_STORE | PW_BIAS, 3, 1, 1);
         PW_CASE(PRO_BNBWD, PW_STORE | PW_BIAS, 4, 2, 1);
         PW_CASE(PRO_BNBWD, PW_STORE, 3, 1, 1);
+        // whole-width tiles (64 x 192, 64 x 256): the prologue + split of an A row is done once instead of once per column tile
+        PW_CASE(PRO_BNBWD, PW_STORE | PW_BIAS, 5, 1, 3);
+        PW_CASE(PRO_BNACT, PW_STORE | PW_STATS, 6, 1, 4);
+        PW_CASE(PRO_BNBWD, PW_STORE | PW_BWDSTATS, 6, 1, 4);
         default: break;
     }
 #undef PW_CASE

@@ -1200,7 +1200,7 @@ class _SegHead(torch.autograd.Function):
         R1 = M // 64
         y1 = torch.empty(M, C1, **f32)
         rec1 = torch.empty(R1, 3, C1, **f32)
-        pw_rowgemm(PRO_BNACT, PW_STORE | PW_STATS, 2, A1=y0, lda1=C0, K1=C0, K2=0, Bimg=img1, M=M, N=C1, rows_per_cloud=Npts,
+        pw_rowgemm(PRO_BNACT, PW_STORE | PW_STATS, 6 if (_PW_WIDE and C1 == 256) else 2, A1=y0, lda1=C0, K1=C0, K2=0, Bimg=img1, M=M, N=C1, rows_per_cloud=Npts,
                    alpha=al_0, delta=de_0, tstride=C0, slope=slope, C=y1, ldc=C1, store_n0=0, rec=rec1)
         mean_1, inv_1, al_1, de_1, _, _ = _pw_bn_finalize(rec1, R1, C1, 0, C1, None, B, bn_1, tr_1, mom_1)
         y2 = torch.empty(M, C2, **f32)
@@ -1263,7 +1263,7 @@ class _SegHead(torch.autograd.Function):
         R1 = M // 64
         da1 = torch.empty(M, C1, **f32)
         r1b = torch.empty(R1, 2, C1, **f32)
-        pw_rowgemm(PRO_BNBWD, PW_STORE | PW_BWDSTATS, 2, A1=da2, Y1=y2, lda1=C2, K1=C2, K2=0, Bimg=img2t, M=M,
+        pw_rowgemm(PRO_BNBWD, PW_STORE | PW_BWDSTATS, 6 if (_PW_WIDE and C1 == 256) else 2, A1=da2, Y1=y2, lda1=C2, K1=C2, K2=0, Bimg=img2t, M=M,
                    N=C1, rows_per_cloud=Npts, alpha=al_2, delta=de_2, P=P2, Q=Q2, tstride=0, slope=slope, C=da1, ldc=C1,
                    store_n0=0, Yp=y1, ldyp=C1, ealpha=al_1, edelta=de_1, emu=mean_1, er=inv_1, etstride=0, rec2=r1b)
         db1, dg1, P1, Q1, _ = bwd_fin(r1b, R1, C1, tr_1, al_1, inv_1, mean_1, False)
@@ -1274,7 +1274,7 @@ class _SegHead(torch.autograd.Function):
               rows_per_slice=_TN_RPS)
         da0 = torch.empty(M, C0, **f32)
         r0b = torch.empty(R1, 2, C0, **f32)
-        pw_rowgemm(PRO_BNBWD, PW_STORE | PW_BWDSTATS, 2, A1=da1, Y1=y1, lda1=C1, K1=C1, K2=0, Bimg=img1t, M=M,
+        pw_rowgemm(PRO_BNBWD, PW_STORE | PW_BWDSTATS, 6 if (_PW_WIDE and C0 == 256) else 2, A1=da1, Y1=y1, lda1=C1, K1=C1, K2=0, Bimg=img1t, M=M,
                    N=C0, rows_per_cloud=Npts, alpha=al_1, delta=de_1, P=P1, Q=Q1, tstride=0, slope=slope, C=da0, ldc=C0,
                    store_n0=0, Yp=y0, ldyp=C0, ealpha=al_0, edelta=de_0, emu=emu_0, er=inv_0, etstride=C0, rec2=r0b)
         db0, dg0, P0, Q0, dc = bwd_fin(r0b, R1, C0, tr_0, al_0, inv_0, emu_0, True, cm=cm_0, want_dc=True)
@@ -1302,7 +1302,7 @@ class _SegHead(torch.autograd.Function):
               M=M, rows_per_cloud=Npts, rows_per_slice=_TN_RPS)
         pw_tn_reduce(folds)             # dW3, dW2, dW1, [dW0_levels ; G]
         dlv = torch.empty(M, KL, **f32)
-        pw_rowgemm(PRO_BNBWD, PW_STORE | PW_BIAS, 4, A1=da0, Y1=y0, A2=levels, lda1=C0, lda2=levels.stride(0), K1=C0, K2=KL,
+        pw_rowgemm(PRO_BNBWD, PW_STORE | PW_BIAS, 5 if (_PW_WIDE and KL == 192) else 4, A1=da0, Y1=y0, A2=levels, lda1=C0, lda2=levels.stride(0), K1=C0, K2=KL,
                    Bimg=img_lv, M=M, N=KL, rows_per_cloud=Npts, alpha=al_0, delta=de_0, P=P0, Q=Q0, tstride=C0, slope=slope,
                    C=dlv, ldc=KL, store_n0=0, bias=npvec)
         sws = torch.empty(_lib.lib.fsg_pw_scatter_rows_workspace_bytes(B, CG) // 4, dtype=torch.int32, device=dev)
@@ -1315,6 +1315,7 @@ class _SegHead(torch.autograd.Function):
 
 _fused_head = _os.environ.get("FSG_FUSED_HEAD", "1") != "0"
 _TN_RPS = int(_os.environ.get("FSG_TN_RPS", "256"))     # rows per slice of the weight-gradient contractions (tuning knob)
+_PW_WIDE = _os.environ.get("FSG_PW_WIDE", "1") != "0"   # whole-width tiles (64 x 192 / 64 x 256) where the product is that narrow
 
 
 def set_fused_head(flag):
