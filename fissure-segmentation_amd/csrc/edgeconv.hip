@@ -414,11 +414,17 @@ __global__ __launch_bounds__(256) void ec1_apply_kernel(const float *__restrict_
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = cg * 64 + lane;
     const float g = gamma[c] * invstd[c], sh = beta[c] - mean[c] * g;
-    for (int p = wave; p < 64; p += 4) {
-        const int i = i0 + p;
+    // the wave's sixteen rows are requested together (a load inside the bounds check of every iteration was one dependent
+    // round trip per row: the whole 9 us of this kernel)
+    float yv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) yv[u] = ysel[((long)b * N + min(i0 + wave + 4 * u, N - 1)) * Co + c];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int p = wave + 4 * u, i = i0 + p;
         float v = 0.f;
         if (i < N) {
-            v = lrelu(__builtin_fmaf(ysel[((long)b * N + i) * Co + c], g, sh), slope);
+            v = lrelu(__builtin_fmaf(yv[u], g, sh), slope);
             if (out_pm) out_pm[((long)b * N + i) * Co + c] = v;
         }
         tile[lane][p] = v;
@@ -460,11 +466,15 @@ __global__ __launch_bounds__(256) void ec1_apply_prep_kernel(const float *__rest
         for (int u = 0; u < 16; ++u) ssum += sv[u];
         red[wave][lane] = ssum;
     }
-    for (int p = wave; p < 64; p += 4) {
-        const int i = i0 + p;
+    float yv[16];      // the wave's sixteen rows, requested together (see ec1_apply_kernel)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) yv[u] = ysel[((long)b * N + min(i0 + wave + 4 * u, N - 1)) * Co + c];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int p = wave + 4 * u, i = i0 + p;
         float v = 0.f;
         if (i < N) {
-            v = lrelu(__builtin_fmaf(ysel[((long)b * N + i) * Co + c], g, sh), slope);
+            v = lrelu(__builtin_fmaf(yv[u], g, sh), slope);
             out_pm[((long)b * N + i) * Co + c] = v;
         }
         tile[lane][p] = v;
@@ -552,32 +562,30 @@ __global__ __launch_bounds__(256) void ec1_bwd_point_kernel(const float *__restr
     float sb = 0.f, sg = 0.f;
     // four rows per round with all their loads issued first (a loop that breaks at the cloud's end is one dependent round
     // trip per row: 16 in a row were the whole 12 us of this kernel); the sums keep the row order
-    for (int p0 = wave; p0 < 64; p0 += 16) {
-        float ys[4], g1[4], g2[4];
+    float ys[16], g1[16], g2[16];      // the wave's sixteen rows of every operand, requested together
 #pragma unroll
-        for (int u4 = 0; u4 < 4; ++u4) {
-            const int i = i0 + p0 + 4 * u4;
-            const bool ok = i < N;
-            const long row = (long)b * N + (ok ? i : i0);
-            ys[u4] = ysel[row * Co + c];
-            g1[u4] = gout_pm ? gout_pm[row * ld_pm + c] : 0.f;
-            g2[u4] = gout_pm2 ? gout_pm2[row * ld_pm2 + c] : 0.f;
-        }
+    for (int q = 0; q < 16; ++q) {
+        const int i = i0 + wave + 16 * (q >> 2) + 4 * (q & 3);
+        const bool ok = i < N;
+        const long row = (long)b * N + (ok ? i : i0);
+        ys[q] = ysel[row * Co + c];
+        g1[q] = gout_pm ? gout_pm[row * ld_pm + c] : 0.f;
+        g2[q] = gout_pm2 ? gout_pm2[row * ld_pm2 + c] : 0.f;
+    }
 #pragma unroll
-        for (int u4 = 0; u4 < 4; ++u4) {
-            const int p = p0 + 4 * u4, i = i0 + p;
-            if (i < N) {
-                const long o = ((long)b * N + i) * Co + c;
-                const float yhat = (ys[u4] - mu) * r;
-                const float u = __builtin_fmaf(ga, yhat, be);
-                float gv = tile[lane][p];
-                if (gout_pm) gv += g1[u4];
-                if (gout_pm2) gv += g2[u4];
-                const float hv = gv * (u > 0.f ? 1.f : slope);
-                h[o] = hv;
-                sb += hv;
-                sg = __builtin_fmaf(hv, yhat, sg);
-            }
+    for (int q = 0; q < 16; ++q) {      // same row order as the loads: the sums keep their association
+        const int p = wave + 16 * (q >> 2) + 4 * (q & 3), i = i0 + p;
+        if (i < N) {
+            const long o = ((long)b * N + i) * Co + c;
+            const float yhat = (ys[q] - mu) * r;
+            const float u = __builtin_fmaf(ga, yhat, be);
+            float gv = tile[lane][p];
+            if (gout_pm) gv += g1[q];
+            if (gout_pm2) gv += g2[q];
+            const float hv = gv * (u > 0.f ? 1.f : slope);
+            h[o] = hv;
+            sb += hv;
+            sg = __builtin_fmaf(hv, yhat, sg);
         }
     }
     red[0][wave][lane] = sb;

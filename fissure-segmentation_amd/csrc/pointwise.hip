@@ -1115,7 +1115,8 @@ __global__ __launch_bounds__(256) void pw_logits_bwd_kernel(const float *__restr
 //   dbeta = sum_b h,  dgamma = sum_b h yhat_sel,  Q = alpha r dgamma / M,  P = alpha (dbeta / M - mean r dgamma / M),
 //   coef[b] = alpha h[b]   (weight of the selected row arg[b] in dy)
 constexpr int GP_MAXB = 8;
-__global__ __launch_bounds__(256) void pw_gf_prep_kernel(const float *__restrict__ dc, const float *__restrict__ W0g, long ldw0,
+constexpr int GP_WAVES = 16;     // waves per workgroup: each walks every 16th row of W0g, all its loads in flight at once
+__global__ __launch_bounds__(64 * GP_WAVES) void pw_gf_prep_kernel(const float *__restrict__ dc, const float *__restrict__ W0g, long ldw0,
                                                          int C0, const float *__restrict__ gfeat, float *__restrict__ dW0g,
                                                          long lddw0, const float *__restrict__ dg_in,
                                                          const float *__restrict__ ysel,
@@ -1126,16 +1127,26 @@ __global__ __launch_bounds__(256) void pw_gf_prep_kernel(const float *__restrict
                                                          float *__restrict__ P, float *__restrict__ Q, float *__restrict__ coef,
                                                          const float *__restrict__ Wgl, long ldwgl, int KL,
                                                          float *__restrict__ Wq, long ldwq) {
-    extern __shared__ float dcs[];     // (B, C0) when dc is given, then [4][GP_MAXB][64] partial dg
+    extern __shared__ float dcs[];     // (B, C0) when dc is given, then [GP_WAVES][GP_MAXB][64] partial dg
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = min(blockIdx.x * 64 + lane, C - 1);       // 64 channels per workgroup, the four waves split k
     const bool livec = blockIdx.x * 64 + lane < C;
     float dgv[GP_MAXB];
 #pragma unroll
     for (int b = 0; b < GP_MAXB; ++b) dgv[b] = 0.f;
+    // what the first wave needs after the contraction is requested now (one memory round trip less at the end)
+    float al = 0.f, de = 0.f, mu = 0.f, r = 0.f, ysv[GP_MAXB];
+#pragma unroll
+    for (int b = 0; b < GP_MAXB; ++b) ysv[b] = 0.f;
+    if (wave == 0) {
+        al = alpha[c]; de = delta[c]; mu = mean[c]; r = invstd[c];
+#pragma unroll
+        for (int b = 0; b < GP_MAXB; ++b)
+            if (b < B) ysv[b] = ysel[(long)b * C + c];
+    }
     if (dc) {
         float *pd = dcs + B * C0;
-        for (int e = threadIdx.x; e < B * C0; e += 256) dcs[e] = dc[e];
+        for (int e = threadIdx.x; e < B * C0; e += 64 * GP_WAVES) dcs[e] = dc[e];
         __syncthreads();
         float gv[GP_MAXB];
 #pragma unroll
@@ -1143,30 +1154,41 @@ __global__ __launch_bounds__(256) void pw_gf_prep_kernel(const float *__restrict
         (void)gv;
         (void)dW0g;
         (void)lddw0;
-#pragma unroll 8
-        for (int k = wave; k < C0; k += 4) {                // loads and FMAs only: eight rows of W0g in flight per thread
-            const float w = W0g[(long)k * ldw0 + c];
+        // sixteen rows of W0g per round, every load issued before the first fma (with four waves and eight rows in flight the
+        // kernel was eight dependent round trips long: 16.8 us)
+        for (int k0 = wave; k0 < C0; k0 += 16 * GP_WAVES) {
+            float w[16];
 #pragma unroll
-            for (int b = 0; b < GP_MAXB; ++b) dgv[b] = __builtin_fmaf(b < B ? dcs[b * C0 + k] : 0.f, w, dgv[b]);
+            for (int u = 0; u < 16; ++u) w[u] = W0g[(long)min(k0 + u * GP_WAVES, C0 - 1) * ldw0 + c];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int k = k0 + u * GP_WAVES;
+                if (k < C0) {
+#pragma unroll
+                    for (int b = 0; b < GP_MAXB; ++b) dgv[b] = __builtin_fmaf(b < B ? dcs[b * C0 + k] : 0.f, w[u], dgv[b]);
+                }
+            }
         }
 #pragma unroll
         for (int b = 0; b < GP_MAXB; ++b) pd[(wave * GP_MAXB + b) * 64 + lane] = dgv[b];
         __syncthreads();
 #pragma unroll
-        for (int b = 0; b < GP_MAXB; ++b)
-            dgv[b] = (pd[(0 * GP_MAXB + b) * 64 + lane] + pd[(1 * GP_MAXB + b) * 64 + lane]) +
-                     (pd[(2 * GP_MAXB + b) * 64 + lane] + pd[(3 * GP_MAXB + b) * 64 + lane]);
+        for (int b = 0; b < GP_MAXB; ++b) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < GP_WAVES; ++q) t += pd[(q * GP_MAXB + b) * 64 + lane];     // wave order: fixed
+            dgv[b] = t;
+        }
     } else {
 #pragma unroll
         for (int b = 0; b < GP_MAXB; ++b) dgv[b] = b < B ? dg_in[(long)b * C + c] : 0.f;
     }
     if (wave == 0 && livec) {
-        const float al = alpha[c], de = delta[c], mu = mean[c], r = invstd[c];
         float sb = 0.f, sg = 0.f;
 #pragma unroll
         for (int b = 0; b < GP_MAXB; ++b)
             if (b < B) {
-                const float ys = ysel[(long)b * C + c], u = __builtin_fmaf(ys, al, de);
+                const float ys = ysv[b], u = __builtin_fmaf(ys, al, de);
                 const float h = dgv[b] * (u > 0.f ? 1.f : slope);
                 coef[(long)b * C + c] = al * h;
                 sb += h;
@@ -1558,7 +1580,7 @@ extern "C" int fsg_pw_linear_f32(const float *A, int64_t lda, const void *image,
 
 // ---- generic members of the family behind the fused DGCNN head (functional.py composes them; include/fsg_hip.h documents
 //      every argument).  Tile codes: 1 = 128 x 128, 2 = 64 x 128, 3 = 64 x 64, 4 = 128 x 64 (rows x columns of C).
-extern "C" int fsg_pw_tile_rows(int tile) { return (tile == 1 || tile == 4) ? 128 : 64; }     // tiles 2, 3, 5, 6: 64 rows
+extern "C" int fsg_pw_tile_rows(int tile) { return (tile == 1 || tile == 4) ? 128 : 64; }     // tiles 2, 3, 5: 64 rows
 
 static int check_rowgemm(const fsg_pw_rowgemm_args *a, int pro, int epi, int BM) {
     FSG_REQUIRE(a && a->A1 && a->Bimg, "fsg_pw_rowgemm_f32: NULL pointer");
@@ -1599,7 +1621,7 @@ static RowGemmArgs to_kernel_args(const fsg_pw_rowgemm_args *a) {
 }
 
 extern "C" int fsg_pw_rowgemm_f32(const fsg_pw_rowgemm_args *a, int pro, int epi, int tile, fsg_stream_t stream) {
-    FSG_REQUIRE(tile >= 1 && tile <= 6, "fsg_pw_rowgemm_f32: tile %d not in 1..6", tile);
+    FSG_REQUIRE(tile >= 1 && tile <= 5, "fsg_pw_rowgemm_f32: tile %d not in 1..5", tile);
     const int rc = check_rowgemm(a, pro, epi, fsg_pw_tile_rows(tile));
     if (rc != FSG_OK) return rc;
     const RowGemmArgs k = to_kernel_args(a);
@@ -1633,10 +1655,9 @@ extern "C" int fsg_pw_rowgemm_f32(const fsg_pw_rowgemm_args *a, int pro, int epi
         PW_CASE(PRO_BNBWD, PW_STORE | PW_BIAS, 3, 1, 1);
         PW_CASE(PRO_BNBWD, PW_STORE | PW_BIAS, 4, 2, 1);
         PW_CASE(PRO_BNBWD, PW_STORE, 3, 1, 1);
-        // whole-width tiles (64 x 192, 64 x 256): the prologue + split of an A row is done once instead of once per column tile
+        // whole-width tile 64 x 192: the prologue + split of an A row is done once instead of once per column tile (a 64 x 256
+        // tile for the 256-wide products holds one workgroup per CU and was slower: 24.9 vs 20.7 us)
         PW_CASE(PRO_BNBWD, PW_STORE | PW_BIAS, 5, 1, 3);
-        PW_CASE(PRO_BNACT, PW_STORE | PW_STATS, 6, 1, 4);
-        PW_CASE(PRO_BNBWD, PW_STORE | PW_BWDSTATS, 6, 1, 4);
         default: break;
     }
 #undef PW_CASE
@@ -1801,7 +1822,7 @@ extern "C" int fsg_pw_gf_prep_f32(const float *dc, const float *W0g, int64_t ldw
                 "fsg_pw_gf_prep_f32: bad arguments (B <= %d)", GP_MAXB);
     FSG_REQUIRE((dc && W0g && gfeat && dW0g && C0 > 0 && (size_t)B * C0 * 4 <= 32 * 1024) || (!dc && dg),
                 "fsg_pw_gf_prep_f32: either dc + W0g + gfeat + dW0g (B C0 <= 8192) or dg");
-    hipLaunchKernelGGL(pw_gf_prep_kernel, dim3((C + 63) / 64), dim3(256), dc ? sizeof(float) * (B * C0 + 4 * GP_MAXB * 64) : 0, (hipStream_t)stream, dc,
+    hipLaunchKernelGGL(pw_gf_prep_kernel, dim3((C + 63) / 64), dim3(64 * GP_WAVES), dc ? sizeof(float) * (B * C0 + GP_WAVES * GP_MAXB * 64) : 0, (hipStream_t)stream, dc,
                        W0g, (long)ldw0, C0, gfeat, dW0g, (long)lddw0, dg, ysel, alpha, delta, mean, invstd, B, C, (long)M, training,
                        slope, dbeta, dgamma, P, Q, coef, W, (long)ldw, K, Wq, (long)ldwq);
     FSG_CHECK_LAUNCH("fsg_pw_gf_prep_f32");

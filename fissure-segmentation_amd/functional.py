@@ -1200,7 +1200,7 @@ class _SegHead(torch.autograd.Function):
         R1 = M // 64
         y1 = torch.empty(M, C1, **f32)
         rec1 = torch.empty(R1, 3, C1, **f32)
-        pw_rowgemm(PRO_BNACT, PW_STORE | PW_STATS, 6 if (_PW_WIDE and C1 == 256) else 2, A1=y0, lda1=C0, K1=C0, K2=0, Bimg=img1, M=M, N=C1, rows_per_cloud=Npts,
+        pw_rowgemm(PRO_BNACT, PW_STORE | PW_STATS, 2, A1=y0, lda1=C0, K1=C0, K2=0, Bimg=img1, M=M, N=C1, rows_per_cloud=Npts,
                    alpha=al_0, delta=de_0, tstride=C0, slope=slope, C=y1, ldc=C1, store_n0=0, rec=rec1)
         mean_1, inv_1, al_1, de_1, _, _ = _pw_bn_finalize(rec1, R1, C1, 0, C1, None, B, bn_1, tr_1, mom_1)
         y2 = torch.empty(M, C2, **f32)
@@ -1263,7 +1263,7 @@ class _SegHead(torch.autograd.Function):
         R1 = M // 64
         da1 = torch.empty(M, C1, **f32)
         r1b = torch.empty(R1, 2, C1, **f32)
-        pw_rowgemm(PRO_BNBWD, PW_STORE | PW_BWDSTATS, 6 if (_PW_WIDE and C1 == 256) else 2, A1=da2, Y1=y2, lda1=C2, K1=C2, K2=0, Bimg=img2t, M=M,
+        pw_rowgemm(PRO_BNBWD, PW_STORE | PW_BWDSTATS, 2, A1=da2, Y1=y2, lda1=C2, K1=C2, K2=0, Bimg=img2t, M=M,
                    N=C1, rows_per_cloud=Npts, alpha=al_2, delta=de_2, P=P2, Q=Q2, tstride=0, slope=slope, C=da1, ldc=C1,
                    store_n0=0, Yp=y1, ldyp=C1, ealpha=al_1, edelta=de_1, emu=mean_1, er=inv_1, etstride=0, rec2=r1b)
         db1, dg1, P1, Q1, _ = bwd_fin(r1b, R1, C1, tr_1, al_1, inv_1, mean_1, False)
@@ -1274,7 +1274,7 @@ class _SegHead(torch.autograd.Function):
               rows_per_slice=_TN_RPS)
         da0 = torch.empty(M, C0, **f32)
         r0b = torch.empty(R1, 2, C0, **f32)
-        pw_rowgemm(PRO_BNBWD, PW_STORE | PW_BWDSTATS, 6 if (_PW_WIDE and C0 == 256) else 2, A1=da1, Y1=y1, lda1=C1, K1=C1, K2=0, Bimg=img1t, M=M,
+        pw_rowgemm(PRO_BNBWD, PW_STORE | PW_BWDSTATS, 2, A1=da1, Y1=y1, lda1=C1, K1=C1, K2=0, Bimg=img1t, M=M,
                    N=C0, rows_per_cloud=Npts, alpha=al_1, delta=de_1, P=P1, Q=Q1, tstride=0, slope=slope, C=da0, ldc=C0,
                    store_n0=0, Yp=y0, ldyp=C0, ealpha=al_0, edelta=de_0, emu=emu_0, er=inv_0, etstride=C0, rec2=r0b)
         db0, dg0, P0, Q0, dc = bwd_fin(r0b, R1, C0, tr_0, al_0, inv_0, emu_0, True, cm=cm_0, want_dc=True)
@@ -1315,7 +1315,10 @@ class _SegHead(torch.autograd.Function):
 
 _fused_head = _os.environ.get("FSG_FUSED_HEAD", "1") != "0"
 _TN_RPS = int(_os.environ.get("FSG_TN_RPS", "256"))     # rows per slice of the weight-gradient contractions (tuning knob)
-_PW_WIDE = _os.environ.get("FSG_PW_WIDE", "1") != "0"   # whole-width tiles (64 x 192 / 64 x 256) where the product is that narrow
+# the 64 x 192 tile for the (B N, 448) x (448, 192) input-gradient product of the first head layer: its BatchNorm-backward
+# prologue + split is then done once per row instead of once per column tile (38.8 -> 33.1 us).  The 64 x 256 tile for the
+# 256-wide products was measured SLOWER (24.9 vs 20.7 us, 25.5 vs 21.3 us: 120 KB of LDS = one workgroup per CU)
+_PW_WIDE = _os.environ.get("FSG_PW_WIDE", "1") != "0"
 
 
 def set_fused_head(flag):

@@ -205,8 +205,10 @@ int fsg_edgeconv2_bwd_f32(const float *grad_out, const float *grad_out_pm, int64
                           float *grad_gamma2, float *grad_beta2, void *workspace, fsg_stream_t stream);
 /* bf16 operand mode of the same two entry points (same arguments, every tensor fp32): the per-edge 64 x C2 contraction
  * of the forward and the three per-tile products of the backward (y2 recompute, dz1 = dy2 W2, dW2 += dy2^T z1) run on
- * v_mfma_f32_32x32x16_bf16 -- operands rounded to bf16 on their way out of LDS, fp32 accumulation; gathers, BatchNorm
- * statistics, selection and all stored tensors are unchanged.  The graph (idx) is always built in fp32. */
+ * v_mfma_f32_32x32x16_bf16 -- operands rounded to bf16 (once, on their way INTO the LDS operand image at C2 = 64; at every
+ * fragment read at C2 = 128), fp32 accumulation; gathers, BatchNorm statistics, selection and all stored tensors are
+ * unchanged.  The graph (idx) is always built in fp32.  (The fp32 entry points run the same kernels at C2 = 64 with three
+ * bf16 pieces per operand and six products -- fp32-grade, see fsg_pw_* below; v_mfma_f32_32x32x2_f32 at C2 = 128.) */
 int fsg_edgeconv2_fwd_bf16(const float *pq, const int32_t *idx, const float *w2, const float *gamma1,
                            const float *beta1, float *running_mean1, float *running_var1, const float *gamma2,
                            const float *beta2, float *running_mean2, float *running_var2, int B, int N, int k, int C2,
@@ -508,7 +510,7 @@ int fsg_pw_linear_bf16(const float *A, int64_t lda, const void *image, const flo
 
 /*
  * The members of the family behind the fused DGCNN head (`functional.seg_head`; models/dgcnn.py:123-162 of the reference).
- * Tile codes: 1 = 128 x 128, 2 = 64 x 128, 3 = 64 x 64, 4 = 128 x 64 (rows x columns of C); fsg_pw_tile_rows(tile) = rows.
+ * Tile codes: 1 = 128 x 128, 2 = 64 x 128, 3 = 64 x 64, 4 = 128 x 64, 5 = 64 x 192 (rows x columns of C; 5 only with the BatchNorm-backward prologue + bias epilogue); fsg_pw_tile_rows(tile) = rows.
  *
  * fsg_pw_rowgemm_f32:  C (M, N) = pro(A) (M, K1 + K2) . B,  B given as a weight image with (K1 + K2) / 16 k-steps.
  *   prologue `pro` on segment 1 of A (segment 2 is always plain):
