@@ -276,40 +276,52 @@ __global__ __launch_bounds__(512) void ec1_stats_select_kernel(const float *__re
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 4 * TPW waves, 4 points each
     const int c = cg * 64 + lane;
     const int ld = 2 * Co;
-    const float *P = pq + (long)b * N * ld;
-    const float *Q = P + Co;
+    const RowGather rows_pq(pq + (long)b * N * ld, (long)N * ld * 4);   // [P | Q] rows of this cloud
     const float sgn = gamma[c] >= 0.f ? 1.f : -1.f;
     float shift = 0.f, s1 = 0.f, s2 = 0.f, cnt = 0.f;
     bool first = true;
+    // One coalesced load brings a point's k neighbour ids into the wave; each id is broadcast with v_readlane into the SCALAR
+    // offset of a buffer load (no 64-bit address arithmetic on the vector unit: it was a third of this kernel's instructions)
+    // and the P-row gathers go out eight at a time; the ids and the Q row of the NEXT point are requested before the current
+    // point's gathers, so a point costs the latency of its gather rounds only.
+    const int ibase = tile * TP * TPW + wave * (TP / 4);
+    int myj = 0;
+    float q = 0.f;
+    if (ibase < N) {
+        myj = lane < k ? idx[((long)b * N + ibase) * k + lane] : 0;
+        q = rows_pq.load(true, ibase, ld, Co + c);
+    }
     for (int t = 0; t < TP / 4; ++t) {
-        const int i = tile * TP * TPW + wave * (TP / 4) + t;
-        if (i >= N) continue;
-        // one coalesced load brings the point's k neighbour ids into the wave; each id is then broadcast with
-        // v_readlane and the P-row gathers are issued four at a time (independent loads hide the L2 latency)
-        const int myj = lane < k ? idx[((long)b * N + i) * k + lane] : 0;
-        const float q = Q[(long)i * ld + c];
+        const int i = ibase + t;
+        if (i >= N) break;
+        const int myj_c = myj;
+        const float q_c = q;
+        if (t + 1 < TP / 4 && i + 1 < N) {
+            myj = lane < k ? idx[((long)b * N + i + 1) * k + lane] : 0;
+            q = rows_pq.load(true, i + 1, ld, Co + c);
+        }
         float best = -INFINITY, tot = 0.f;
         int barg = 0;
-        for (int s0 = 0; s0 < k; s0 += 4) {
-            float y[4];
+        for (int s0 = 0; s0 < k; s0 += 8) {
+            float y[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int s = min(s0 + u, k - 1);
-                const int j = __builtin_amdgcn_readlane(myj, s);
-                y[u] = P[(long)j * ld + c];
+            for (int u = 0; u < 8; ++u) {
+                const int j = __builtin_amdgcn_readlane(myj_c, min(s0 + u, k - 1));
+                y[u] = rows_pq.load(true, j, ld, c);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (s0 + u >= k) break;
-                const float yy = y[u] + q;
-                tot += yy;
-                const float v = sgn * yy;
-                if (v > best) { best = v; barg = s0 + u; }
-                if (training) {
-                    if (first) { shift = yy; first = false; }
-                    const float d = yy - shift;
-                    s1 += d;
-                    s2 = __builtin_fmaf(d, d, s2);
+            for (int u = 0; u < 8; ++u) {
+                if (s0 + u < k) {
+                    const float yy = y[u] + q_c;
+                    tot += yy;
+                    const float v = sgn * yy;
+                    if (v > best) { best = v; barg = s0 + u; }
+                    if (training) {
+                        if (first) { shift = yy; first = false; }
+                        const float d = yy - shift;
+                        s1 += d;
+                        s2 = __builtin_fmaf(d, d, s2);
+                    }
                 }
             }
         }
@@ -685,6 +697,7 @@ int fsg_ec_stats1_records(int B, int N) { return B * fsg_cdiv(N, TP * TPW); }
 
 int fsg_ec_stats1_launch(const float *pq, const int32_t *idx, const float *gamma, int B, int N, int k, int Co,
                          float *ysel, uint8_t *arg, float *ssum, float *partials, hipStream_t st) {
+    FSG_REQUIRE((long)N * 2 * Co * 4 < (1L << 31), "edgeconv/stats: a cloud's [P | Q] rows must stay below 2 GiB (N=%d, Co=%d)", N, Co);
     hipLaunchKernelGGL(ec1_stats_select_kernel, dim3(B, fsg_cdiv(N, TP * TPW), Co / 64), dim3(256 * TPW), 0, st, pq, idx,
                        gamma, N, k, Co, 1, ysel, arg, ssum, partials);
     FSG_CHECK_LAUNCH("edgeconv/stats");
@@ -886,6 +899,7 @@ extern "C" int fsg_edgeconv1_fwd_f32(const float *pq, const int32_t *idx, const 
     FSG_REQUIRE(B > 0 && N > 0 && k > 0 && k <= 64 && Co > 0 && Co % 64 == 0 && B <= 65535,
                 "fsg_edgeconv1_fwd_f32: bad shape B=%d N=%d k=%d Co=%d (Co must be a multiple of 64)", B, N, k, Co);
     FSG_REQUIRE(!training || workspace, "fsg_edgeconv1_fwd_f32: training needs the workspace");
+    FSG_REQUIRE((long)N * 2 * Co * 4 < (1L << 31), "fsg_edgeconv1_fwd_f32: a cloud's [P | Q] rows must stay below 2 GiB (N=%d, Co=%d)", N, Co);
     hipStream_t st = (hipStream_t)stream;
     const int tiles = fsg_cdiv(N, TP * TPW);
     hipLaunchKernelGGL(ec1_stats_select_kernel, dim3(B, tiles, Co / 64), dim3(256 * TPW), 0, st, pq, idx, gamma, N, k, Co,

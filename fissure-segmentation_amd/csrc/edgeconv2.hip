@@ -42,28 +42,6 @@ constexpr int MAXPAIR = 3;      // output tiles per wave
 
 __device__ __forceinline__ float lrelu(float u, float slope) { return u > 0.f ? u : u * slope; }
 
-// Row gathers with lanes = channels: the row index is wave-uniform (v_readlane of the neighbour list), so the row offset
-// belongs in the SCALAR offset of a buffer load and the lane's channel in its vector offset -- no per-load 64-bit address
-// arithmetic on the VALU (the plain-pointer form cost ~5 VALU issues per load, 160 of the ~330 of the gather phase), and a
-// row outside the tile is simply an offset outside the resource (reads 0).
-struct RowGather {
-    __amdgpu_buffer_rsrc_t rs;
-    unsigned oob;   // a byte offset outside the resource
-    __device__ __forceinline__ RowGather(const float *base, long bytes) {
-        const uintptr_t a = reinterpret_cast<uintptr_t>(base);
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-        const int n = __builtin_amdgcn_readfirstlane((int)bytes);
-        rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), 0, n, 0x00020000);
-        oob = (unsigned)n;
-    }
-    // element `col` (per lane) of row `row` (uniform) of a matrix with `ld` floats per row; !ok -> 0
-    __device__ __forceinline__ float load(bool ok, int row, int ld, int col) const {
-        const unsigned so = ok ? (unsigned)row * (unsigned)(ld * 4) : oob;
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)col * 4u,
-                                                                             __builtin_amdgcn_readfirstlane(so), 0));
-    }
-};
-
 struct Tile {
     int TP, R, Rpad;
 };
