@@ -1037,10 +1037,14 @@ def test_edgeconv1_fused_vs_unfused(fsg, device, B, C, Np, k, Co, train):
 
 
 @pytest.mark.parametrize("B,C,Np,k,C2,train", [(2, 3, 300, 20, 64, True), (1, 15, 77, 7, 64, True), (2, 3, 130, 40, 128, True),
-                                               (3, 6, 513, 16, 64, False), (8, 3, 2048, 20, 64, True)])
+                                               (3, 6, 513, 16, 64, False), (8, 3, 2048, 20, 64, True), (2, 3, 100, 3, 64, True),
+                                               (2, 3, 257, 30, 64, True), (1, 3, 90, 64, 64, True)])
 def test_edgeconv2_fused_vs_unfused(fsg, device, B, C, Np, k, C2, train):
     """csrc/edgeconv2.hip (two-layer fused EdgeConv, MFMA) against the unfused composition
-    [fsg_edge_gather -> (Conv2d -> BatchNorm2d -> LeakyReLU) x 2 -> max]."""
+    [fsg_edge_gather -> (Conv2d -> BatchNorm2d -> LeakyReLU) x 2 -> max].  The C2 = 64 cases run the split-image kernels:
+    k = 20 / 7 / 16 -> 64-row tiles of 3 / 9 / 4 points (9 > 4: the per-point table of the backward is filled by its loop
+    form), k = 3 -> the 16-point cap of a tile, k = 30 -> 128-row tiles (4 points), k = 64 -> one point per 64-row tile; ragged
+    last tiles everywhere.  C2 = 128: the fp32-MFMA kernels."""
     from fissure_segmentation_amd.norm import BatchNorm2d
     torch.manual_seed(C + C2)
     conv1 = torch.nn.Conv2d(2 * C, 64, 1, bias=False).to(device)
