@@ -1197,7 +1197,7 @@ static bool ec2_split(int C2) {
 
 // tiles of the split kernels: RT * 32 edge rows = TP points; 128 rows when that cuts the padding by more than 15 % (k = 40:
 // 40 of 64 rows against 120 of 128), 64 rows otherwise; `wgs` workgroups over the B clouds
-static void ec2s_tiling(int k, int B, int N, bool bwd, int &RT, int &TP, int &G) {
+static void ec2s_tiling(int k, int B, int N, bool bwd, bool bf16, int &RT, int &TP, int &G) {
     static int rt_env = -1, fwd_wgs = -1, bwd_wgs = -1;
     if (rt_env < 0) {
         rt_env = ec2_env_int("FSG_EC2S_RT");
@@ -1207,6 +1207,9 @@ static void ec2s_tiling(int k, int B, int N, bool bwd, int &RT, int &TP, int &G)
     const int tp2 = 64 / k, tp4 = 128 / k;
     const float u2 = tp2 * k / 64.f, u4 = tp4 * k / 128.f;
     RT = u4 > 1.15f * u2 ? 4 : 2;
+    // the forward with three pieces per operand: 128-row tiles hold one workgroup per CU (82 KB of LDS) and lose more than the
+    // padding costs (k = 40, 32 x 2048: 472 vs 545 us); the backward and the one-piece kernels keep the rule above
+    if (!bwd && !bf16) RT = 2;
     if (rt_env == 2 || rt_env == 4) RT = rt_env;
     TP = RT == 4 ? tp4 : tp2;
     if (TP < 1) TP = 1;
@@ -1247,7 +1250,8 @@ extern "C" size_t fsg_edgeconv2_workspace_bytes(int B, int N, int k, int C2) {
     ec2_tiling(k, C2, TP, Rpad, G, B, N);
     if (ec2_split(C2)) {
         int RT, TPs, Gs;
-        ec2s_tiling(k, B, N, false, RT, TPs, Gs);
+        ec2s_tiling(k, B, N, false, false, RT, TPs, Gs);   // (sizes: the larger of the fp32 / bf16 grids)
+        { int RTb, TPb, Gb; ec2s_tiling(k, B, N, false, true, RTb, TPb, Gb); if (Gb > Gs) Gs = Gb; }
         if (Gs > G) G = Gs;
     }
     const size_t rec1 = (size_t)fsg_ec_stats1_records(B, N) * 3 * C1 + fsg_ec_finalize_stage_floats(C1);
@@ -1275,7 +1279,7 @@ static int ec2_fwd_impl(bool bf16, const float *pq, const int32_t *idx, const fl
     ec2_tiling(k, C2, TP, Rpad, G, B, N);
     int RTs = 0, TPs = 0, Gs = 0, Gws = G;     // Gws: the record count the workspace layout is sized for
     if (ec2_split(C2)) {
-        ec2s_tiling(k, B, N, false, RTs, TPs, Gs);
+        ec2s_tiling(k, B, N, false, bf16, RTs, TPs, Gs);
         if (Gs > Gws) Gws = Gs;
     }
     const int rec1 = fsg_ec_stats1_records(B, N);
@@ -1388,7 +1392,7 @@ extern "C" size_t fsg_edgeconv2_bwd_workspace_bytes(int B, int N, int k, int C2)
     ec2_bwd_tiling(k, C2, TP, Rpad, G, B, N);
     if (ec2_split(C2)) {
         int RT, TPs, Gs;
-        ec2s_tiling(k, B, N, true, RT, TPs, Gs);
+        ec2s_tiling(k, B, N, true, false, RT, TPs, Gs);
         if (Gs > G) G = Gs;
     }
     const size_t point_rec = (size_t)B * fsg_cdiv(N, 64) * 2 * C2;       // ec1_bwd_point partials
@@ -1419,7 +1423,7 @@ static int ec2_bwd_impl(bool bf16, const float *grad_out, const float *grad_out_
     ec2_bwd_tiling(k, C2, TP, Rpad, G, B, N);
     int RTs = 0, TPs = 0, Gs = 0, Gws = G;     // Gws: the record count the workspace layout is sized for
     if (ec2_split(C2)) {
-        ec2s_tiling(k, B, N, true, RTs, TPs, Gs);
+        ec2s_tiling(k, B, N, true, bf16, RTs, TPs, Gs);
         if (Gs > Gws) Gws = Gs;
     }
     float *point_part = (float *)workspace;
