@@ -1114,8 +1114,10 @@ __global__ __launch_bounds__(256) void pw_logits_bwd_kernel(const float *__restr
 // then, with h[b] = dg[b] f'(alpha ysel[b] + delta):
 //   dbeta = sum_b h,  dgamma = sum_b h yhat_sel,  Q = alpha r dgamma / M,  P = alpha (dbeta / M - mean r dgamma / M),
 //   coef[b] = alpha h[b]   (weight of the selected row arg[b] in dy)
-constexpr int GP_MAXB = 8;
-constexpr int GP_WAVES = 16;     // waves per workgroup: each walks every 16th row of W0g, all its loads in flight at once
+// <clouds a thread carries, waves per workgroup>: <8, 16> up to 8 clouds per rank (each wave walks every 16th row of W0g, all
+// its loads in flight at once), <32, 4> up to 32 (the reference's experiment scripts train with 32 clouds per GPU): the
+// per-wave partial table [waves][clouds][64] must fit LDS next to the (B, C0) block of dc
+template <int GP_MAXB, int GP_WAVES>
 __global__ __launch_bounds__(64 * GP_WAVES) void pw_gf_prep_kernel(const float *__restrict__ dc, const float *__restrict__ W0g, long ldw0,
                                                          int C0, const float *__restrict__ gfeat, float *__restrict__ dW0g,
                                                          long lddw0, const float *__restrict__ dg_in,
@@ -1205,6 +1207,7 @@ __global__ __launch_bounds__(64 * GP_WAVES) void pw_gf_prep_kernel(const float *
 }
 
 // dW0g[k, j] = sum_b dc[b, k] g[b, j]  (C0 x CG outputs, B terms each): thread = column j, eight rows k per workgroup row
+template <int GP_MAXB>
 __global__ __launch_bounds__(256) void pw_outer_kernel(const float *__restrict__ dc, const float *__restrict__ g, int B, int C0,
                                                        int CG, float *__restrict__ out, long ldo, const float *__restrict__ Q,
                                                        const float *__restrict__ P, const float *__restrict__ Wgl, long ldwgl,
@@ -1818,19 +1821,26 @@ extern "C" int fsg_pw_gf_prep_f32(const float *dc, const float *W0g, int64_t ldw
                                   float *dbeta, float *dgamma, float *P, float *Q, float *coef, const float *W, int64_t ldw, int K,
                                   float *Wq, int64_t ldwq, fsg_stream_t stream) {
     FSG_REQUIRE(!Wq || (W && K > 0 && ldwq >= K + 1 && dc), "fsg_pw_gf_prep_f32: Wq needs W, K, ldwq >= K + 1 and the dc form");
-    FSG_REQUIRE(ysel && alpha && delta && mean && invstd && dbeta && dgamma && P && Q && coef && B > 0 && B <= GP_MAXB && C > 0 && M > 0,
-                "fsg_pw_gf_prep_f32: bad arguments (B <= %d)", GP_MAXB);
+    FSG_REQUIRE(ysel && alpha && delta && mean && invstd && dbeta && dgamma && P && Q && coef && B > 0 && B <= 32 && C > 0 && M > 0,
+                "fsg_pw_gf_prep_f32: bad arguments (B <= 32)");
     FSG_REQUIRE((dc && W0g && gfeat && dW0g && C0 > 0 && (size_t)B * C0 * 4 <= 32 * 1024) || (!dc && dg),
                 "fsg_pw_gf_prep_f32: either dc + W0g + gfeat + dW0g (B C0 <= 8192) or dg");
-    hipLaunchKernelGGL(pw_gf_prep_kernel, dim3((C + 63) / 64), dim3(64 * GP_WAVES), dc ? sizeof(float) * (B * C0 + GP_WAVES * GP_MAXB * 64) : 0, (hipStream_t)stream, dc,
-                       W0g, (long)ldw0, C0, gfeat, dW0g, (long)lddw0, dg, ysel, alpha, delta, mean, invstd, B, C, (long)M, training,
-                       slope, dbeta, dgamma, P, Q, coef, W, (long)ldw, K, Wq, (long)ldwq);
-    FSG_CHECK_LAUNCH("fsg_pw_gf_prep_f32");
-    if (dc) {
-        hipLaunchKernelGGL(pw_outer_kernel, dim3((C + 255) / 256, (C0 + 7) / 8), dim3(256), 0, (hipStream_t)stream, dc, gfeat, B, C0, C,
-                           dW0g, (long)lddw0, Q, P, W, (long)ldw, K, Wq, (long)ldwq);
-        FSG_CHECK_LAUNCH("fsg_pw_gf_prep_f32/outer");
-    }
+#define FSG_GF_PREP(MAXB, WAVES)                                                                                                     \
+    do {                                                                                                                         \
+        hipLaunchKernelGGL((pw_gf_prep_kernel<MAXB, WAVES>), dim3((C + 63) / 64), dim3(64 * WAVES),                                \
+                           dc ? sizeof(float) * (B * C0 + WAVES * MAXB * 64) : 0, (hipStream_t)stream, dc, W0g, (long)ldw0, C0, gfeat, \
+                           dW0g, (long)lddw0, dg, ysel, alpha, delta, mean, invstd, B, C, (long)M, training, slope, dbeta, dgamma,  \
+                           P, Q, coef, W, (long)ldw, K, Wq, (long)ldwq);                                                           \
+        FSG_CHECK_LAUNCH("fsg_pw_gf_prep_f32");                                                                                    \
+        if (dc) {                                                                                                                \
+            hipLaunchKernelGGL((pw_outer_kernel<MAXB>), dim3((C + 255) / 256, (C0 + 7) / 8), dim3(256), 0, (hipStream_t)stream, dc, \
+                               gfeat, B, C0, C, dW0g, (long)lddw0, Q, P, W, (long)ldw, K, Wq, (long)ldwq);                         \
+            FSG_CHECK_LAUNCH("fsg_pw_gf_prep_f32/outer");                                                                          \
+        }                                                                                                                        \
+    } while (0)
+    if (B <= 8) FSG_GF_PREP(8, 16);
+    else FSG_GF_PREP(32, 4);
+#undef FSG_GF_PREP
     return FSG_OK;
 }
 

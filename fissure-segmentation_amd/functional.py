@@ -1330,7 +1330,8 @@ def set_fused_head(flag):
 
 
 def seg_head_supported(levels, B, Npts, Wg, W0, W1, W2, W3):
-    """the fused head needs: fp32 GPU rows, clouds of a multiple of 256 points, channel counts on the 32 / 64 grid"""
+    """the fused head needs: fp32 GPU rows, clouds of a multiple of 256 points, channel counts on the 32 / 64 grid, at most 32
+    clouds per rank (the reference's experiment scripts train with 32)"""
     if not _fused_head:     # (bf16 operand mode keeps the fused head: its products are fp32-grade, above what the mode asks for)
         return False
     KL = levels.shape[1]
@@ -1338,7 +1339,7 @@ def seg_head_supported(levels, B, Npts, Wg, W0, W1, W2, W3):
             Npts % 256 == 0 and levels.shape[0] == B * Npts and KL % 64 == 0 and Wg.shape[0] % 128 == 0 and
             W0.shape[0] % 64 == 0 and W0.shape[1] == KL + Wg.shape[0] and W1.shape[0] % 64 == 0 and W1.shape[1] == W0.shape[0] and
             W2.shape[0] % 64 == 0 and W2.shape[1] == W1.shape[0] and W3.shape[1] == W2.shape[0] and W3.shape[0] <= 8 and
-            W2.shape[0] % 32 == 0 and Wg.shape[0] <= 4096 and B <= 8)
+            W2.shape[0] % 32 == 0 and Wg.shape[0] <= 4096 and B <= 32 and B * W0.shape[0] <= 8192)
 
 
 def seg_head(levels, B, Npts, global_block, seg_blocks):

@@ -636,7 +636,7 @@ int fsg_pw_logits_bwd_f32(const float *g, int classes, const float *W3, const fl
  *   dX = selected rows - 1 (W^T P)^T - X (W^T diag(Q) W),   dW = selected rows - P s^T - diag(Q) W G.
  * fsg_pw_gf_prep_f32: per channel dbeta, dgamma, P, Q and coef (B, C) = weight of the selected row in dy.  The gradient of the
  *   global feature is either given (dg (B, C), dc == NULL) or formed here from the gradient dc (B, C0) of the first head layer's
- *   per-cloud constant: dg = dc W0g (W0g (C0, C), row stride ldw0), together with dW0g (C0, C) = dc^T gfeat (B <= 8).
+ *   per-cloud constant: dg = dc W0g (W0g (C0, C), row stride ldw0), together with dW0g (C0, C) = dc^T gfeat (B <= 32).
  *   Wq != NULL: also the rows [Q[c] W[c, :] | -P[c]] (C, K + 1) with row stride ldwq -- the left operand of the row contraction
  *   [M1 ; npvec] = [Q o W | -P]^T W (fsg_pw_tn_f32 over the C channel rows).
  * fsg_pw_scatter_rows_f32: dX[b Npts + arg[b,c], :] += coef[b,c] W[c, :], summed per destination row in channel order

@@ -2488,7 +2488,7 @@ def _head_reference_fp64(levels, B, Npts, P, slope, train, eps=1e-5):
     return y @ P["W3"].t() + P["b3"]
 
 
-@pytest.mark.parametrize("B,Npts,train", [(8, 2048, True), (3, 256, True), (2, 512, False)])
+@pytest.mark.parametrize("B,Npts,train", [(8, 2048, True), (3, 256, True), (2, 512, False), (32, 256, True), (13, 1024, True)])
 def test_seg_head_fused_vs_fp64_and_unfused(fsg, device, B, Npts, train):
     """The fused DGCNN-seg head (functional.seg_head: csrc/pointwise.hip) against the same head in float64 torch ops and
     against the round-2 path (vendor GEMMs + fsg_bn_act stages): logits 1e-4 of their scale, gradients of the input rows and
