@@ -812,25 +812,34 @@ __global__ __launch_bounds__(256) void ec2s_fwd_kernel(const float *__restrict__
             float best = -INFINITY, tot = 0.f;
             int barg = 0;
             const float *yp = Y + p * k * LD2 + lane;
+            if (first) {                     // wave-uniform, once per wave: the shift of the BatchNorm-2 sums
+                shift = yp[0];
+                first = false;
+            }
+            float t1 = 0.f, t2 = 0.f;
+            // branch-free: selects instead of `if (v > best)` (the compiler turned that into a branch per row: with the row
+            // bound and the first-value test the loop ran ~290 cycles per row -- half of the kernel at k = 40)
             for (int s0 = 0; s0 < k; s0 += 8) {     // eight rows per round: the LDS reads are in flight together
                 float yv[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) yv[u] = yp[min(s0 + u, k - 1) * LD2];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    if (s0 + u < k) {
-                        const float y = yv[u];
-                        tot += y;
-                        const float v = sgn * y;
-                        if (v > best) { best = v; barg = s0 + u; }
-                        if (training) {
-                            if (first) { shift = y; first = false; }
-                            const float d = y - shift;
-                            s1 += d;
-                            s2 = __builtin_fmaf(d, d, s2);
-                        }
-                    }
+                    const bool in = s0 + u < k;       // wave-uniform
+                    const float y = yv[u];
+                    tot += in ? y : 0.f;
+                    const float v = in ? sgn * y : -INFINITY;
+                    const bool gt = v > best;
+                    best = gt ? v : best;
+                    barg = gt ? s0 + u : barg;
+                    const float d = in ? y - shift : 0.f;
+                    t1 += d;
+                    t2 = __builtin_fmaf(d, d, t2);
                 }
+            }
+            if (training) {
+                s1 += t1;
+                s2 += t2;
             }
             const long o = ((long)b * N + i) * C2 + lane;
             ysel[o] = sgn * best;
