@@ -25,7 +25,8 @@ constexpr int LPT = TI * TK / 256;                  // tile elements per thread 
 __global__ __launch_bounds__(256) void gemm_small_kernel(const float *__restrict__ A, long sai, long sak,
                                                          const float *__restrict__ B, long sbk, long sbj,
                                                          const float *__restrict__ bias, float *__restrict__ C, long ldc,
-                                                         int I, int J, int K, int kchunk, float *__restrict__ part) {
+                                                         int I, int J, int K, int kchunk, float *__restrict__ part,
+                                                         float *__restrict__ rowsum) {
     __shared__ float As[TK * LDT], Bs[TK * LDT];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, ql = lane & 31, half = lane >> 5;
     const int i0 = blockIdx.x * TI, j0 = blockIdx.y * TJ;
@@ -48,6 +49,11 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const float *__restrict
             bv[r] = (j0 + bj < J && k0 + bk < kend) ? B[(long)(k0 + bk) * sbk + (long)(j0 + bj) * sbj] : 0.f;
         }
     };
+    // optional by-product: rowsum[i] = sum_k A(i, k) -- with A = dY^T this is the bias gradient of the Linear whose weight
+    // gradient the product is (one ATen column reduction less per Linear).  The first column of workgroups sums its A tiles as
+    // they pass through LDS: thread i < 64 walks the tile's 32 k-rows of row i; k order is fixed, so it is reproducible.
+    const bool do_rs = rowsum != nullptr && blockIdx.y == 0 && tid < TI;
+    float rs = 0.f;
     if (kbeg < kend) fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += TK) {
         __syncthreads();  // previous tile consumed
@@ -61,10 +67,19 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const float *__restrict
         }
         __syncthreads();
         if (k0 + TK < kend) fetch(k0 + TK);
+        if (do_rs) {
+#pragma unroll
+            for (int kk = 0; kk < TK; ++kk) rs += As[kk * LDT + tid];     // rows / k beyond the matrix were staged as zeros
+        }
 #pragma unroll
         for (int s = 0; s < TK / 2; ++s)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(2 * s + half) * LDT + wi + ql], Bs[(2 * s + half) * LDT + wj + ql],
                                                        acc, 0, 0, 0);
+    }
+    if (do_rs && i0 + tid < I) {
+        // partial sums of the splits behind the partial products: [S][I] at part + S * I * J (gridDim.z = S)
+        if (part) part[(long)gridDim.z * I * J + (long)blockIdx.z * I + i0 + tid] = rs;
+        else rowsum[i0 + tid] = rs;
     }
     const int col = j0 + wj + ql;
     if (col >= J) return;
@@ -89,8 +104,13 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const float *__restrict
 // combined in slice order through LDS: fixed order, reproducible)
 __global__ __launch_bounds__(256) void gemm_small_reduce_flat_kernel(const float *__restrict__ part, int S, long IJ, int J,
                                                                      const float *__restrict__ bias, float *__restrict__ C,
-                                                                     long ldc) {
+                                                                     long ldc, int I, float *__restrict__ rowsum) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;   // few splits: one thread per output
+    if (rowsum && t >= IJ && t < IJ + I) {                 // the row sums' partials sit behind the products': [S][I]
+        float a = 0.f;
+        for (int s = 0; s < S; ++s) a += part[(long)S * IJ + (long)s * I + (t - IJ)];
+        rowsum[t - IJ] = a;
+    }
     if (t >= IJ) return;
     float a = 0.f;
     for (int s = 0; s < S; ++s) a += part[(long)s * IJ + t];
@@ -101,10 +121,26 @@ __global__ __launch_bounds__(256) void gemm_small_reduce_flat_kernel(const float
 
 __global__ __launch_bounds__(256) void gemm_small_reduce_kernel(const float *__restrict__ part, int S, long IJ, int J,
                                                                 const float *__restrict__ bias, float *__restrict__ C,
-                                                                long ldc) {
+                                                                long ldc, int I, float *__restrict__ rowsum) {
     __shared__ float red[16][17];
     const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const long t = (long)blockIdx.x * 16 + o;
+    const long nb = (IJ + 15) / 16;                        // workgroups of the products; the rest fold the row sums
+    if (rowsum && (long)blockIdx.x >= nb) {                // (their partials sit behind the products': [S][I])
+        const long ri = ((long)blockIdx.x - nb) * 16 + o;
+        float a = 0.f;
+        if (ri < I)
+            for (int s = sl; s < S; s += 16) a += part[(long)S * IJ + (long)s * I + ri];
+        red[sl][o] = a;
+        __syncthreads();
+        if (sl == 0 && ri < I) {
+            float r = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) r += red[i][o];
+            rowsum[ri] = r;
+        }
+        return;
+    }
     float a = 0.f;
     if (t < IJ)
         for (int s = sl; s < S; s += 16) a += part[(long)s * IJ + t];
@@ -138,12 +174,22 @@ inline int splits_for(int I, int J, int K) {
 extern "C" size_t fsg_gemm_small_workspace_bytes(int I, int J, int K) {
     if (I <= 0 || J <= 0 || K <= 0) return 0;
     const int s = splits_for(I, J, K);
-    return s > 1 ? sizeof(float) * (size_t)s * (size_t)I * (size_t)J : 0;
+    return s > 1 ? sizeof(float) * (size_t)s * ((size_t)I * (size_t)J + (size_t)I) : 0;      // products + row sums of every split
 }
+
+extern "C" int fsg_gemm_small_rowsum_f32(const float *A, int64_t sa_i, int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_j,
+                                         const float *bias, float *C, int64_t ldc, int I, int J, int K, float *rowsum,
+                                         void *workspace, fsg_stream_t stream);
 
 extern "C" int fsg_gemm_small_f32(const float *A, int64_t sa_i, int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_j,
                                   const float *bias, float *C, int64_t ldc, int I, int J, int K, void *workspace,
                                   fsg_stream_t stream) {
+    return fsg_gemm_small_rowsum_f32(A, sa_i, sa_k, B, sb_k, sb_j, bias, C, ldc, I, J, K, nullptr, workspace, stream);
+}
+
+extern "C" int fsg_gemm_small_rowsum_f32(const float *A, int64_t sa_i, int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_j,
+                                         const float *bias, float *C, int64_t ldc, int I, int J, int K, float *rowsum,
+                                         void *workspace, fsg_stream_t stream) {
     FSG_REQUIRE(A && B && C, "fsg_gemm_small_f32: NULL pointer");
     FSG_REQUIRE(I > 0 && J > 0 && K > 0 && ldc >= J, "fsg_gemm_small_f32: bad shape I=%d J=%d K=%d ldc=%ld", I, J, K, (long)ldc);
     FSG_REQUIRE(fsg_cdiv(J, TJ) <= 65535, "fsg_gemm_small_f32: J too large");
@@ -154,16 +200,16 @@ extern "C" int fsg_gemm_small_f32(const float *A, int64_t sa_i, int64_t sa_k, co
     const int S_eff = fsg_cdiv(K, kchunk);  // every split non-empty
     float *part = S_eff > 1 ? (float *)workspace : nullptr;
     hipLaunchKernelGGL(gemm_small_kernel, dim3(fsg_cdiv(I, TI), fsg_cdiv(J, TJ), S_eff), dim3(256), 0, st, A, (long)sa_i,
-                       (long)sa_k, B, (long)sb_k, (long)sb_j, bias, C, (long)ldc, I, J, K, kchunk, part);
+                       (long)sa_k, B, (long)sb_k, (long)sb_j, bias, C, (long)ldc, I, J, K, kchunk, part, rowsum);
     FSG_CHECK_LAUNCH("fsg_gemm_small_f32");
     if (part) {
-        const long IJ = (long)I * J;
+        const long IJ = (long)I * J, outs = IJ + (rowsum ? I : 0);
         if (S_eff >= 16)
-            hipLaunchKernelGGL(gemm_small_reduce_kernel, dim3(fsg_cdiv(IJ, 16)), dim3(256), 0, st, part, S_eff, IJ, J, bias, C,
-                               (long)ldc);
+            hipLaunchKernelGGL(gemm_small_reduce_kernel, dim3(fsg_cdiv(IJ, 16) + (rowsum ? fsg_cdiv(I, 16) : 0)), dim3(256), 0, st, part,
+                               S_eff, IJ, J, bias, C, (long)ldc, I, rowsum);
         else
-            hipLaunchKernelGGL(gemm_small_reduce_flat_kernel, dim3(fsg_cdiv(IJ, 256)), dim3(256), 0, st, part, S_eff, IJ, J,
-                               bias, C, (long)ldc);
+            hipLaunchKernelGGL(gemm_small_reduce_flat_kernel, dim3(fsg_cdiv(outs, 256)), dim3(256), 0, st, part, S_eff, IJ, J,
+                               bias, C, (long)ldc, I, rowsum);
         FSG_CHECK_LAUNCH("fsg_gemm_small_f32/reduce");
     }
     return FSG_OK;

@@ -244,14 +244,17 @@ def edge_features(x, idx):
 SMALL_GEMM_FLOPS = 6e8   # below this the vendor GEMM tends to pick one huge macro-tile (one workgroup): use fsg_gemm_small_f32
 
 
-def gemm_small(a, sa_i, sa_k, b, sb_k, sb_j, bias, I, J, K):
-    """C (I,J) = A(i,k) B(k,j) (+ bias[j]) with explicit element strides -- include/fsg_hip.h: fsg_gemm_small_f32."""
+def gemm_small(a, sa_i, sa_k, b, sb_k, sb_j, bias, I, J, K, rowsum=False):
+    """C (I,J) = A(i,k) B(k,j) (+ bias[j]) with explicit element strides -- include/fsg_hip.h: fsg_gemm_small_f32.
+    rowsum=True: also sum_k A(i,k) (fsg_gemm_small_rowsum_f32: the bias gradient next to a weight gradient) -> (C, rowsum)"""
     out = torch.empty(I, J, dtype=torch.float32, device=a.device)
     nbytes = _lib.lib.fsg_gemm_small_workspace_bytes(I, J, K)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=a.device) if nbytes else None
+    rs = torch.empty(I, dtype=torch.float32, device=a.device) if rowsum else None
     with torch.cuda.device(a.device):
-        _lib.call("fsg_gemm_small_f32", _p(a), sa_i, sa_k, _p(b), sb_k, sb_j, _p(bias), _p(out), J, I, J, K, _p(ws), _stream())
-    return out
+        _lib.call("fsg_gemm_small_rowsum_f32", _p(a), sa_i, sa_k, _p(b), sb_k, sb_j, _p(bias), _p(out), J, I, J, K, _p(rs), _p(ws),
+                  _stream())
+    return (out, rs) if rowsum else out
 
 
 def _small(I, J, K, *tensors):
@@ -314,9 +317,12 @@ class _LinearPM(torch.autograd.Function):
             return gx, gw, gb
         if ctx.needs_input_grad[0]:
             gx = _linear_dx(g2, w, bf16=ctx.bf16).view_as(x)
+        want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            gw = _linear_dw(g2, x2, bf16=ctx.bf16)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gw = _linear_dw(g2, x2, bf16=ctx.bf16, with_bias_grad=want_gb)
+            if isinstance(gw, tuple):      # the small-GEMM path hands the bias gradient (row sums of dY^T) over with the product
+                gw, gb = gw
+        if want_gb and gb is None:
             gb = _bias_grad(g2)
         return gx, gw, gb
 
@@ -333,15 +339,16 @@ def _linear_dx(g2, w, out=None, bf16=False):
     return gemm_small(g2, N, 1, w, K, 1, None, M, K, N) if _small(M, K, N, g2, w) else g2 @ w
 
 
-def _linear_dw(g2, x2, bf16=False):
-    """dW = dY^T X: a tiny output behind a long reduction (see _LinearPM)"""
+def _linear_dw(g2, x2, bf16=False, with_bias_grad=False):
+    """dW = dY^T X: a tiny output behind a long reduction (see _LinearPM).  with_bias_grad: the small-GEMM path returns
+    (dW, db) -- db = column sums of dY as a by-product of the same launch; the other paths return dW alone"""
     M, N = g2.shape
     K = x2.shape[1]
     if bf16:
         return _bf16_mm(g2.t(), x2)
     S = 16 if (M % 16 == 0 and M >= 4096) else 1
     if _small(N, K, M, g2, x2):
-        return gemm_small(g2, 1, N, x2, K, 1, None, N, K, M)
+        return gemm_small(g2, 1, N, x2, K, 1, None, N, K, M, rowsum=with_bias_grad)
     if S > 1 and x2.is_contiguous():
         return torch.bmm(g2.view(S, M // S, -1).transpose(1, 2), x2.view(S, M // S, -1)).sum(0)
     return g2.t() @ x2

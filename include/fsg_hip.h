@@ -363,6 +363,12 @@ size_t fsg_gemm_small_workspace_bytes(int I, int J, int K);
 int fsg_gemm_small_f32(const float *A, int64_t sa_i, int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_j,
                        const float *bias, float *C, int64_t ldc, int I, int J, int K, void *workspace,
                        fsg_stream_t stream);
+/* The same product with a by-product: rowsum[i] = sum_k A(i, k) (NULL: none).  With A = dY^T (the weight gradient
+ * dW = dY^T X of a Linear, models/pointtransformer/seg_model.py) that is the layer's bias gradient -- one launch instead of the
+ * product plus a column reduction.  Same workspace, same fixed summation order. */
+int fsg_gemm_small_rowsum_f32(const float *A, int64_t sa_i, int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_j,
+                              const float *bias, float *C, int64_t ldc, int I, int J, int K, float *rowsum, void *workspace,
+                              fsg_stream_t stream);
 
 /*
  * Fused PointTransformerLayer body: replaces models/pointtransformer/seg_model.py:38-53 after the three

@@ -496,6 +496,12 @@ def test_small_gemm(fsg, device, I, J, K, sa, sb):
     ref = (a if sa == "ik" else a.T).astype(np.float64) @ (b if sb == "kj" else b.T).astype(np.float64) + bias
     assert np.abs(N(c) - ref).max() <= 3e-7 * np.sqrt(K) * max(1.0, np.abs(ref).max())
     assert torch.equal(c, fsg.functional.gemm_small(*args, G(bias, device), I, J, K))
+    # the row-sum by-product (fsg_gemm_small_rowsum_f32: the bias gradient next to a weight gradient): same product, + sum_k A(i, k)
+    c2, rs = fsg.functional.gemm_small(*args, G(bias, device), I, J, K, rowsum=True)
+    assert torch.equal(c2, c)
+    rref = (a if sa == "ik" else a.T).astype(np.float64).sum(1)
+    assert np.abs(N(rs) - rref).max() <= 3e-7 * np.sqrt(K) * max(1.0, np.abs(rref).max()) + 1e-5
+    assert torch.equal(rs, fsg.functional.gemm_small(*args, G(bias, device), I, J, K, rowsum=True)[1])
 
 
 def test_linear_pm_routing_and_grads(fsg, device):
@@ -508,7 +514,8 @@ def test_linear_pm_routing_and_grads(fsg, device):
         fsg._lib.start_timing()
         y = fsg.functional.linear_pm(xt, wt, bt)
         y.backward(G(g.astype(np.float32), device))
-        assert len(fsg._lib.stop_timing().get("fsg_gemm_small_f32", [])) == n_small, (M, Nn, K)
+        timed = fsg._lib.stop_timing()
+        assert len(timed.get("fsg_gemm_small_f32", [])) + len(timed.get("fsg_gemm_small_rowsum_f32", [])) == n_small, (M, Nn, K)
         for got, ref in [(y, x @ w.T + b), (xt.grad, g @ w), (wt.grad, g.T @ x), (bt.grad, g.sum(0))]:
             assert np.abs(N(got) - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
 
