@@ -358,8 +358,8 @@ __global__ __launch_bounds__(256) void pw_rowgemm_kernel(const RowGemmArgs p) {
             const int nbl = (p.N + 31) / 32 - col0 / 32;      // 32-column blocks of the image at / behind this tile
     #pragma unroll
             for (int q = 0; q < BU; ++q) {
-                const int u = tid + 256 * q, jb = u / 384, rem = u - jb * 384;
-                rb[q] = jb < nbl ? bsrc[(long)jb * KS * 192 + rem] : u32x4{0u, 0u, 0u, 0u};
+                const int u = tid + 256 * q, jb = min(u / 384, nbl - 1), rem = u % 384;   // blocks behind N: any valid one (their columns are never stored) -- no branch per load
+                rb[q] = bsrc[(long)jb * KS * 192 + rem];
             }
         };
 
@@ -449,10 +449,18 @@ __global__ __launch_bounds__(256) void pw_rowgemm_kernel(const RowGemmArgs p) {
                 const int col = col0 + (wn * WN + j) * 32 + lc;
                 float bv = 0.f;                       // the bias is applied on the way out (PW_BIAS comes with PW_STORE only)
                 if constexpr ((EPI & PW_BIAS) != 0) bv = col < p.N ? p.bias[col] : 0.f;
+                if (row0 + BM <= p.M && col0 + BN <= p.N) {       // tile inside the matrix (workgroup-uniform): sixteen plain stores
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = row0 + (wm * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                    if (row < p.M && col < p.N) p.C[(long)row * p.ldc + (col - p.store_n0)] = acc[i][j][e] + bv;
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = row0 + (wm * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                        p.C[(long)row * p.ldc + (col - p.store_n0)] = acc[i][j][e] + bv;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = row0 + (wm * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                        if (row < p.M && col < p.N) p.C[(long)row * p.ldc + (col - p.store_n0)] = acc[i][j][e] + bv;
+                    }
                 }
             }
     }
