@@ -776,10 +776,18 @@ __global__ __launch_bounds__(256) void pw_tn_kernel(const TnArgs p) {
 #pragma unroll
         for (int j = 0; j < T2; ++j) {
             const int col = c2_0 + (w2 * T2 + j) * 32 + lc;
+            if (c1_0 + BT1 <= N1 && c2_0 + BT2 <= p.N2) {        // block inside the output (workgroup-uniform): plain stores
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = c1_0 + (w1 * T1 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                if (row < N1 && col < p.N2) out[(long)row * p.N2 + col] = acc[i][j][e];
+                for (int e = 0; e < 16; ++e) {
+                    const int row = c1_0 + (w1 * T1 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    out[(long)row * p.N2 + col] = acc[i][j][e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = c1_0 + (w1 * T1 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    if (row < N1 && col < p.N2) out[(long)row * p.N2 + col] = acc[i][j][e];
+                }
             }
         }
 }
@@ -1155,8 +1163,8 @@ __global__ __launch_bounds__(64 * GP_WAVES) void pw_gf_prep_kernel(const float *
             if (b < B) ysv[b] = ysel[(long)b * C + c];
     }
     if (dc) {
-        float *pd = dcs + B * C0;
-        for (int e = threadIdx.x; e < B * C0; e += 64 * GP_WAVES) dcs[e] = dc[e];
+        float *pd = dcs + GP_MAXB * C0;
+        for (int e = threadIdx.x; e < GP_MAXB * C0; e += 64 * GP_WAVES) dcs[e] = e < B * C0 ? dc[e] : 0.f;   // clouds behind B: zeros, no tests below
         __syncthreads();
         float gv[GP_MAXB];
 #pragma unroll
@@ -1172,11 +1180,10 @@ __global__ __launch_bounds__(64 * GP_WAVES) void pw_gf_prep_kernel(const float *
             for (int u = 0; u < 16; ++u) w[u] = W0g[(long)min(k0 + u * GP_WAVES, C0 - 1) * ldw0 + c];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                const int k = k0 + u * GP_WAVES;
-                if (k < C0) {
+                const int k = k0 + u * GP_WAVES, kc = min(k, C0 - 1);
+                const float wz = k < C0 ? w[u] : 0.f;              // rows behind C0 contribute zero: a select, not a branch
 #pragma unroll
-                    for (int b = 0; b < GP_MAXB; ++b) dgv[b] = __builtin_fmaf(b < B ? dcs[b * C0 + k] : 0.f, w[u], dgv[b]);
-                }
+                for (int b = 0; b < GP_MAXB; ++b) dgv[b] = __builtin_fmaf(dcs[b * C0 + kc], wz, dgv[b]);
             }
         }
 #pragma unroll
@@ -1831,12 +1838,12 @@ extern "C" int fsg_pw_gf_prep_f32(const float *dc, const float *W0g, int64_t ldw
     FSG_REQUIRE(!Wq || (W && K > 0 && ldwq >= K + 1 && dc), "fsg_pw_gf_prep_f32: Wq needs W, K, ldwq >= K + 1 and the dc form");
     FSG_REQUIRE(ysel && alpha && delta && mean && invstd && dbeta && dgamma && P && Q && coef && B > 0 && B <= 32 && C > 0 && M > 0,
                 "fsg_pw_gf_prep_f32: bad arguments (B <= 32)");
-    FSG_REQUIRE((dc && W0g && gfeat && dW0g && C0 > 0 && (size_t)B * C0 * 4 <= 32 * 1024) || (!dc && dg),
-                "fsg_pw_gf_prep_f32: either dc + W0g + gfeat + dW0g (B C0 <= 8192) or dg");
+    FSG_REQUIRE((dc && W0g && gfeat && dW0g && C0 > 0 && (size_t)(B <= 8 ? 8 : 32) * C0 * 4 <= 32 * 1024) || (!dc && dg),
+                "fsg_pw_gf_prep_f32: either dc + W0g + gfeat + dW0g (C0 <= 1024 up to 8 clouds, <= 256 up to 32) or dg");
 #define FSG_GF_PREP(MAXB, WAVES)                                                                                                     \
     do {                                                                                                                         \
         hipLaunchKernelGGL((pw_gf_prep_kernel<MAXB, WAVES>), dim3((C + 63) / 64), dim3(64 * WAVES),                                \
-                           dc ? sizeof(float) * (B * C0 + WAVES * MAXB * 64) : 0, (hipStream_t)stream, dc, W0g, (long)ldw0, C0, gfeat, \
+                           dc ? sizeof(float) * (MAXB * C0 + WAVES * MAXB * 64) : 0, (hipStream_t)stream, dc, W0g, (long)ldw0, C0, gfeat, \
                            dW0g, (long)lddw0, dg, ysel, alpha, delta, mean, invstd, B, C, (long)M, training, slope, dbeta, dgamma,  \
                            P, Q, coef, W, (long)ldw, K, Wq, (long)ldwq);                                                           \
         FSG_CHECK_LAUNCH("fsg_pw_gf_prep_f32");                                                                                    \

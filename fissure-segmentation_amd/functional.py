@@ -1346,7 +1346,7 @@ def seg_head_supported(levels, B, Npts, Wg, W0, W1, W2, W3):
             Npts % 256 == 0 and levels.shape[0] == B * Npts and KL % 64 == 0 and Wg.shape[0] % 128 == 0 and
             W0.shape[0] % 64 == 0 and W0.shape[1] == KL + Wg.shape[0] and W1.shape[0] % 64 == 0 and W1.shape[1] == W0.shape[0] and
             W2.shape[0] % 64 == 0 and W2.shape[1] == W1.shape[0] and W3.shape[1] == W2.shape[0] and W3.shape[0] <= 8 and
-            W2.shape[0] % 32 == 0 and Wg.shape[0] <= 4096 and B <= 32 and B * W0.shape[0] <= 8192)
+            W2.shape[0] % 32 == 0 and Wg.shape[0] <= 4096 and B <= 32 and (8 if B <= 8 else 32) * W0.shape[0] <= 8192)
 
 
 def seg_head(levels, B, Npts, global_block, seg_blocks):
