@@ -22,6 +22,8 @@
 // Lanes run along channels (Co % 64 == 0): every P-row gather is one coalesced 256-byte access served by L2;
 // blockIdx.x = cloud, so the workgroups of a cloud share an XCD (round-robin placement) and its L2 keeps that
 // cloud's P rows.
+#include <type_traits>
+
 #include "fsg_common.h"
 
 size_t fsg_ec_finalize_stage_floats(int Co);
@@ -482,13 +484,10 @@ __global__ __launch_bounds__(256) void ec1_apply_prep_kernel(const float *__rest
 #pragma unroll
     for (int u = 0; u < 16; ++u) yv[u] = ysel[((long)b * N + min(i0 + wave + 4 * u, N - 1)) * Co + c];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < 16; ++u) {          // N % 64 == 0 (launch condition): every row of the tile exists
         const int p = wave + 4 * u, i = i0 + p;
-        float v = 0.f;
-        if (i < N) {
-            v = lrelu(__builtin_fmaf(yv[u], g, sh), slope);
-            out_pm[((long)b * N + i) * Co + c] = v;
-        }
+        const float v = lrelu(__builtin_fmaf(yv[u], g, sh), slope);
+        out_pm[((long)b * N + i) * Co + c] = v;
         tile[lane][p] = v;
     }
     __syncthreads();
@@ -500,10 +499,8 @@ __global__ __launch_bounds__(256) void ec1_apply_prep_kernel(const float *__rest
     for (int off = 32; off > 0; off >>= 1) dv = fmaxf(dv, __shfl_xor(dv, off));
     if (wave == 0) mu[lane] = m;
     if (lane == 0) wmax[wave] = dv;
-    for (int cc = wave; cc < 64; cc += 4) {
-        const int i = i0 + lane;
-        if (i < N) out[((long)b * Co + cc) * N + i] = tile[cc][lane];
-    }
+#pragma unroll 4
+    for (int cc = wave; cc < 64; cc += 4) out[((long)b * Co + cc) * N + i0 + lane] = tile[cc][lane];
     __syncthreads();
     const float maxdev = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
     // power of two that maps the sample's largest deviation into [2^9, 2^10) (as knn_split_prep_kernel)
@@ -584,22 +581,27 @@ __global__ __launch_bounds__(256) void ec1_bwd_point_kernel(const float *__restr
         g1[q] = gout_pm ? gout_pm[row * ld_pm + c] : 0.f;
         g2[q] = gout_pm2 ? gout_pm2[row * ld_pm2 + c] : 0.f;
     }
+    // two copies of the row loop: tiles inside the cloud (workgroup-uniform) run it without the per-row test and its branches
+    auto rows = [&](auto checked) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {      // same row order as the loads: the sums keep their association
-        const int p = wave + 16 * (q >> 2) + 4 * (q & 3), i = i0 + p;
-        if (i < N) {
-            const long o = ((long)b * N + i) * Co + c;
-            const float yhat = (ys[q] - mu) * r;
-            const float u = __builtin_fmaf(ga, yhat, be);
-            float gv = tile[lane][p];
-            if (gout_pm) gv += g1[q];
-            if (gout_pm2) gv += g2[q];
-            const float hv = gv * (u > 0.f ? 1.f : slope);
-            h[o] = hv;
-            sb += hv;
-            sg = __builtin_fmaf(hv, yhat, sg);
+        for (int q = 0; q < 16; ++q) {      // same row order as the loads: the sums keep their association
+            const int p = wave + 16 * (q >> 2) + 4 * (q & 3), i = i0 + p;
+            if (!decltype(checked)::value || i < N) {
+                const long o = ((long)b * N + i) * Co + c;
+                const float yhat = (ys[q] - mu) * r;
+                const float u = __builtin_fmaf(ga, yhat, be);
+                float gv = tile[lane][p];
+                if (gout_pm) gv += g1[q];
+                if (gout_pm2) gv += g2[q];
+                const float hv = gv * (u > 0.f ? 1.f : slope);
+                h[o] = hv;
+                sb += hv;
+                sg = __builtin_fmaf(hv, yhat, sg);
+            }
         }
-    }
+    };
+    if (i0 + 64 <= N) rows(std::false_type{});
+    else rows(std::true_type{});
     red[0][wave][lane] = sb;
     red[1][wave][lane] = sg;
     __syncthreads();
