@@ -1345,11 +1345,13 @@ __global__ __launch_bounds__(256) void pw_scatter_rows_kernel(const float *__res
     const unsigned *keys = sorted + (long)b * Cp2;
     const int c0 = chunk * SC_CHUNK;
     if (c0 >= C) return;
+    // the keys are the same for every thread of the workgroup: held as SCALARS (readfirstlane), so that the segment logic below
+    // is scalar control flow and the row / channel offsets of the loads are scalar too
     unsigned key[SC_CHUNK];
-    const unsigned prev = c0 > 0 ? keys[c0 - 1] : 0xFFFFFFFFu;
-    const unsigned next = c0 + SC_CHUNK < C ? keys[c0 + SC_CHUNK] : 0xFFFFFFFFu;
+    const unsigned prev = __builtin_amdgcn_readfirstlane(c0 > 0 ? keys[c0 - 1] : 0xFFFFFFFFu);
+    const unsigned next = __builtin_amdgcn_readfirstlane(c0 + SC_CHUNK < C ? keys[c0 + SC_CHUNK] : 0xFFFFFFFFu);
 #pragma unroll
-    for (int i = 0; i < SC_CHUNK; ++i) key[i] = c0 + i < C ? keys[c0 + i] : 0xFFFFFFFFu;
+    for (int i = 0; i < SC_CHUNK; ++i) key[i] = __builtin_amdgcn_readfirstlane(c0 + i < C ? keys[c0 + i] : 0xFFFFFFFFu);
     for (int k0 = 0; k0 < K; k0 += 256) {
         const int k = min(k0 + tid, K - 1);
         float wv[SC_CHUNK], cf[SC_CHUNK], old[SC_CHUNK];
@@ -1361,7 +1363,7 @@ __global__ __launch_bounds__(256) void pw_scatter_rows_kernel(const float *__res
             cf[i] = coef[(long)b * C + c];
             old[i] = dX[((long)b * Npts + r) * ldx + k];
         }
-        if (k0 + tid >= K) continue;
+        const bool act = k0 + tid < K;      // threads behind K keep running (clamped column): only their stores are masked, the segment logic stays scalar
         float acc = 0.f, base = 0.f;
         bool open = false;                                  // a segment whose head lies in this chunk is being summed
         unsigned row = 0;
@@ -1371,7 +1373,7 @@ __global__ __launch_bounds__(256) void pw_scatter_rows_kernel(const float *__res
             const unsigned r = key[i] >> 12;
             const bool head = (i == 0 ? (prev >> 12) : (key[i - 1] >> 12)) != r || (i == 0 && prev == 0xFFFFFFFFu);
             if (head) {
-                if (open) dX[((long)b * Npts + row) * ldx + k] = base + acc;
+                if (open && act) dX[((long)b * Npts + row) * ldx + k] = base + acc;
                 open = true;
                 row = r;
                 base = old[i];
@@ -1385,7 +1387,7 @@ __global__ __launch_bounds__(256) void pw_scatter_rows_kernel(const float *__res
                 const unsigned c = keys[e] & 4095u;
                 acc = __builtin_fmaf(coef[(long)b * C + c], W[(long)c * ldw + k], acc);
             }
-            dX[((long)b * Npts + row) * ldx + k] = base + acc;
+            if (act) dX[((long)b * Npts + row) * ldx + k] = base + acc;
         }
     }
 }
