@@ -12,6 +12,7 @@ import fissure_segmentation_amd as fsg  # noqa: E402
 from fissure_segmentation_amd import functional as F  # noqa: E402
 
 OLD = 2097152
+MONO = 536870912   # the monolithic coarse-sweep kernel of rounds 2-3 (one launch)
 dev = torch.device("cuda:0")
 
 
@@ -110,6 +111,8 @@ if __name__ == "__main__":
             ok &= check(2, 64, 2048, 20, "biased", flags=fl)
             ok &= check(2, 3, 2048, 20, "uniform", flags=fl, oracle=True)
             ok &= check(1, 33, 4096, 63, "biased", drop=True, flags=fl)
+        for args in ((8, 64, 2048, 20, "biased"), (2, 3, 2048, 20, "uniform"), (1, 64, 8192, 40, "lowdim"), (2, 16, 1024, 20, "outlier")):
+            ok &= check(*args, flags=MONO)                        # the monolithic kernel still agrees
         print("ALL EQUAL" if ok else "MISMATCH", flush=True)
     import ctypes
     lib = fsg._lib.lib
@@ -124,11 +127,12 @@ if __name__ == "__main__":
         lib.fsg_debug_knn_split_stats(st, 0)
         print(f"stats B={B} C={C} N={N} k={k} {kind:8s}: {st[1] / max(st[0], 1):.1f} listed per query, max {st[3]}, slow {st[2]} of {st[0]}", flush=True)
         for nm, fl in (("setup", 67108864), ("setup+sweep1", 8388608), ("..+tau+sweep2", 16777216)):
-            print(f"   {nm}: {timeit(B, C, N, k, kind, fl):.1f} us", flush=True)
+            print(f"   monolithic kernel, {nm}: {timeit(B, C, N, k, kind, fl | MONO):.1f} us", flush=True)
     for (B, C, N, k, kind) in [(8, 64, 2048, 20, "biased"), (8, 64, 2048, 20, "lowdim"), (8, 64, 2048, 20, "uniform"),
                                (8, 3, 2048, 20, "uniform"), (4, 64, 8192, 40, "lowdim"), (4, 3, 8192, 40, "uniform"),
                                (32, 3, 2048, 40, "uniform"), (8, 3, 4096, 20, "uniform"), (8, 64, 4096, 20, "lowdim"),
                                (8, 128, 4096, 20, "lowdim")]:
         tn, tb, to = timeit(B, C, N, k, kind, 0), timeit(B, C, N, k, kind, 1073741824), timeit(B, C, N, k, kind, OLD)
-        print(f"time B={B} C={C} N={N} k={k} {kind:8s}: split fp16 {tn:8.1f} us   split 3 x bf16 {tb:8.1f} us   two-phase {to:8.1f} us", flush=True)
+        tm = timeit(B, C, N, k, kind, MONO)
+        print(f"time B={B} C={C} N={N} k={k} {kind:8s}: nominate + refine {tn:8.1f} us   (3 x bf16 form {tb:8.1f} us)   monolithic {tm:8.1f} us   two-phase {to:8.1f} us", flush=True)
     sys.exit(0 if ok else 1)
