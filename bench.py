@@ -31,6 +31,7 @@ from fissure_segmentation_amd.models.dgcnn import DGCNNSeg  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_16x16x4_f32 / 32x32x2, exact fp32)
+L2_GATHER_PEAK = 17.8e12       # MI355X_MICROARCH.md, "Indexed rows": rows served from the XCD's L2, 66-73 GB/s per CU = 16.8-18.8 TB/s
 WORKLOADS = {
     # name: (clouds per GPU, points, k, description)
     "c2": (8, 2048, 20, "DGCNN-seg N=2048 k=20, 8 clouds/GPU, dynamic graph, fp32 (BASELINE configs[1])"),
@@ -98,7 +99,8 @@ def usable_cores():
 
 def cpu_baseline(B, N, k, classes, budget_s=12.0, max_steps=8):
     """The oracle's pure-PyTorch CPU restatement (kind "port") on the host cores, same step definition; a bounded sample:
-    whole steps of the same batch until ~budget_s seconds of CPU work are spent (at least 2, at most max_steps)."""
+    whole steps of the same batch (callers pass fewer clouds for the N = 8192 workload: a step there materialises
+    (B,N,N) and (B,2C,N,k) tensors) until ~budget_s seconds of CPU work are spent (at least 2, at most max_steps)."""
     from oracle import ref_cpu
     cores = usable_cores()
     torch.set_num_threads(cores)
@@ -281,6 +283,7 @@ def main():
     fence()
     launch = "eager"
     step = eager_step
+    breakdown, step_no = D.StepBreakdown(on_gpu=True), [0]
     if use_graph:
         # the step has static shapes: capture fwd+loss+bwd (and, on one GPU, Adam) once into a hipGraph and replay it;
         # with data parallelism the gradient all-reduce runs between the fwd/bwd graph and the optimizer graph
@@ -309,7 +312,9 @@ def main():
 
             def graph_step():
                 if flat_sync:     # graph 1 -> in-place all-reduce of flat.grad on the replay stream -> graph 2
-                    D.flat_sync_step(g1.replay, opt.flat.grad, g2.replay)
+                    step_no[0] += 1
+                    D.flat_sync_step(g1.replay, opt.flat.grad, g2.replay,
+                                     probe=breakdown if step_no[0] % 10 == 0 else None)   # HIP events every 10th step
                     return static_loss
                 g1.replay()
                 if world > 1:
@@ -370,7 +375,7 @@ def main():
         torch.cuda.synchronize()
         return 1e3 * e0.elapsed_time(e1) / reps
 
-    group_us, knn64_us, knn_prepared = None, None, False
+    group_us, knn64_us, knn_prepared, knn_nominees = None, None, False, None
     try:
         if not dgcnn:
             raise LookupError("no EdgeConv group in this workload")
@@ -403,11 +408,22 @@ def main():
                     for _ in range(10):
                         F_.knn_graph(feat, k)
             knn64_us = replay_us(knn10, 20) / 10
+            try:     # nominees per query of that build, from the kernel's own counters (debug flag 33554432)
+                import ctypes
+                st_ = (ctypes.c_ulonglong * 4)()
+                _lib.lib.fsg_debug_knn_split_stats.argtypes = [ctypes.c_void_p, ctypes.c_int]
+                _lib.lib.fsg_debug_knn_split_stats(st_, 1)
+                F_.knn_graph(feat, k, _debug_flags=33554432)
+                torch.cuda.synchronize()
+                _lib.lib.fsg_debug_knn_split_stats(st_, 0)
+                knn_nominees = st_[1] / max(st_[0], 1)
+            except Exception as e:
+                print(f"[bench] nominee count failed ({type(e).__name__}: {e})", file=sys.stderr)
     except LookupError:
         pass
     except Exception as e:
         print(f"[bench] group timing by graph replay failed ({type(e).__name__}: {e})", file=sys.stderr)
-    head_us = None
+    head_us, vendor_us = None, None
     if dgcnn and rank == 0:
         # the widest product of the fused point-wise head on its own (levels (B N, 192) x [W_global ; W0_levels]^T (1280, 192),
         # csrc/pointwise.hip): plain member of the kernel family, same tile and loop as inside the step
@@ -416,6 +432,8 @@ def main():
             w_h = torch.randn(1280, 192, device=device) * 0.1
             img_h = fsg.functional.pw_weight_image(w_h)
             head_us = replay_us(lambda: fsg.functional.pw_linear(a_h, img_h, 1280, tile=1), 20)
+            w_t = w_h.t().contiguous()
+            vendor_us = replay_us(lambda: torch.mm(a_h, w_t), 20)     # the vendor library's fp32 GEMM at the same shape, same run
         except Exception as e:
             print(f"[bench] head product timing failed ({type(e).__name__}: {e})", file=sys.stderr)
     if not torch.isfinite(loss):
@@ -447,6 +465,17 @@ def main():
         if rank == 0:
             np.savez(args.dump_check, params=params, avg_grad=avg, world=world, B=B, N=N, k=k or 0, launch=launch,
                      grad_sync="flat" if flat_sync else "bucketed")
+    # N > 1: where the step's time goes (HIP events around graph 1 / the all-reduce / graph 2 on every 10th step), max over ranks
+    breakdown_us = None
+    if world > 1:
+        torch.cuda.synchronize()
+        mean = breakdown.mean_us()
+        bt = torch.tensor([mean[n] for n in D.StepBreakdown.NAMES] if mean else [0.0, 0.0, 0.0], dtype=torch.float64, device=device)
+        dist.all_reduce(bt, op=dist.ReduceOp.MAX)
+        if mean:
+            breakdown_us = {n: round(v, 1) for n, v in zip(D.StepBreakdown.NAMES, bt.tolist())}
+            breakdown_us["probed_steps"] = len(breakdown.steps)
+            breakdown_us["reduced_as"] = "mean over the probed steps per rank, maximum over the ranks"
     t = torch.tensor(blocks, dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)       # per block: the slowest rank
@@ -467,16 +496,17 @@ def main():
         knn_calls = kernel_ms.get("fsg_knn_dense_ws_f32", [])
         knn_prep_calls = kernel_ms.get("fsg_knn_dense_prepared_f32", [])   # feature-space builds prepared by their producer
         if knn_calls and args.workload != "c2s":
-            # DOMINANT KERNEL GROUP of the DGCNN-type workloads: the feature-space graph build (fsg_knn_dense_ws_f32: prep +
-            # knn_split_kernel, csrc/knn_split.hip).  Its compulsory HBM traffic is tiny (4C + 4k bytes per point), so the
-            # ceilings that can bind are on-chip.  The kernel is priced against what it EXECUTES, three ceilings, none of which
-            # can be exceeded:
+            # DOMINANT KERNEL GROUP of the DGCNN-type workloads: the feature-space graph build (csrc/knn_split.hip, two launches:
+            # knn_nominate_kernel + knn_refine_kernel).  Its compulsory HBM traffic is tiny (4C + 4k bytes per point), so the
+            # ceilings that can bind are on-chip.  It is priced against what it EXECUTES / MOVES, every term derived in THIS run
+            # (shapes, the nominee count read back from the kernel's own counters, the time by HIP events), none can be exceeded:
             #   mfma_f16    issued matrix flop (two coarse sweeps on v_mfma_f32_32x32x16_f16 = 2 x 2 B N^2 Cpad) / 2.5 PFLOP/s
-            #   valu_issue  vector instructions issued (SQ_INSTS_VALU per launch, PMC pass under profiles/) x 4 cycles / 1024 SIMDs
-            #               against the kernel's cycles at the 2.4 GHz peak clock
             #   refine_f32  exact fp32 fma chains of the nominated candidates (B N x nominees x 2C) / 157.3 TFLOP/s
-            # `frac` is the largest of the three and `bound` names it.  candidates_per_s (B N^2 / t) is a throughput figure, not
-            # a fraction of anything.
+            #   l2_to_cu    bytes every CU has to pull out of its XCD's L2: each 64-query workgroup reads the cloud's whole coarse
+            #               image once (operand tiles resident for both sweeps at N = 2048, twice otherwise) + the fp32 rows of the
+            #               nominees, against the chip's L2 -> CU gather rate (MI355X_MICROARCH.md, "Indexed rows": 66-73 GB/s per
+            #               CU from the XCD's L2 = 16.8-18.8 TB/s; 17.8 used)
+            # `frac` is the largest and `bound` names it.  candidates_per_s (B N^2 / t) is a throughput figure, not a fraction.
             chans = {"c5": (3, 64, 64, 128)}.get(args.workload, EDGE_LAYERS_C)
             if knn_prep_calls:     # DGCNN-seg: build 1 (coordinates) through the plain entry, builds 2 and 3 prepared
                 pp = len(knn_prep_calls) // n_timed
@@ -490,7 +520,7 @@ def main():
             timed_as = "HIP events around the C-ABI entry point on its stream (eager steps of the same workload)"
             if knn64_us is not None and chans[li] == 64:
                 avg_ms = knn64_us * 1e-3
-                timed_as = ("HIP events around hipGraph replays of 10 back-to-back launches of the entry point on the replay "
+                timed_as = ("HIP events around hipGraph replays of 10 back-to-back calls of the entry point on the replay "
                             "stream (" + ("fsg_knn_dense_prepared_f32: the prep products come out of the producing EdgeConv's "
                                           "apply pass, as inside the step" if knn_prepared else "prep kernel included") +
                             ", no Python launch gaps); eager per-call timing: "
@@ -499,47 +529,42 @@ def main():
             cpad = 4 if chans[li] <= 4 else 16 * -(-chans[li] // 16)
             products = 3 if chans[li] <= 4 else 1                        # two bf16 pieces (three products) up to 4 channels
             issued = 2.0 * products * 2.0 * B * N * N * max(cpad, 16)    # two sweeps, k padded to one 16-deep MFMA step
-            pmc = {}
-            for cand in ("r3_knn_sq_counters.txt", "r2b_knn_sq_counters.txt"):
-                path = os.path.join(ROOT, "profiles", cand)
-                if os.path.exists(path):
-                    for ln in open(path):
-                        f = ln.split()
-                        if f and f[0].startswith("SQ_") and "mean=" in ln:
-                            pmc[f[0]] = float(ln.split("mean=")[1])
-                    pmc["file"] = "profiles/" + cand
-                    break
-            ceilings = {"mfma_f16": round(issued / t_s / 2.5e15, 4)}
-            nominees = {20: 25.6, 40: 70.0}.get(k, float(k) * 1.5)       # measured nominees per query
-            ceilings["refine_f32"] = round(B * N * nominees * 2.0 * chans[li] / t_s / (MFMA_FP32_PEAK_TFLOPS * 1e12), 4)
-            if args.workload == "c2" and chans[li] == 64 and "SQ_INSTS_VALU" in pmc:
-                ceilings["valu_issue"] = round(pmc["SQ_INSTS_VALU"] * 4.0 / 1024.0 / (t_s * 2.4e9), 4)
+            nominees = knn_nominees if (knn_nominees and chans[li] == 64) else {20: 27.4, 40: 77.2}.get(k, float(k) * 1.5)
+            image_bpp = 32.0 if chans[li] <= 4 else 2.0 * cpad           # coarse image bytes per point (1 KiB blocks per 32 points)
+            image_reads = 1.0 if N == 2048 else 2.0                      # resident operand tiles at 64 tiles per cloud
+            l2_bytes = B * (N / 64.0) * N * image_bpp * image_reads + B * N * nominees * cpad * 4.0
+            ceilings = {"mfma_f16": round(issued / t_s / 2.5e15, 4),
+                        "refine_f32": round(B * N * nominees * 2.0 * chans[li] / t_s / (MFMA_FP32_PEAK_TFLOPS * 1e12), 4),
+                        "l2_to_cu": round(l2_bytes / t_s / L2_GATHER_PEAK, 4)}
             bound = max(ceilings, key=ceilings.get)
             knn_traffic = None
             if args.workload == "c2":
-                for kname, rec in traffic_all.get("kernels", {}).items():
-                    if kname.startswith("knn_split_kernel<4"):
-                        knn_traffic = rec.get("hbm_bytes_per_launch")
+                kt = [rec.get("hbm_bytes_per_launch") for kname, rec in traffic_all.get("kernels", {}).items()
+                      if kname.startswith("knn_nominate_kernel<4") or kname.startswith("knn_refine_kernel<64")]
+                knn_traffic = sum(kt) if len(kt) == 2 else None
             unit = {"mfma_f16": ("TFLOP/s", issued / t_s / 1e12, 2500.0),
                     "refine_f32": ("TFLOP/s", ceilings["refine_f32"] * MFMA_FP32_PEAK_TFLOPS, MFMA_FP32_PEAK_TFLOPS),
-                    "valu_issue": ("G vector instructions/s", pmc.get("SQ_INSTS_VALU", 0.0) / t_s / 1e9, 1024 * 2.4 / 4.0)}[bound]
-            roofline = {"bound": {"mfma_f16": "mfma", "refine_f32": "mfma", "valu_issue": "valu-issue"}[bound],
+                    "l2_to_cu": ("GB/s", l2_bytes / t_s / 1e9, L2_GATHER_PEAK / 1e9)}[bound]
+            roofline = {"bound": {"mfma_f16": "mfma", "refine_f32": "mfma", "l2_to_cu": "l2"}[bound],
                         "achieved": round(unit[1], 2), "peak": round(unit[2], 1), "unit": unit[0], "frac": ceilings[bound],
                         "ceilings": ceilings,
+                        "ceilings_derived_from": "shapes + the kernel's own nominee counter + HIP-event time, all of this run; peaks "
+                                                 "from MI355X_MICROARCH.md (2.5 PFLOP/s f16 matrix, 157.3 TFLOP/s fp32, 17.8 TB/s L2 -> CU)",
                         "traffic": knn_traffic,
                         "traffic_source": "profiles/hbm_traffic.json (PMC passes of an earlier run of the same command), not measured in this run",
-                        "counters_source": pmc.get("file"),
-                        "kernel": f"feature-space graph build on {chans[li]} channels (knn_split_kernel, csrc/knn_split.hip; its prep "
-                                  "products are emitted by the producing EdgeConv's apply pass): two "
+                        "kernel": f"feature-space graph build on {chans[li]} channels (csrc/knn_split.hip: knn_nominate_kernel + "
+                                  "knn_refine_kernel; its prep products are emitted by the producing EdgeConv's apply pass): two "
                                   "coarse sweeps on the matrix cores nominate candidates under a rigorous error bound; exact fp32 "
                                   "fma chains + ranking for the nominees (bit-identical to the fp32 oracle)",
-                        "issued_matrix_flops_per_launch": issued, "avg_us": round(1e3 * avg_ms, 1), "launches_per_step": per_step,
+                        "issued_matrix_flops_per_launch": issued, "l2_to_cu_bytes_per_launch": l2_bytes,
+                        "nominees_per_query": round(nominees, 2),
+                        "avg_us": round(1e3 * avg_ms, 1), "launches_per_step": per_step,
                         "candidates_per_s": round(B * N * N / t_s, 1),
                         "timed_as": timed_as}
         if dgcnn:
             # the north-star HBM view of the forward "kNN + gather" group, against BOTH byte counts of SURVEY 8(d)
             grp = ["fsg_knn_dense_ws_f32", "fsg_knn_dense_prepared_f32", "fsg_edge_gather_fwd_f32", "fsg_edgeconv1_fwd_f32",
-                   "fsg_edgeconv2_fwd_f32", "fsg_edgeconv_apply_f32"]
+                   "fsg_edgeconv2_fwd_f32", "fsg_edgeconv2_fwd_bf16", "fsg_edgeconv_apply_f32"]   # (bf16 operand mode: its own entry)
             grp_ms = sum(sum(kernel_ms.get(n, [])) for n in grp) / n_timed
             ref_bytes = knn_gather_bytes_per_point(k) * B * N
             min_bytes = knn_gather_min_bytes_per_point(k) * B * N
@@ -585,10 +610,14 @@ def main():
                "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-               "precision": ("fp32 storage, fp32 accumulation, fp32-grade products everywhere: the EdgeConv contractions and the "
-                             "graph build's exact distances on the fp32 matrix instruction / fp32 fma chains; the point-wise head's "
-                             "products as three bf16 pieces per fp32 operand and six bf16 MFMA products each (dropped terms <= 2^-26 "
-                             "|a||b|, error vs fp64 at or below the vendor fp32 GEMM's: tests/test_gpu_parity.py::test_pw_linear_is_fp32_grade)"
+               "precision": ("fp32 storage, fp32 accumulation, fp32-grade products everywhere.  Graph build: coarse fp16 / bf16 matrix "
+                             "sweeps only NOMINATE, every ranked or returned distance is the oracle's fp32 fma chain (indices and distance "
+                             "bits equal the CPU oracle's).  The per-edge 64 x 64 contraction of the two-layer EdgeConv (ec2s_fwd / "
+                             "ec2s_bwd, csrc/edgeconv2.hip) and the point-wise head's products (csrc/pointwise.hip) run as three bf16 "
+                             "pieces per fp32 operand and six v_mfma_f32_32x32x16_bf16 products each, fp32 accumulation (dropped terms "
+                             "<= 2^-26 |a||b|; error vs fp64 at or below an fp32 fma chain's / the vendor fp32 GEMM's: "
+                             "tests/test_gpu_parity.py::test_pw_linear_is_fp32_grade, ::test_ec2s_is_fp32_grade); one-layer EdgeConvs "
+                             "are per-point fp32 products + fp32 gathers"
                              if dtype == "f32" else
                              "bf16 operands / fp32 accumulation in the per-edge EdgeConv contraction (v_mfma_f32_32x32x16_bf16) and "
                              "the vendor GEMMs; graph build, BatchNorm statistics, stored activations and gradients fp32"),
@@ -600,7 +629,9 @@ def main():
                           "dist_backend": None if world == 1 else dist.get_backend(), "ranks_seen": ranks_seen,
                           "grad_sync": None if world == 1 else
                           ("one in-place all-reduce of FlatAdam's flat gradient buffer between the fwd/bwd graph and the "
-                           "optimizer graph" if flat_sync else "bucketed averager (cat, all-reduce, copy back)")},
+                           "optimizer graph" if flat_sync else "bucketed averager (cat, all-reduce, copy back)"),
+                          "allreduce_payload_bytes": None if world == 1 else (opt.flat.grad.numel() * 4 if flat_sync else None),
+                          "step_breakdown_us": breakdown_us},
                "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "reported": "median block",
                           "block_ms_min_median_max": [round(1e3 * blocks[0], 3), round(1e3 * elapsed, 3), round(1e3 * blocks[-1], 3)],
                           "gpu_busy_s": round(sum(blocks), 2)},
@@ -614,13 +645,17 @@ def main():
                    "achieved": round(6 * 2.0 * B * N * 1280 * 192 / (head_us * 1e-6) / 1e12, 1),
                    "frac": round(6 * 2.0 * B * N * 1280 * 192 / (head_us * 1e-6) / 2.5e15, 4),
                    "fp32_equivalent_tflops": round(2.0 * B * N * 1280 * 192 / (head_us * 1e-6) / 1e12, 1),
-                   "vendor_fp32_gemm_same_shape_tflops": 111.5},
+                   "vendor_fp32_gemm_same_shape_tflops": None if vendor_us is None else
+                   round(2.0 * B * N * 1280 * 192 / (vendor_us * 1e-6) / 1e12, 1),
+                   "vendor_fp32_gemm_timed_as": "torch.mm(a, w^T) at (B N, 192) x (192, 1280), hipGraph replay, this run"},
                "entry_points": {n: {k2: round(v, 2) for k2, v in d.items()} for n, d in sorted(per_kernel.items())}}
         if not dgcnn:
             out["config"]["step"] = ("fwd + cross-entropy + generalised Dice + bwd + Adam" if args.workload in ("c3", "c3f", "c3b")
                                      else "fwd + Chamfer(reconstruction, input) + bwd + Adam")
         if world == 1 and not args.no_cpu_baseline and dgcnn and args.workload != "c2s":
-            out["cpu_baseline"] = cpu_baseline(B, N, k, classes)
+            # (N = 8192: one cloud per CPU step -- a step of the oracle materialises (B,N,N) and (B,2C,N,k) tensors)
+            out["cpu_baseline"] = cpu_baseline(B if N <= 2048 else 1, N, k, classes, budget_s=12.0 if N <= 2048 else 20.0,
+                                               max_steps=8 if N <= 2048 else 3)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -806,14 +806,10 @@ extern "C" int fsg_graph_reverse_csr(const int32_t *idx, int B, int N, int k, in
         if (rc != FSG_ERR_UNSUPPORTED) return rc;
     }
     const size_t lds = sizeof(int) * ((size_t)N + 1024);
-    static size_t granted = 64 * 1024;
-    if (lds > granted) {
-        if (hipFuncSetAttribute((const void *)csr_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess) {
-            fsg_set_error("fsg_graph_reverse_csr: cannot raise dynamic LDS to %zu", lds);
-            return FSG_ERR_HIP;
-        }
-        granted = lds;
+    static FsgLdsGrant grant;
+    if (!grant.raise((const void *)csr_build_kernel, lds)) {
+        fsg_set_error("fsg_graph_reverse_csr: cannot raise dynamic LDS to %zu", lds);
+        return FSG_ERR_HIP;
     }
     hipLaunchKernelGGL(csr_build_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, idx, N, k, rowptr, col);
     FSG_CHECK_LAUNCH("fsg_graph_reverse_csr");

@@ -1306,29 +1306,21 @@ static int ec2_fwd_impl(bool bf16, const float *pq, const int32_t *idx, const fl
     const size_t lds = sizeof(float) * ((size_t)C2 * LD1 + (size_t)Rpad * (C2 + 1) + 3 * 4 * C2);
 #define FSG_EC2_FWD(CC, BFX)                                                                                             \
     do {                                                                                                                 \
-        static bool granted = false;                                                                                     \
-        if (!granted) {                                                                                                  \
-            if (hipFuncSetAttribute((const void *)ec2_fwd_kernel<CC, BFX>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                    160 * 1024 - 512) != hipSuccess) {                                                   \
-                fsg_set_error("fsg_edgeconv2_fwd: cannot raise dynamic LDS");                                            \
-                return FSG_ERR_HIP;                                                                                      \
-            }                                                                                                            \
-            granted = true;                                                                                              \
-        }                                                                                                                \
+        static FsgLdsGrant grant;                                                                                     \
+        if (!grant.raise((const void *)ec2_fwd_kernel<CC, BFX>, 160 * 1024 - 512)) {                                  \
+            fsg_set_error("fsg_edgeconv2_fwd: cannot raise dynamic LDS");                                             \
+            return FSG_ERR_HIP;                                                                                       \
+        }                                                                                                             \
         hipLaunchKernelGGL((ec2_fwd_kernel<CC, BFX>), dim3(B, G), dim3(256), lds, st, pq, idx, w2, gamma1, beta1, mean1,    \
                            invstd1, gamma2, N, k, TP, Rpad, training, slope, ysel2, arg2, ssum2, part2);                 \
     } while (0)
 #define FSG_EC2S_FWD(NPX, RTX)                                                                                            \
     do {                                                                                                                 \
-        static bool granted = false;                                                                                     \
-        if (!granted) {                                                                                                  \
-            if (hipFuncSetAttribute((const void *)ec2s_fwd_kernel<NPX, RTX>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                    160 * 1024 - 512) != hipSuccess) {                                                   \
-                fsg_set_error("fsg_edgeconv2_fwd: cannot raise dynamic LDS");                                            \
-                return FSG_ERR_HIP;                                                                                      \
-            }                                                                                                            \
-            granted = true;                                                                                              \
-        }                                                                                                                \
+        static FsgLdsGrant grant;                                                                                     \
+        if (!grant.raise((const void *)ec2s_fwd_kernel<NPX, RTX>, 160 * 1024 - 512)) {                                \
+            fsg_set_error("fsg_edgeconv2_fwd: cannot raise dynamic LDS");                                             \
+            return FSG_ERR_HIP;                                                                                       \
+        }                                                                                                             \
         hipLaunchKernelGGL((ec2s_fwd_kernel<NPX, RTX>), dim3(B, G), dim3(256), ec2s_fwd_lds(NPX, RTX, TPs), st, pq, idx, w2,    \
                            gamma1, beta1, mean1, invstd1, gamma2, N, k, TPs, training, slope, ysel2, arg2, ssum2, part2); \
     } while (0)
@@ -1451,30 +1443,22 @@ static int ec2_bwd_impl(bool bf16, const float *grad_out, const float *grad_out_
                                         2 * C1 + 2 * C1) + (size_t)TP * C2 + 2 * (size_t)Rpad + 16;
 #define FSG_EC2_BWD(CC, BFX)                                                                                                \
     do {                                                                                                                 \
-        static bool granted = false;                                                                                     \
-        if (!granted) {                                                                                                  \
-            if (hipFuncSetAttribute((const void *)ec2_bwd_kernel<CC, BFX>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                    160 * 1024 - 512) != hipSuccess) {                                                   \
-                fsg_set_error("fsg_edgeconv2_bwd_f32: cannot raise dynamic LDS");                                        \
-                return FSG_ERR_HIP;                                                                                      \
-            }                                                                                                            \
-            granted = true;                                                                                              \
-        }                                                                                                                \
+        static FsgLdsGrant grant;                                                                                     \
+        if (!grant.raise((const void *)ec2_bwd_kernel<CC, BFX>, 160 * 1024 - 512)) {                                  \
+            fsg_set_error("fsg_edgeconv2_bwd_f32: cannot raise dynamic LDS");                                         \
+            return FSG_ERR_HIP;                                                                                       \
+        }                                                                                                             \
         hipLaunchKernelGGL((ec2_bwd_kernel<CC, BFX>), dim3(B, G), dim3(256), lds, st, pq, idx, w2, gamma1, beta1, mean1, invstd1, \
                            gamma2, mean2, invstd2, grad_beta2, grad_gamma2, h2, arg2, N, k, TP, Rpad, training, invM,    \
                            slope, du1, dw_part, p1_part);                                                                \
     } while (0)
 #define FSG_EC2S_BWD(NPX, RTX)                                                                                            \
     do {                                                                                                                 \
-        static bool granted = false;                                                                                     \
-        if (!granted) {                                                                                                  \
-            if (hipFuncSetAttribute((const void *)ec2s_bwd_kernel<NPX, RTX>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                    160 * 1024 - 512) != hipSuccess) {                                                   \
-                fsg_set_error("fsg_edgeconv2_bwd_f32: cannot raise dynamic LDS");                                        \
-                return FSG_ERR_HIP;                                                                                      \
-            }                                                                                                            \
-            granted = true;                                                                                              \
-        }                                                                                                                \
+        static FsgLdsGrant grant;                                                                                     \
+        if (!grant.raise((const void *)ec2s_bwd_kernel<NPX, RTX>, 160 * 1024 - 512)) {                                \
+            fsg_set_error("fsg_edgeconv2_bwd_f32: cannot raise dynamic LDS");                                         \
+            return FSG_ERR_HIP;                                                                                       \
+        }                                                                                                             \
         hipLaunchKernelGGL((ec2s_bwd_kernel<NPX, RTX>), dim3(B, G), dim3(256), ec2s_bwd_lds(NPX, RTX, TPs), st, pq, idx,   \
                            w2, gamma1, beta1, mean1, invstd1, gamma2, mean2, invstd2, grad_beta2, grad_gamma2, h2, arg2, \
                            N, k, TPs, training, invM, slope, du1, dw_part, p1_part);                                     \

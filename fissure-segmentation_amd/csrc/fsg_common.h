@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "../../include/fsg_hip.h"
 
 #define FSG_WAVE 64
@@ -28,6 +30,31 @@ void fsg_set_error(const char *fmt, ...);
     } while (0)
 
 static inline int fsg_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Dynamic LDS above the 64 KiB every kernel may use is granted per kernel AND per device (hipFuncSetAttribute acts on the
+// current device's copy of the function).  One instance per call site -- a function-local static of the launching function /
+// template instantiation --, remembering what each device has been granted; safe when several host threads launch.
+struct FsgLdsGrant {
+    static constexpr int kMaxDevices = 64;
+    std::atomic<size_t> bytes[kMaxDevices];
+    FsgLdsGrant() {
+        for (auto &b : bytes) b.store(64 * 1024, std::memory_order_relaxed);
+    }
+    // make sure the kernel may be launched with `need` bytes of dynamic LDS on the current device; false if the runtime refuses
+    bool raise(const void *kernel, size_t need) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        const bool tracked = dev >= 0 && dev < kMaxDevices;
+        if (tracked && need <= bytes[dev].load(std::memory_order_acquire)) return true;
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess) return false;
+        if (tracked) {     // monotone maximum (another thread may have raised it further in the meantime)
+            size_t cur = bytes[dev].load(std::memory_order_relaxed);
+            while (cur < need && !bytes[dev].compare_exchange_weak(cur, need, std::memory_order_release)) {
+            }
+        }
+        return true;
+    }
+};
 
 #ifdef __HIPCC__
 // Row gathers with lanes = channels: the row index is wave-uniform (v_readlane of the neighbour list), so the row offset

@@ -194,14 +194,10 @@ extern "C" int fsg_knn_dense_f32(const float *x, int B, int N, int64_t stride_b,
             fsg_set_error("fsg_knn_dense_f32: LDS need %zu B > 160 KiB (N=%d c_knn=%d)", lds, N, c_knn);
             return FSG_ERR_UNSUPPORTED;
         }
-        static size_t lds_granted = 64 * 1024;  // per instantiation (the lambda is instantiated per kernel)
-        if (lds > lds_granted) {
-            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) {
-                fsg_set_error("fsg_knn_dense_f32: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
-                return FSG_ERR_HIP;
-            }
-            lds_granted = lds;
+        static FsgLdsGrant grant;  // per instantiation (the lambda is instantiated per kernel)
+        if (!grant.raise((const void *)kern, lds)) {
+            fsg_set_error("fsg_knn_dense_f32: cannot raise dynamic LDS to %zu", lds);
+            return FSG_ERR_HIP;
         }
         dim3 grid(fsg_cdiv(N, QB), B);
         hipLaunchKernelGGL(kern, grid, dim3(BLOCK), lds, st, x, N, Npad, (long)stride_b, (long)stride_c, c_knn, k,

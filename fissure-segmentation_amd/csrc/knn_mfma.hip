@@ -215,14 +215,10 @@ int fsg_knn_mfma_launch(const float *x, int B, int N, int64_t stride_b, int64_t 
     dim3 grid(fsg_cdiv(N, 32), B);
 #define FSG_KNN_MFMA(KS)                                                                                              \
     do {                                                                                                              \
-        static bool granted = false;                                                                                  \
-        if (!granted) {                                                                                               \
-            if (hipFuncSetAttribute((const void *)knn_mfma_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                    (int)lds) != hipSuccess) {                                                        \
-                fsg_set_error("fsg_knn_dense_f32: cannot raise dynamic LDS to %zu", lds);                             \
-                return FSG_ERR_HIP;                                                                                   \
-            }                                                                                                         \
-            granted = true;                                                                                           \
+        static FsgLdsGrant grant;                                                                                     \
+        if (!grant.raise((const void *)knn_mfma_kernel<KS>, (int)lds)) {                                              \
+            fsg_set_error("fsg_knn_dense_f32: cannot raise dynamic LDS to %zu", lds);                                 \
+            return FSG_ERR_HIP;                                                                                       \
         }                                                                                                             \
         hipLaunchKernelGGL(knn_mfma_kernel<KS>, grid, dim3(256), lds, st, x, xx_scratch, N, (long)stride_b,           \
                            (long)stride_c, c_knn, k, flags, idx_out, dist_out);                                       \

@@ -763,15 +763,11 @@ int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int
     do {                                                                                                               \
         const size_t lds = sizeof(float) * QB * ((CHK) + 4) + sizeof(u64) * (QB * (CKK)) + sizeof(int) * QB +           \
                            ((QL) ? sizeof(float) * 4 * (KS) * QB : 0) + ((STRM) ? 2 * sizeof(int) * QB : 0);           \
-        static bool granted = false;                                                                                   \
-        if (!granted) {                                                                                                \
-            if (hipFuncSetAttribute((const void *)knn_rows_mfma_kernel<KS, WV, SV, CHK, CKK, false, QL, STRM>,         \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {             \
-                fsg_set_error("fsg_knn_dense_f32: cannot raise dynamic LDS to %zu", lds);                              \
-                return FSG_ERR_HIP;                                                                                    \
-            }                                                                                                          \
-            granted = true;                                                                                            \
-        }                                                                                                              \
+        static FsgLdsGrant grant;                                                                                     \
+        if (!grant.raise((const void *)knn_rows_mfma_kernel<KS, WV, SV, CHK, CKK, false, QL, STRM>, (int)lds)) {      \
+            fsg_set_error("fsg_knn_dense_f32: cannot raise dynamic LDS to %zu", lds);                                 \
+            return FSG_ERR_HIP;                                                                                       \
+        }                                                                                                             \
         hipLaunchKernelGGL((knn_rows_mfma_kernel<KS, WV, SV, CHK, CKK, false, QL, STRM>), grid, dim3((WV) * 64), lds, st, x, \
                            xx_scratch, N,                                                                              \
                            (long)stride_b, (long)stride_c, c_knn, k, flags, idx_out, dist_out, SegArgs{});             \
@@ -785,7 +781,7 @@ int fsg_knn_rows_mfma_launch(const float *x, int B, int N, int64_t stride_b, int
     // streamed selection (STREAM = true, 512-candidate chunks, 16 waves), formerly flag 131072.  Exact (same parity suite) but
     // MEASURED SLOWER than the two-phase kernel and therefore opt-in: B=8 N=2048 k=20 C=64 101 vs 88 us, C=3 70 vs 52 us;
     // B=4 N=8192 k=40 C=64 567 vs 542 us (tools/knn_ablate_phases.py, eager timing incl. the squared-norm launch).  What the
-    // instrumented build (-DFSG_KNN_STATS, tools/knn_stream_stats.py) shows: the filter works as designed -- 57 survivors
+    // instrumented build (-DFSG_KNN_STATS; the statistics script went with the streamed variant in round 3) showed: the filter works as designed -- 57 survivors
     // per row for a 1536-candidate epoch (expected 60), 3.7 % of the workgroups redo an epoch -- but a streamed epoch costs
     // as much as the distance block + full selection it replaces: with 2-6 tiles per wave and epoch the operand-load
     // latency, the two barriers and the rank-by-counting merge (which dominates the selection either way) are all exposed,
@@ -819,14 +815,10 @@ int fsg_knn_segment_rows_launch(const float *xyz, const float *new_xyz, const in
     if (nsample > 32 || b > 4096) return FSG_ERR_UNSUPPORTED;
     constexpr int WV = 16, SV = 96, CHK = 1024, CKK = 64;
     const size_t lds = sizeof(float) * QB * (CHK + 4) + sizeof(u64) * (QB * CKK) + sizeof(int) * QB;
-    static bool granted = false;
-    if (!granted) {
-        if (hipFuncSetAttribute((const void *)knn_rows_mfma_kernel<1, WV, SV, CHK, CKK, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            fsg_set_error("fsg_knn_segment_f32: cannot raise dynamic LDS to %zu", lds);
-            return FSG_ERR_HIP;
-        }
-        granted = true;
+    static FsgLdsGrant grant;
+    if (!grant.raise((const void *)knn_rows_mfma_kernel<1, WV, SV, CHK, CKK, true>, (int)lds)) {
+        fsg_set_error("fsg_knn_segment_f32: cannot raise dynamic LDS to %zu", lds);
+        return FSG_ERR_HIP;
     }
     const SegArgs sa{new_xyz, offset, new_offset, b};
     hipLaunchKernelGGL((knn_rows_mfma_kernel<1, WV, SV, CHK, CKK, true>), dim3(fsg_cdiv(m, QB) + b), dim3(WV * 64), lds, st,

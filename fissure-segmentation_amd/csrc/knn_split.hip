@@ -1808,15 +1808,11 @@ static int launch_monolithic(const SplitPlan &p, const float *x, const float *pr
     if (p.KS == 8 && (flags & 1073741824)) return FSG_ERR_UNSUPPORTED;   // 128 channels: fp16 image only
 #define FSG_KNN_MONO(KSV, PK, HF)                                                                                      \
     do {                                                                                                               \
-        static bool granted = false;                                                                                   \
-        if (!granted) {                                                                                                \
-            if (hipFuncSetAttribute((const void *)knn_split_kernel<KSV, PK, HF>,                                       \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {           \
-                fsg_set_error("fsg_knn_dense_ws_f32: cannot raise dynamic LDS");                                       \
-                return FSG_ERR_HIP;                                                                                    \
-            }                                                                                                          \
-            granted = true;                                                                                            \
-        }                                                                                                              \
+        static FsgLdsGrant grant;                                                                                     \
+        if (!grant.raise((const void *)knn_split_kernel<KSV, PK, HF>, 160 * 1024)) {                                  \
+            fsg_set_error("fsg_knn_dense_ws_f32: cannot raise dynamic LDS");                                          \
+            return FSG_ERR_HIP;                                                                                       \
+        }                                                                                                             \
         if (!prepared_xt)                                                                                              \
             hipLaunchKernelGGL((knn_split_prep_kernel<KSV, PK, HF>), pgrid, dim3(256), 0, st, x, N, p.Np,              \
                                (long)stride_b, (long)stride_c, c_knn, xx, xt, cand, xs, cscale);                       \
@@ -1889,15 +1885,11 @@ int fsg_knn_split_launch_ex(const float *x, const float *prepared_xt, int B, int
     const dim3 rgrid(p.Np / (2 * RQW), B);
 #define FSG_KNN_SPLIT(KSV, PK, HF)                                                                                      \
     do {                                                                                                               \
-        static bool granted = false;                                                                                   \
-        if (!granted) {                                                                                                \
-            if (hipFuncSetAttribute((const void *)knn_nominate_kernel<KSV, PK, HF, false>,                             \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {           \
-                fsg_set_error("fsg_knn_dense_ws_f32: cannot raise dynamic LDS");                                       \
-                return FSG_ERR_HIP;                                                                                    \
-            }                                                                                                          \
-            granted = true;                                                                                            \
-        }                                                                                                              \
+        static FsgLdsGrant grant;                                                                                     \
+        if (!grant.raise((const void *)knn_nominate_kernel<KSV, PK, HF, false>, 160 * 1024)) {                        \
+            fsg_set_error("fsg_knn_dense_ws_f32: cannot raise dynamic LDS");                                          \
+            return FSG_ERR_HIP;                                                                                       \
+        }                                                                                                             \
         if (!prepared_xt)                                                                                              \
             hipLaunchKernelGGL((knn_split_prep_kernel<KSV, PK, HF>), pgrid, dim3(256), 0, st, x, N, p.Np,              \
                                (long)stride_b, (long)stride_c, c_knn, xx, xt, cand, xs, cscale);                       \

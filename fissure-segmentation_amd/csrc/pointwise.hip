@@ -578,14 +578,10 @@ int launch_rowgemm(const RowGemmArgs &a, hipStream_t st, const char *name) {
     size_t lds = (PIPE ? 2 : 1) * ((size_t)(BM / 32) * 2 * NP + (size_t)(BN / 32) * 2 * NP) * 1024 + sizeof(float) * 4 * (size_t)a.K1;
     const size_t scratch = sizeof(float) * 2 * 2 * WN * 32;
     if (lds < scratch) lds = scratch;
-    static size_t granted = 64 * 1024;
-    if (lds > granted) {
-        if (hipFuncSetAttribute((const void *)pw_rowgemm_kernel<WM, WN, PRO, EPI, PIPE, NP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) {
-            fsg_set_error("%s: cannot raise dynamic LDS to %zu", name, lds);
-            return FSG_ERR_HIP;
-        }
-        granted = lds;
+    static FsgLdsGrant grant;      // (per template instantiation; the grant itself is per device)
+    if (!grant.raise((const void *)pw_rowgemm_kernel<WM, WN, PRO, EPI, PIPE, NP>, lds)) {
+        fsg_set_error("%s: cannot raise dynamic LDS to %zu", name, lds);
+        return FSG_ERR_HIP;
     }
     hipLaunchKernelGGL((pw_rowgemm_kernel<WM, WN, PRO, EPI, PIPE, NP>), dim3(grid), dim3(256), lds, st, a);
     FSG_CHECK_LAUNCH(name);

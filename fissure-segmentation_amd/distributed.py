@@ -64,19 +64,70 @@ def broadcast_parameters(model, src=0):
         off += t.numel()
 
 
-def flat_sync_step(run_fwd_bwd, flat_grad, run_update, collective=None):
+def flat_sync_step(run_fwd_bwd, flat_grad, run_update, collective=None, probe=None):
     """One data-parallel step of the flat scheme, in the only order that is correct: `run_fwd_bwd()` (graph 1: forward, loss,
     backward, gather into `flat_grad`) -> ONE in-place SUM all-reduce of `flat_grad`, issued synchronously (async_op=False) on
     the current stream, so the device executes it after everything `run_fwd_bwd` enqueued and before anything `run_update`
     enqueues -> `run_update()` (graph 2: scale by 1/world + Adam).  No handle escapes, nothing runs on a side stream: there is
-    no window in which the update could read an un-reduced buffer.  `collective` replaces dist.all_reduce in tests."""
+    no window in which the update could read an un-reduced buffer.  `collective` replaces dist.all_reduce in tests.
+    `probe` (a StepBreakdown) marks the four boundaries of this step: fwd_bwd | allreduce | update."""
+    if probe is not None:
+        probe.mark()
     out = run_fwd_bwd()
+    if probe is not None:
+        probe.mark()
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         work = (collective or dist.all_reduce)(flat_grad, op=dist.ReduceOp.SUM, async_op=False)
         if work is not None:          # a backend that hands a handle back even for a synchronous call
             work.wait()
+    if probe is not None:
+        probe.mark()
     run_update()
+    if probe is not None:
+        probe.mark()
     return out
+
+
+class StepBreakdown:
+    """Where a data-parallel step spends its time: fwd_bwd (graph 1) | allreduce | update (graph 2).  On a GPU the marks are HIP
+    events recorded on the current (replay) stream -- stream-ordered, the host does not wait; on the CPU (gloo tests) they are
+    host clock readings.  bench.py passes one to `flat_sync_step` every 10th step and reports the mean spans, maximum over the
+    ranks, as config.step_breakdown_us: a first hardware run at N > 1 then shows whether a scaling loss is collective latency,
+    rank skew (a long allreduce span on the fast ranks) or host launch."""
+    NAMES = ("fwd_bwd", "allreduce", "update")
+
+    def __init__(self, on_gpu):
+        self.on_gpu = bool(on_gpu)
+        self.steps = []          # per probed step: four marks
+        self._cur = []
+
+    def mark(self):
+        if self.on_gpu:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+        else:
+            import time
+            e = time.perf_counter()
+        self._cur.append(e)
+        if len(self._cur) == 4:
+            self.steps.append(self._cur)
+            self._cur = []
+
+    def spans_us(self):
+        """(n_probed, 3) microseconds; call after a device synchronize"""
+        out = []
+        for m in self.steps:
+            if self.on_gpu:
+                out.append([1e3 * m[i].elapsed_time(m[i + 1]) for i in range(3)])
+            else:
+                out.append([1e6 * (m[i + 1] - m[i]) for i in range(3)])
+        return out
+
+    def mean_us(self):
+        sp = self.spans_us()
+        if not sp:
+            return None
+        return {n: sum(r[i] for r in sp) / len(sp) for i, n in enumerate(self.NAMES)}
 
 
 class BucketedGradAverager:

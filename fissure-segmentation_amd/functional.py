@@ -1177,10 +1177,14 @@ class _SegHead(torch.autograd.Function):
         img_lv = torch.empty((KL // 32) * (ks_a + ks_b) * 3 * 1024, dtype=torch.uint8, device=dev)   # [W0_levels^T ; -M1]: backward
         specs = [(Wg, 1.0, img0, 0, None), (W0[:, :KL], 1.0, img0[(CG // 32) * ksl * 3 * 1024:], 0, None), (W1, 1.0, None, 0, None),
                  (W2, 1.0, None, 0, None), (W3, 1.0, None, 0, None)]
-        # transposed images for the backward products ride in the same launch
-        specs += [(W2.t(), 1.0, None, 0, None), (W1.t(), 1.0, None, 0, None), (W0[:, :KL].t(), 1.0, img_lv, 0, ks_a + ks_b)]
+        # (forward runs with grad mode off: whether a backward can follow is what the tensors require)
+        need_bwd = any(t.requires_grad for t in (levels, Wg, gg, bg, W0, g0, b0, W1, g1, b1, W2, g2, b2, W3) if t is not None) or \
+            (b3 is not None and b3.requires_grad)
+        if need_bwd:    # transposed images for the backward products ride in the same launch
+            specs += [(W2.t(), 1.0, None, 0, None), (W1.t(), 1.0, None, 0, None), (W0[:, :KL].t(), 1.0, img_lv, 0, ks_a + ks_b)]
         imgs = pw_weight_images(specs)
-        img1, img2, img3, img2t, img1t = imgs[2], imgs[3], imgs[4], imgs[5], imgs[6]
+        img1, img2, img3 = imgs[2], imgs[3], imgs[4]
+        img2t, img1t = (imgs[5], imgs[6]) if need_bwd else (None, None)
         # levels -> global-feature statistics / selection + y0
         R0 = M // 128
         rec0 = torch.empty(R0, 3, CG + C0, **f32)
@@ -1218,6 +1222,8 @@ class _SegHead(torch.autograd.Function):
         out = torch.empty(M, CLS, **f32)
         pw_rowgemm(PRO_BNACT, PW_STORE | PW_BIAS, 3, A1=y2, lda1=C2, K1=C2, K2=0, Bimg=img3, M=M, N=CLS, rows_per_cloud=Npts,
                    alpha=al_2, delta=de_2, tstride=0, slope=slope, C=out, ldc=CLS, store_n0=0, bias=b3)
+        if not need_bwd:       # inference: nothing kept
+            return out
         ctx.images = (img2t, img1t, img_lv)
         ctx.save_for_backward(levels, y0, y1, y2, Wg, W0, W1, W2, W3, g, ysel, arg, c,
                               mean_g, inv_g, al_g, de_g, mean_0, inv_0, al_0, de_0, emu_0,
@@ -1336,11 +1342,19 @@ def set_fused_head(flag):
     return old
 
 
-def seg_head_supported(levels, B, Npts, Wg, W0, W1, W2, W3):
+def seg_head_supported(levels, B, Npts, Wg, W0, W1, W2, W3, blocks=None):
     """the fused head needs: fp32 GPU rows, clouds of a multiple of 256 points, channel counts on the 32 / 64 grid, at most 32
-    clouds per rank (the reference's experiment scripts train with 32)"""
+    clouds per rank (the reference's experiment scripts train with 32); `blocks` = (global block, *segmentation blocks): the
+    four BatchNorm-backed blocks must be what models/dgcnn.py:282-323 builds -- conv without bias, AFFINE BatchNorm1d, LeakyReLU
+    (the fused node has no place for a conv bias in front of a BatchNorm and reads gamma / beta unconditionally)"""
     if not _fused_head:     # (bf16 operand mode keeps the fused head: its products are fp32-grade, above what the mode asks for)
         return False
+    if blocks is not None:
+        for blk in blocks[:4]:
+            conv, bn, act = blk.layers[0], blk.layers[1], blk.layers[2]
+            if (conv.bias is not None or not isinstance(bn, torch.nn.BatchNorm1d) or not bn.affine or
+                    not isinstance(act, torch.nn.LeakyReLU)):
+                return False
     KL = levels.shape[1]
     return (levels.is_cuda and levels.dtype == torch.float32 and levels.stride(1) == 1 and levels.stride(0) % 4 == 0 and
             Npts % 256 == 0 and levels.shape[0] == B * Npts and KL % 64 == 0 and Wg.shape[0] % 128 == 0 and

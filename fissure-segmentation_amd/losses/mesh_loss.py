@@ -11,21 +11,27 @@ decoders is out of scope), so the surface SAMPLING stays with the caller:
 * with pytorch3d `Meshes`, when pytorch3d is importable: sampled by `pytorch3d.ops.sample_points_from_meshes` and the three
   regularisers (edge length, normal consistency, uniform Laplacian) come from pytorch3d exactly as in the reference.
 
-The regularisers need mesh connectivity; without pytorch3d a positive weight on any of them raises NotImplementedError
-(never a silent zero).  Returns `(loss, components)` like the reference (model_trainer.py:180-185 unpacks it)."""
+The regularisers need mesh connectivity; without pytorch3d a positive weight on any of them raises NotImplementedError at
+CONSTRUCTION (never a silent zero, never a failure after the run has been set up).  Returns `(loss, components)` like the reference (model_trainer.py:180-185 unpacks it)."""
 from torch import nn
 
 from .chamfer_loss import chamfer_distance
 
 
+_P3 = []     # [result] once resolved: (pytorch3d.loss, pytorch3d.ops, Meshes) or None
+
+
 def _pytorch3d():
-    try:
-        import pytorch3d.loss as p3l
-        import pytorch3d.ops as p3o
-        from pytorch3d.structures import Meshes
-        return p3l, p3o, Meshes
-    except Exception:       # absent (this image) or an inert placeholder
-        return None
+    """pytorch3d's pieces, resolved ONCE per process (a failing import is not retried on every forward)"""
+    if not _P3:
+        try:
+            import pytorch3d.loss as p3l
+            import pytorch3d.ops as p3o
+            from pytorch3d.structures import Meshes
+            _P3.append((p3l, p3o, Meshes))
+        except Exception:       # absent (this image) or an inert placeholder
+            _P3.append(None)
+    return _P3[0]
 
 
 class RegularizedMeshLoss(nn.Module):
@@ -38,6 +44,15 @@ class RegularizedMeshLoss(nn.Module):
         self.w_laplacian = w_laplacian
         self.n_samples = n_samples
         self.sampler = sampler
+        # a regulariser that cannot be served fails HERE, at construction (where the reference's import of pytorch3d would
+        # have failed), not on the first forward after dataset and model have been set up
+        wanted = [n for n, w in (("edge length", w_edge_length), ("normal consistency", w_normal_consistency),
+                                 ("Laplacian", w_laplacian)) if w > 0]
+        if wanted and _pytorch3d() is None:
+            raise NotImplementedError(
+                "RegularizedMeshLoss: the " + ", ".join(wanted) + " term(s) need pytorch3d (mesh connectivity is outside the "
+                "MI355X hot path, SURVEY section 8); set their weights to 0 (the Chamfer term runs on the HIP kernel) or install "
+                "pytorch3d")
 
     def _samples(self, mesh, p3):
         import torch

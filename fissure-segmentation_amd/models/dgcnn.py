@@ -248,7 +248,8 @@ class DGCNNSeg(DGCNNBase):
         seg0 = self.segmentation[0]
         w = lambda conv: conv.weight.view(conv.out_channels, -1)
         if F_hip.seg_head_supported(levels, B, N, w(gf[0]), w(seg0.layers[0]), w(self.segmentation[1].layers[0]),
-                                    w(self.segmentation[2].layers[0]), w(self.segmentation[3].layers[0])):
+                                    w(self.segmentation[2].layers[0]), w(self.segmentation[3].layers[0]),
+                                    blocks=[self.global_feature[0]] + list(self.segmentation)):
             # the whole head as ONE autograd node on the fused kernels of csrc/pointwise.hip: fp32-grade products on the bf16
             # matrix pipe, BatchNorm statistics / apply / backward inside the products' epilogues and prologues, the
             # (B*N, 1024) global-feature activation never written, its backward in Gram form

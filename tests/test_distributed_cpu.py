@@ -221,3 +221,49 @@ def test_gloo_world2_flat_sync_step_orders_collective_between_the_graphs():
     mp.spawn(_worker_order, args=(world, port, out), nprocs=world, join=True)
     for r in range(world):
         assert out[r] == [[3.0] * 5, [3.0] * 5]        # 1 + 2 from both ranks: the update read the reduced buffer
+
+
+def _worker_breakdown(rank, world, port, out):
+    """flat_sync_step with a StepBreakdown probe on every 2nd step: the three spans (fwd_bwd | allreduce | update) of a probed
+    step must add up to the time of the whole step measured around the call, and the collective must still see the right
+    buffer.  Stand-ins for the graphs sleep for known times (rank 1 is the slow rank: its peer waits inside the collective)."""
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from fissure_segmentation_amd import distributed as D
+    D.init_from_env(backend="gloo")
+    flat = torch.zeros(1 << 16)
+    probe = D.StepBreakdown(on_gpu=False)
+
+    def g1():
+        time.sleep(0.020 + 0.015 * rank)
+        flat.fill_(float(rank + 1))
+
+    def g2():
+        time.sleep(0.010)
+
+    whole = []
+    for i in range(6):
+        dist.barrier()
+        t0 = time.perf_counter()
+        D.flat_sync_step(g1, flat, g2, probe=probe if i % 2 == 0 else None)
+        whole.append(1e6 * (time.perf_counter() - t0))
+        assert float(flat[0]) == 3.0
+    out[rank] = {"spans": probe.spans_us(), "whole": whole[0::2], "mean": probe.mean_us()}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_step_breakdown_adds_up():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_breakdown, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        rec = out[r]
+        assert len(rec["spans"]) == 3 and set(rec["mean"]) == {"fwd_bwd", "allreduce", "update"}
+        for spans, whole in zip(rec["spans"], rec["whole"]):
+            assert abs(sum(spans) - whole) <= 0.05 * whole, (spans, whole)     # the three spans ARE the step
+            assert spans[0] >= 0.9 * 1e6 * (0.020 + 0.015 * r) and spans[2] >= 0.9 * 1e4
+    # rank skew shows up where it belongs: the fast rank waits for the slow one INSIDE its allreduce span
+    assert out[0]["mean"]["allreduce"] > out[1]["mean"]["allreduce"] + 5e3

@@ -1,5 +1,5 @@
 """In-kernel cycle breakdown of the production kNN kernel (one wave of every workgroup, s_memtime stamps).  Needs the
-instrumented source (python tools/knn_instrument.py) built with -DFSG_KNN_STATS (see tools/knn_stream_stats.py); revert with
+instrumented source (python tools/knn_instrument.py) built with -DFSG_KNN_STATS; revert with
 git checkout afterwards.  Prints average stamped cycles per workgroup for each section, for the first and the last wave."""
 import ctypes, sys, torch
 sys.path[:0] = ["/root/repo", "/root/repo/tests"]
