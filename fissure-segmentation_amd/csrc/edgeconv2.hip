@@ -1198,10 +1198,13 @@ static int ec2_env_int(const char *name) {
 }
 
 // C2 = 64 runs on the split-bf16 kernels (FSG_EC2_OLD=1: the fp32-MFMA kernels above, kept for C2 = 128 and as a cross-check)
+static int ec2_old_env = -1;
+// tests: switch the C2 = 64 path between the split-bf16 kernels (0) and the fp32-MFMA kernels (1) inside one process
+// (tests/test_gpu_parity.py::test_ec2s_is_fp32_grade holds the former to the latter's error against fp64)
+extern "C" void fsg_debug_ec2_use_fp32_mfma(int on) { ec2_old_env = on ? 1 : 0; }
 static bool ec2_split(int C2) {
-    static int old_env = -1;
-    if (old_env < 0) old_env = ec2_env_int("FSG_EC2_OLD") > 0 ? 1 : 0;
-    return C2 == 64 && !old_env;
+    if (ec2_old_env < 0) ec2_old_env = ec2_env_int("FSG_EC2_OLD") > 0 ? 1 : 0;
+    return C2 == 64 && !ec2_old_env;
 }
 
 // tiles of the split kernels: RT * 32 edge rows = TP points; 128 rows when that cuts the padding by more than 15 % (k = 40:

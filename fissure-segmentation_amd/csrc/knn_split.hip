@@ -1862,7 +1862,13 @@ int fsg_knn_split_launch_ex(const float *x, const float *prepared_xt, int B, int
     u32x4 *cand = reinterpret_cast<u32x4 *>(w + p.off_cand);
     float *xs = reinterpret_cast<float *>(w + p.off_xs);
     float *cscale = reinterpret_cast<float *>(w + p.off_scale);
-    if (flags & 536870912) {
+    // One launch or two.  The two-launch form wins wherever the refine's batches of eight queries fit one sub-batch of 256
+    // entries; at k + drop > 32 on 64 and more channels with N > 4096 (BASELINE config 4: ~77 nominees per query, three
+    // sub-batches per wave, 2 x 32 KB of bitmaps per wave and sweep) the monolithic kernel is still ahead (4 x 8192, k = 40,
+    // 64 channels: 209 vs 241 us; every other measured shape: 0 - 35 % in favour of two launches).  Flag 536870912 forces the
+    // monolithic kernel, flag 268435456 (cycle stamps of the two-launch form) the two-launch form.
+    const bool big_k = k + drop > 32 && p.CP >= 64 && N > 4096 && !(flags & 268435456);
+    if ((flags & 536870912) || big_k) {
         const int rc = launch_monolithic(p, x, prepared_xt, B, N, stride_b, stride_c, c_knn, k, flags, idx_out, dist_out, xx, xt, cand, xs, cscale, st);
         if (rc != FSG_OK) return rc;
         FSG_CHECK_LAUNCH("fsg_knn_dense_ws_f32/split-monolithic");

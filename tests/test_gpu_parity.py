@@ -1842,7 +1842,8 @@ def _model_vs_oracle(net, ref, x, gseed, device, out_tol, g_floor, tape=None, lo
     Gradients: LeakyReLU / ReLU kinks make the backward pass discontinuous in the forward values, so two fp32 evaluations of the
     SAME algorithm differ by more than rounding.  The bar is computed from the oracle (FlipOracle above): the HIP gradient must
     be as close to the fp64 one as  max(g_floor, 10 x the oracle's own fp32 error, 2 x the change the oracle's gradient suffers
-    when every pre-activation within fp32 noise of a kink takes the other slope)  -- on all entries, nothing trimmed."""
+    when every pre-activation within fp32 noise of a kink takes the other slope)  -- on all entries, nothing trimmed; and where
+    that flip change is SMALLER than the oracle's own fp32 error, as close as max(g_floor, 3 x that error) (the ratchet)."""
     import copy
     xt = G(x, device).requires_grad_(True)
     y = net(xt)
@@ -1883,10 +1884,22 @@ def _model_vs_oracle(net, ref, x, gseed, device, out_tol, g_floor, tape=None, lo
     near, total = flips.counter
     report["flip_zone"] = {"activations_inside": near, "of": total, "fraction": near / max(total, 1)}
     assert near <= 1e-3 * total, report["flip_zone"]
+    # RATCHET (round 4): the flip bar is only available where flips CAN explain more than the oracle's own fp32 error.  A tensor
+    # whose flip bound is below the oracle's fp32 error is held to 3 x that error (a kernel regression to a few 1e-2 in one
+    # weight gradient no longer hides behind a 2 e_flip that belongs to other tensors' kinks); the report counts the tensors
+    # that actually needed the flip bar.
+    def passes(e_hip, e_cpu, e_flip):
+        if e_flip < e_cpu:
+            return e_hip <= max(g_floor, 3 * e_cpu), False
+        return e_hip <= max(g_floor, 10 * e_cpu, 2 * e_flip), e_hip > max(g_floor, 10 * e_cpu)
+    needed_flip = []
     if xt.grad is not None:
         e_hip, e_cpu, e_flip = _rel(N(xt.grad), gx64), _rel(gx32, gx64), _rel(gxf, gx64)
         report["grad_x"] = (e_hip, e_cpu, e_flip)
-        assert e_hip <= max(g_floor, 10 * e_cpu, 2 * e_flip), ("grad_x", e_hip, e_cpu, e_flip)
+        ok, used = passes(e_hip, e_cpu, e_flip)
+        assert ok, ("grad_x", e_hip, e_cpu, e_flip)
+        if used:
+            needed_flip.append("grad_x")
     scale = max(float(np.linalg.norm(v)) for v in gp64.values())
     worst, bad = ("", 0.0, 0.0, 0.0), []
     for n, p in net.named_parameters():
@@ -1895,9 +1908,13 @@ def _model_vs_oracle(net, ref, x, gseed, device, out_tol, g_floor, tape=None, lo
         e_hip, e_cpu, e_flip = _rel(got, gp64[n], None, den), _rel(gp32[n], gp64[n], None, den), _rel(gpf[n], gp64[n], None, den)
         if e_hip > worst[1]:
             worst = (n, e_hip, e_cpu, e_flip)
-        if e_hip > max(g_floor, 10 * e_cpu, 2 * e_flip):
+        ok, used = passes(e_hip, e_cpu, e_flip)
+        if not ok:
             bad.append((n, e_hip, e_cpu, e_flip))
+        if used:
+            needed_flip.append(n)
     report["worst_param (e_hip, e_cpu32, e_flip)"] = worst
+    report["tensors_that_needed_the_flip_bar"] = (len(needed_flip), needed_flip[:6])
     if tape is not None:
         report["rows_with_other_neighbours_in_own_graph"] = tape.flipped
     print("\nPARITY", type(net).__name__, tuple(x.shape), report)
@@ -2563,15 +2580,30 @@ def test_seg_head_fused_vs_fp64_and_unfused(fsg, device, B, Npts, train):
     def rel(a, b):
         return float((a.double() - b).norm() / b.norm().clamp_min(1e-30))
 
-    def rel_rows(a, b, drop=4):
-        """input-row gradient: a max-pool near-tie (two points of a cloud within fp32 rounding in one of the 1024 channels)
-        legitimately routes one channel's gradient to another row -- the `drop` worst rows are left out (seen once in eight
-        runs: 5e-3 of the norm from one such pair)"""
+    # input-row gradient: a max-pool near-tie (two points of a cloud within fp32 rounding of each other in one of the 1024
+    # global-feature channels) legitimately routes that channel's gradient to the other row.  EXACTLY those rows are left out:
+    # the winner and the runner-up of every (cloud, channel) whose fp64 margin is below the fp32 noise of the activation
+    # (8 roundings of its magnitude: a 192-term fp32 product chain + BatchNorm); round 3 dropped the four worst rows instead.
+    with torch.no_grad():
+        bnp = lambda yv: ((yv - (yv.mean(0) if train else P64["rmg"])) /
+                          torch.sqrt((yv.var(0, unbiased=False) if train else P64["rvg"]) + 1e-5) * P64["gg"] + P64["bg"])
+        ag = torch.nn.functional.leaky_relu(bnp(x64 @ P64["Wg"].t()), 0.2).view(B, Npts, -1)
+        top2 = ag.topk(2, dim=1)
+        margin = top2.values[:, 0] - top2.values[:, 1]                                   # (B, 1024)
+        noise = 8 * 2.0 ** -24 * top2.values[:, 0].abs().clamp_min(1e-3 * float(ag.abs().max()))
+        tie = margin <= noise
+        keep = torch.ones(M, dtype=torch.bool, device=ag.device)
+        bidx = torch.arange(B, device=ag.device).view(B, 1).expand_as(tie)
+        for r in range(2):
+            keep[(bidx * Npts + top2.indices[:, r])[tie]] = False
+    n_tie_rows = int((~keep).sum())
+    assert n_tie_rows <= 16, n_tie_rows                                                   # a handful at most, or the inputs are degenerate
+
+    def rel_rows(a, b):
         d = (a.double() - b).pow(2).sum(1)
-        keep = torch.ones_like(d, dtype=torch.bool)
-        keep[d.topk(drop).indices] = False
         return float((d[keep].sum().sqrt()) / b.norm().clamp_min(1e-30))
     errs = {"x": (rel_rows(gxf, x64.grad), rel_rows(gxu, x64.grad))}
+    print("HEAD rows left out as max-pool near-ties (fp64 margin below fp32 noise):", n_tie_rows)
     gmax = max(float(v.grad.norm()) for v in P64.values() if v.grad is not None)
     for k in names:
         if P64[k].grad.norm() < 1e-6 * gmax:
@@ -2584,6 +2616,87 @@ def test_seg_head_fused_vs_fp64_and_unfused(fsg, device, B, Npts, train):
         for k in bns:
             torch.testing.assert_close(stf[k][0], stu[k][0], rtol=1e-4, atol=1e-5)
             torch.testing.assert_close(stf[k][1], stu[k][1], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,C,Np,k", [(8, 3, 2048, 20), (2, 3, 1024, 40)])
+def test_ec2s_is_fp32_grade(fsg, device, B, C, Np, k):
+    """The split-bf16 kernels of the two-layer EdgeConv (ec2s_fwd / ec2s_bwd, csrc/edgeconv2.hip: three bf16 pieces per fp32
+    operand, six v_mfma_f32_32x32x16_bf16 products, fp32 accumulation -- the kernels of the headline path since round 3) must be
+    as close to an fp64 composition of the same layers on the same graph as the fp32-MFMA kernels they replaced
+    (v_mfma_f32_32x32x2_f32: an exact fp32 fma chain): output and every gradient within 2 x the fp32 kernels' error (with a
+    floor of 2e-6 of the output scale / 3e-5 in norm for the gradients, where that error happens to be tiny), and within
+    1e-5 / 1e-3 absolutely.
+    Reference op: models/dgcnn.py:226-243 (EdgeConv with two shared-MLP layers)."""
+    import ctypes
+    from fissure_segmentation_amd.norm import BatchNorm2d
+    F_hip = fsg.functional
+    lib = fsg._lib.lib
+    lib.fsg_debug_ec2_use_fp32_mfma.argtypes = [ctypes.c_int]
+    lib.fsg_debug_ec2_use_fp32_mfma.restype = None
+    torch.manual_seed(5 + Np)
+    x = torch.rand(B, C, Np, device=device)
+    conv1 = torch.nn.Conv2d(2 * C, 64, 1, bias=False).to(device)
+    conv2 = torch.nn.Conv2d(64, 64, 1, bias=False).to(device)
+    bn1, bn2 = BatchNorm2d(64).to(device), BatchNorm2d(64).to(device)
+    with torch.no_grad():
+        for bn in (bn1, bn2):
+            bn.weight.copy_((torch.rand(64, device=device) + 0.5) * torch.where(torch.arange(64, device=device) % 7 == 0, -1.0, 1.0))
+            bn.bias.copy_(torch.randn(64, device=device) * 0.2)
+    idx = F_hip.knn_graph(x, k, c_knn=3)
+    gr = torch.randn(B, 64, Np, device=device)
+    mods = (conv1, conv2, bn1, bn2)
+
+    def run():
+        for m in mods:
+            for p in m.parameters():
+                p.grad = None
+        xt = x.clone().requires_grad_(True)
+        with F_hip.deferred_bn_counters():
+            y = F_hip.edgeconv2(xt, idx, conv1.weight, bn1, conv2.weight, bn2, 0.2)
+        y.backward(gr)
+        return dict(out=y.detach().double(), grad_x=xt.grad.double(), grad_w1=conv1.weight.grad.double().view(64, 2 * C),
+                    grad_w2=conv2.weight.grad.double().view(64, 64), grad_g1=bn1.weight.grad.double(), grad_b1=bn1.bias.grad.double(),
+                    grad_g2=bn2.weight.grad.double(), grad_b2=bn2.bias.grad.double())
+    try:
+        lib.fsg_debug_ec2_use_fp32_mfma(0)
+        split = run()
+        lib.fsg_debug_ec2_use_fp32_mfma(1)
+        exact = run()
+    finally:
+        lib.fsg_debug_ec2_use_fp32_mfma(0)
+    # fp64 composition (models/dgcnn.py:28-36 edge features, two conv + train-mode BatchNorm + LeakyReLU blocks, max over k)
+    xd = x.double().requires_grad_(True)
+    w1 = conv1.weight.detach().double().view(64, 2 * C).requires_grad_(True)
+    w2 = conv2.weight.detach().double().view(64, 64).requires_grad_(True)
+    g1, b1 = bn1.weight.detach().double().requires_grad_(True), bn1.bias.detach().double().requires_grad_(True)
+    g2, b2 = bn2.weight.detach().double().requires_grad_(True), bn2.bias.detach().double().requires_grad_(True)
+    xp = xd.transpose(1, 2)
+    nb = xp.reshape(B * Np, C)[(idx.long() + (torch.arange(B, device=device) * Np).view(B, 1, 1)).reshape(-1)].view(B, Np, k, C)
+    ctr = xp.unsqueeze(2).expand(B, Np, k, C)
+    e = torch.cat([nb - ctr, ctr], -1)
+
+    def block(t, w, g, b_):
+        t = t @ w.t()
+        mu, var = t.mean((0, 1, 2)), t.var((0, 1, 2), unbiased=False)
+        return torch.nn.functional.leaky_relu((t - mu) / torch.sqrt(var + 1e-5) * g + b_, 0.2)
+    yd = block(block(e, w1, g1, b1), w2, g2, b2).max(2)[0].permute(0, 2, 1)
+    yd.backward(gr.double())
+    want = dict(out=yd.detach(), grad_x=xd.grad, grad_w1=w1.grad, grad_w2=w2.grad, grad_g1=g1.grad, grad_b1=b1.grad,
+                grad_g2=g2.grad, grad_b2=b2.grad)
+    rep, bad = {}, []
+    for n in want:
+        sc = float(want[n].abs().max())
+        if n == "out":
+            es, ee = float((split[n] - want[n]).abs().max()) / sc, float((exact[n] - want[n]).abs().max()) / sc
+            lim, floor = 1e-5, 2e-6
+        else:
+            es, ee = float((split[n] - want[n]).norm() / want[n].norm()), float((exact[n] - want[n]).norm() / want[n].norm())
+            lim, floor = 1e-3, 3e-5
+        rep[n] = ("%.2e" % es, "%.2e" % ee)
+        if es > min(lim, max(2 * ee, floor)):
+            bad.append((n, es, ee))
+    print("\nEC2S vs fp64 (split-bf16 kernels, fp32-MFMA kernels):", rep)
+    assert not bad, bad
 
 
 def test_seg_head_backward_is_bitwise_reproducible(fsg, device):
