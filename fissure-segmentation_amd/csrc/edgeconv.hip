@@ -267,101 +267,145 @@ __global__ __launch_bounds__(256) void csr_sort_rows_kernel(const int32_t *__res
 }
 
 // ------------------------------------------------------------------ forward
+// Round 4.  The SQ counters of round 3's kernel (lanes = channels, one 4-byte load per lane and row) show it VALU-bound: 4.7 M
+// vector instructions per launch = 14 per gathered value, 59 % of the SIMD cycles at 4 cycles per instruction, no matrix work
+// to hide behind.  This version has a lane own FOUR channels of ONE point: group g = lane / 16 works on point ibase + g, lane
+// c16 = lane % 16 on channels 4 c16 .. 4 c16 + 3 of its rows -- a row is one 16-byte load per lane (a wave instruction reads
+// four whole 256-byte rows, one per point), addresses and neighbour ids are computed once per FOUR values, sums and the
+// BatchNorm moments run on packed fp32 instructions (v_pk_add_f32 / v_pk_fma_f32: two channels per instruction).  ~5.5
+// instructions per value with the selection, ~2.5 without (SELECT = false: the statistics pass of a two-layer EdgeConv, whose
+// selection belongs to its second layer).  Values and association are those of the first version: yy = y + q, tot summed in
+// slot order, the first maximum of sgn yy wins.
+template <bool SELECT>
 __global__ __launch_bounds__(512) void ec1_stats_select_kernel(const float *__restrict__ pq,
                                                                 const int32_t *__restrict__ idx,
                                                                 const float *__restrict__ gamma, int N, int k, int Co,
                                                                 int training, float *__restrict__ ysel,
                                                                 uint8_t *__restrict__ arg, float *__restrict__ ssum,
                                                                 float *__restrict__ partials) {
-    __shared__ float red[3][4 * TPW][64];
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    constexpr int NW = 4 * TPW;                        // waves
+    __shared__ float red[2][4 * NW][64];               // (mean, M2) of every 16-lane group (= point) of the workgroup
     const int b = blockIdx.x, tile = blockIdx.y, cg = blockIdx.z;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 4 * TPW waves, 4 points each
-    const int c = cg * 64 + lane;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, c16 = lane & 15;
+    const int c0 = cg * 64 + 4 * c16;                 // first of this lane's four channels
     const int ld = 2 * Co;
-    const RowGather rows_pq(pq + (long)b * N * ld, (long)N * ld * 4);   // [P | Q] rows of this cloud
-    const float sgn = gamma[c] >= 0.f ? 1.f : -1.f;
-    float shift = 0.f, s1 = 0.f, s2 = 0.f, cnt = 0.f;
-    bool first = true;
-    // One coalesced load brings a point's k neighbour ids into the wave; each id is broadcast with v_readlane into the SCALAR
-    // offset of a buffer load (no 64-bit address arithmetic on the vector unit: it was a third of this kernel's instructions)
-    // and the P-row gathers go out eight at a time; the ids and the Q row of the NEXT point are requested before the current
-    // point's gathers, so a point costs the latency of its gather rounds only.
-    const int ibase = tile * TP * TPW + wave * (TP / 4);
-    int myj = 0;
-    float q = 0.f;
-    if (ibase < N) {
-        myj = lane < k ? idx[((long)b * N + ibase) * k + lane] : 0;
-        q = rows_pq.load(true, ibase, ld, Co + c);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(pq + (long)b * N * ld), 0, __builtin_amdgcn_readfirstlane((int)((long)N * ld * 4)), 0x00020000);
+    f2 sgn[2] = {{1.f, 1.f}, {1.f, 1.f}};
+    if (SELECT) {
+        const f4 gm = *reinterpret_cast<const f4 *>(gamma + c0);
+        sgn[0] = f2{gm[0] >= 0.f ? 1.f : -1.f, gm[1] >= 0.f ? 1.f : -1.f};
+        sgn[1] = f2{gm[2] >= 0.f ? 1.f : -1.f, gm[3] >= 0.f ? 1.f : -1.f};
     }
-    for (int t = 0; t < TP / 4; ++t) {
-        const int i = ibase + t;
-        if (i >= N) break;
-        const int myj_c = myj;
-        const float q_c = q;
-        if (t + 1 < TP / 4 && i + 1 < N) {
-            myj = lane < k ? idx[((long)b * N + i + 1) * k + lane] : 0;
-            q = rows_pq.load(true, i + 1, ld, Co + c);
+    const int i = tile * TP * TPW + wave * (TP / 4) + g;    // this group's point
+    const bool live = i < N;
+    const int ic = live ? i : N - 1;
+    // the point's neighbour ids (lane c16 holds slots c16, c16 + 16, ...) and its Q row
+    int ids[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (16 * r < k) ids[r] = (16 * r + c16 < k) ? idx[((long)b * N + ic) * k + 16 * r + c16] : 0;
+    const f4 q4 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
+        rs, (unsigned)ic * (unsigned)(ld * 4) + (unsigned)((Co + c0) * 4), 0, 0));
+    const f2 q[2] = {{q4[0], q4[1]}, {q4[2], q4[3]}};
+    f2 tot[2] = {{0.f, 0.f}, {0.f, 0.f}}, shift[2] = {{0.f, 0.f}, {0.f, 0.f}}, s1[2] = {{0.f, 0.f}, {0.f, 0.f}},
+       s2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int barg[4] = {0, 0, 0, 0};
+    // rounds of RB neighbours: a round's loads are all requested before its first value is used (RB = 8: two register sets of
+    // 32 keep the kernel at <= 128 VGPRs = two 512-thread workgroups per CU)
+    constexpr int RB = SELECT ? 8 : 10;        // (without the selection's registers ten fit: k = 20 is ONE round trip of twenty loads)
+    auto request = [&](int s0, u4 (&y)[RB]) {
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int s = min(s0 + u, k - 1);                         // uniform
+            const int r = s >> 4;
+            const int held = r == 0 ? ids[0] : (r == 1 ? ids[1] : (r == 2 ? ids[2] : ids[3]));
+            const int j = __builtin_amdgcn_ds_bpermute(4 * ((lane & 48) | (s & 15)), held);   // lane (g, s % 16) holds slot s
+            y[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)j * (unsigned)(ld * 4) + (unsigned)(c0 * 4), 0, 0);
         }
-        float best = -INFINITY, tot = 0.f;
-        int barg = 0;
-        for (int s0 = 0; s0 < k; s0 += 8) {
-            float y[8];
+    };
+    auto consume = [&](int s0, const u4 (&y)[RB]) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = __builtin_amdgcn_readlane(myj_c, min(s0 + u, k - 1));
-                y[u] = rows_pq.load(true, j, ld, c);
-            }
+        for (int u = 0; u < RB; ++u) {
+            const int s = s0 + u;
+            if (s < k) {                                             // uniform
+                const f4 yv = __builtin_bit_cast(f4, y[u]);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (s0 + u < k) {
-                    const float yy = y[u] + q_c;
-                    tot += yy;
-                    const float v = sgn * yy;
-                    if (v > best) { best = v; barg = s0 + u; }
+                for (int hf = 0; hf < 2; ++hf) {
+                    const f2 yy = f2{yv[2 * hf], yv[2 * hf + 1]} + q[hf];
+                    tot[hf] += yy;
                     if (training) {
-                        if (first) { shift = yy; first = false; }
-                        const float d = yy - shift;
-                        s1 += d;
-                        s2 = __builtin_fmaf(d, d, s2);
+                        if (s == 0) shift[hf] = yy;
+                        const f2 d = yy - shift[hf];
+                        s1[hf] += d;
+                        s2[hf] = __builtin_elementwise_fma(d, d, s2[hf]);
+                    }
+                    if (SELECT) {
+                        const f2 v = sgn[hf] * yy;
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+                            if (v[e] > best[2 * hf + e]) { best[2 * hf + e] = v[e]; barg[2 * hf + e] = s; }
                     }
                 }
             }
         }
-        const long o = ((long)b * N + i) * Co + c;
-        ysel[o] = sgn * best;
-        arg[o] = (uint8_t)barg;
-        if (ssum) ssum[o] = tot;
-        cnt += (float)k;
+    };
+    u4 ya[RB], yb[RB];
+    request(0, ya);
+    for (int s0 = 0; s0 < k; s0 += 2 * RB) {
+        if (s0 + RB < k) request(s0 + RB, yb);
+        consume(s0, ya);
+        if (s0 + 2 * RB < k) request(s0 + 2 * RB, ya);
+        if (s0 + RB < k) consume(s0 + RB, yb);
+    }
+    if (live) {
+        const long o = ((long)b * N + i) * Co + c0;
+        if (SELECT) {
+            *reinterpret_cast<f4 *>(ysel + o) = f4{sgn[0][0] * best[0], sgn[0][1] * best[1], sgn[1][0] * best[2], sgn[1][1] * best[3]};
+            *reinterpret_cast<unsigned *>(arg + o) =
+                (unsigned)barg[0] | ((unsigned)barg[1] << 8) | ((unsigned)barg[2] << 16) | ((unsigned)barg[3] << 24);
+        }
+        if (ssum) *reinterpret_cast<f4 *>(ssum + o) = f4{tot[0][0], tot[0][1], tot[1][0], tot[1][1]};
     }
     if (!training) return;
-    // per-wave (n, mean, M2) -> per-workgroup record (Chan merge), then one global record per workgroup
-    float mean = 0.f, m2 = 0.f;
-    if (cnt > 0.f) {
-        mean = shift + s1 / cnt;
-        m2 = fmaxf(s2 - s1 * s1 / cnt, 0.f);
+    // per-group (mean, M2) of the point's k values -> LDS; wave 0 merges the workgroup's 4 NW groups.  Every live group holds
+    // exactly k values, so Chan's merge collapses to  mean = average of the group means,  M2 = sum M2_g + k sum (mean_g - mean)^2:
+    // two passes of independent adds in a fixed order, ONE division (a chain of 31 pairwise merges with a division each was
+    // ~3 us of one wave at the end of every workgroup).
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float s1e = s1[e >> 1][e & 1], s2e = s2[e >> 1][e & 1], she = shift[e >> 1][e & 1];
+        red[0][wave * 4 + g][4 * c16 + e] = she + s1e / (float)k;
+        red[1][wave * 4 + g][4 * c16 + e] = fmaxf(s2e - s1e * s1e / (float)k, 0.f);
     }
-    red[0][wave][lane] = cnt;
-    red[1][wave][lane] = mean;
-    red[2][wave][lane] = m2;
     __syncthreads();
     if (wave == 0) {
-        float n = red[0][0][lane], mu = red[1][0][lane], M2 = red[2][0][lane];
-#pragma unroll
-        for (int w = 1; w < 4 * TPW; ++w) {
-            const float nb_ = red[0][w][lane];
-            if (nb_ > 0.f) {
-                const float tot = n + nb_;
-                const float delta = red[1][w][lane] - mu;
-                mu += delta * (nb_ / tot);
-                M2 += red[2][w][lane] + delta * delta * (n * nb_ / tot);
-                n = tot;
-            }
+        const int c = cg * 64 + lane;
+        const int live_groups = min(4 * NW, max(0, N - tile * TP * TPW));    // points of this workgroup inside the cloud
+        float sm = 0.f, sM = 0.f;
+#pragma unroll 8
+        for (int w = 0; w < 4 * NW; ++w) {
+            const bool on = w < live_groups;
+            sm += on ? red[0][w][lane] : 0.f;
+            sM += on ? red[1][w][lane] : 0.f;
+        }
+        const float mu = live_groups > 0 ? sm / (float)live_groups : 0.f;
+        float dev = 0.f;
+#pragma unroll 8
+        for (int w = 0; w < 4 * NW; ++w) {
+            const float d = red[0][w][lane] - mu;
+            dev = __builtin_fmaf(w < live_groups ? d : 0.f, d, dev);
         }
         const long rec = (long)b * gridDim.y + tile;
         float *pr = partials + rec * 3 * Co;
-        pr[c] = n;
+        pr[c] = (float)live_groups * (float)k;
         pr[Co + c] = mu;
-        pr[2 * Co + c] = M2;
+        pr[2 * Co + c] = sM + (float)k * dev;
     }
 }
 
@@ -636,55 +680,83 @@ __global__ __launch_bounds__(64 * SUMP_SLICES) void sum_partials_kernel(const fl
     }
 }
 
-// one wave per destination point j: dP_j (reverse-graph gather) and dQ_j
+// one wave per destination point j: dP_j (reverse-graph gather) and dQ_j.  Round 4 (the counters show the first version VALU-
+// bound like the forward pass: 6.2 M vector instructions per launch, 56 % of the SIMD cycles): a lane owns FOUR channels, group
+// g = lane / 16 takes the in-edges t = g (mod 4) of the destination -- one 16-byte load per lane and row piece, addresses once per
+// four values, the Q sums on packed fp32 adds.  The four groups' partial sums meet through LDS in a fixed order
+// ((g0 + g1) + (g2 + g3)) and the in-edges of a destination are sorted: reproducible bit for bit from run to run, as before.
 __global__ __launch_bounds__(256) void ec1_bwd_gather_kernel(
     const float *__restrict__ pq, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ h, const uint8_t *__restrict__ arg, const float *__restrict__ ssum,
     const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ invstd,
     const float *__restrict__ dbeta, const float *__restrict__ dgamma, int N, int k, int Co, int training, float invM,
     float *__restrict__ grad_pq) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ float comb[4][2][4][64];        // [wave][ah | aq][group][channel]
     const int b = blockIdx.x, cg = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = blockIdx.y * 4 + wave;
-    if (j >= N) return;
-    const int c = cg * 64 + lane;
+    if (j >= N) return;                        // (wave-uniform; no workgroup barrier below)
+    const int g = lane >> 4, c16 = lane & 15;
+    const int c0 = cg * 64 + 4 * c16;
     const int ld = 2 * Co;
     const float *P = pq + (long)b * N * ld;
     const float *Q = P + Co;
+    const float *hb = h + (long)b * N * Co;
+    const uint8_t *ab = arg + (long)b * N * Co;
     const int beg = rowptr[(long)b * (N + 1) + j], end = rowptr[(long)b * (N + 1) + j + 1];
     const int32_t *cb = col + (long)b * N * k;
-    float ah = 0.f, aq = 0.f;
-    for (int t0 = beg; t0 < end; t0 += 64) {  // in-edges in chunks of 64: one coalesced load, then lane broadcasts
+    float ah[4] = {0.f, 0.f, 0.f, 0.f};
+    f2 aq[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    constexpr int RU = 5;                     // in-edges in flight per group (20 per wave and round trip)
+    for (int t0 = beg; t0 < end; t0 += 64) {  // in-edges in chunks of 64: one coalesced load, then ds_bpermute broadcasts
         const int mye = (t0 + lane < end) ? cb[t0 + lane] : 0;
         const int cnt = min(64, end - t0);
-        // eight in-edges per round (independent gathers in flight); the sums keep the edge order (same bits)
-        for (int t = 0; t < cnt; t += 8) {
-            float hv[8], qv[8];
-            int av[8], sl[8];
+        for (int t = 0; t < cnt; t += 4 * RU) {
+            f4 hv[RU], qv[RU];
+            unsigned av[RU];
+            int sl[RU];
+            bool ok[RU];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = __builtin_amdgcn_readlane(mye, min(t + u, cnt - 1));
-                const long o = ((long)b * N + (e >> 6)) * Co + c;
-                hv[u] = h[o];
-                av[u] = arg[o];
-                sl[u] = e & 63;
-                qv[u] = training ? Q[(long)(e >> 6) * ld + c] : 0.f;
+            for (int u = 0; u < RU; ++u) {
+                const int tt = t + 4 * u + g;
+                ok[u] = tt < cnt;
+                const int e = __builtin_amdgcn_ds_bpermute(4 * min(tt, cnt - 1), mye);
+                const long o = (long)(e >> 6) * Co + c0;
+                hv[u] = *reinterpret_cast<const f4 *>(hb + o);
+                av[u] = *reinterpret_cast<const unsigned *>(ab + o);
+                sl[u] = ok[u] ? (e & 63) : 255;                        // (no slot is 255: a masked edge never hits)
+                qv[u] = training ? *reinterpret_cast<const f4 *>(Q + (long)(e >> 6) * ld + c0) : f4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (t + u < cnt) {
-                    ah += (av[u] == sl[u]) ? hv[u] : 0.f;
-                    aq += qv[u];
+            for (int u = 0; u < RU; ++u) {
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) ah[e4] += ((int)((av[u] >> (8 * e4)) & 255u) == sl[u]) ? hv[u][e4] : 0.f;
+                if (training) {
+                    const float m = ok[u] ? 1.f : 0.f;
+                    aq[0] += f2{qv[u][0], qv[u][1]} * f2{m, m};
+                    aq[1] += f2{qv[u][2], qv[u][3]} * f2{m, m};
                 }
+            }
         }
     }
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4) {
+        comb[wave][0][g][4 * c16 + e4] = ah[e4];
+        comb[wave][1][g][4 * c16 + e4] = aq[e4 >> 1][e4 & 1];
+    }
+    __builtin_amdgcn_wave_barrier();          // (a wave's own LDS operations complete in order)
+    const int c = cg * 64 + lane;
+    const float ahs = (comb[wave][0][0][lane] + comb[wave][0][1][lane]) + (comb[wave][0][2][lane] + comb[wave][0][3][lane]);
+    const float aqs = (comb[wave][1][0][lane] + comb[wave][1][1][lane]) + (comb[wave][1][2][lane] + comb[wave][1][3][lane]);
     const float r = invstd[c], coef = r * gamma[c], mu = mean[c];
     const long oj = ((long)b * N + j) * Co + c;
-    float dp = ah, dq = h[oj];
+    float dp = ahs, dq = h[oj];
     if (training) {
         const float db = dbeta[c] * invM, dg = dgamma[c] * invM * r;
         const float deg = (float)(end - beg);
-        dp -= deg * db + dg * (deg * (P[(long)j * ld + c] - mu) + aq);
+        dp -= deg * db + dg * (deg * (P[(long)j * ld + c] - mu) + aqs);
         dq -= (float)k * db + dg * (ssum[oj] - (float)k * mu);
     }
     float *gp = grad_pq + ((long)b * N + j) * ld;
@@ -700,7 +772,8 @@ int fsg_ec_stats1_records(int B, int N) { return B * fsg_cdiv(N, TP * TPW); }
 int fsg_ec_stats1_launch(const float *pq, const int32_t *idx, const float *gamma, int B, int N, int k, int Co,
                          float *ysel, uint8_t *arg, float *ssum, float *partials, hipStream_t st) {
     FSG_REQUIRE((long)N * 2 * Co * 4 < (1L << 31), "edgeconv/stats: a cloud's [P | Q] rows must stay below 2 GiB (N=%d, Co=%d)", N, Co);
-    hipLaunchKernelGGL(ec1_stats_select_kernel, dim3(B, fsg_cdiv(N, TP * TPW), Co / 64), dim3(256 * TPW), 0, st, pq, idx,
+    // (statistics + per-point sums only: the selection of a two-layer EdgeConv belongs to its second layer; ysel / arg untouched)
+    hipLaunchKernelGGL(ec1_stats_select_kernel<false>, dim3(B, fsg_cdiv(N, TP * TPW), Co / 64), dim3(256 * TPW), 0, st, pq, idx,
                        gamma, N, k, Co, 1, ysel, arg, ssum, partials);
     FSG_CHECK_LAUNCH("edgeconv/stats");
     return FSG_OK;
@@ -900,7 +973,7 @@ extern "C" int fsg_edgeconv1_fwd_f32(const float *pq, const int32_t *idx, const 
     FSG_REQUIRE((long)N * 2 * Co * 4 < (1L << 31), "fsg_edgeconv1_fwd_f32: a cloud's [P | Q] rows must stay below 2 GiB (N=%d, Co=%d)", N, Co);
     hipStream_t st = (hipStream_t)stream;
     const int tiles = fsg_cdiv(N, TP * TPW);
-    hipLaunchKernelGGL(ec1_stats_select_kernel, dim3(B, tiles, Co / 64), dim3(256 * TPW), 0, st, pq, idx, gamma, N, k, Co,
+    hipLaunchKernelGGL(ec1_stats_select_kernel<true>, dim3(B, tiles, Co / 64), dim3(256 * TPW), 0, st, pq, idx, gamma, N, k, Co,
                        training, ysel, arg, ssum, workspace);
     FSG_CHECK_LAUNCH("fsg_edgeconv1_fwd_f32/stats");
     if (training) {

@@ -481,61 +481,92 @@ __global__ __launch_bounds__(256) void ec2_bwd_kernel(
     }
 }
 
-// one wave per destination point j: dP_j from the in-edges' du1 rows (reverse graph), dQ_j from its own k rows
+// one wave per destination point j: dP_j from the in-edges' du1 rows (reverse graph), dQ_j from its own k rows.  Round 4
+// (edgeconv.hip, ec1_bwd_gather_kernel): a lane owns FOUR channels, group g = lane / 16 takes the rows t = g (mod 4) -- a wave
+// instruction reads four whole 256-byte rows, the sums run on packed fp32 adds, the groups' partial sums meet through LDS in a
+// fixed order ((g0 + g1) + (g2 + g3)): reproducible bit for bit from run to run.
 __global__ __launch_bounds__(256) void ec2_bwd_gather_kernel(
     const float *__restrict__ pq, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ du1, const float *__restrict__ ssum1, const float *__restrict__ gamma1,
     const float *__restrict__ mean1, const float *__restrict__ invstd1, const float *__restrict__ dbeta1,
     const float *__restrict__ dgamma1, int N, int k, int training, float invM, float *__restrict__ grad_pq) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ float comb[4][3][4][C1];          // [wave][ad | aq | own][group][channel]
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: keep it scalar
     const int j = blockIdx.y * 4 + wave;
-    if (j >= N) return;
-    const int c = lane;
+    if (j >= N) return;                          // (wave-uniform; no workgroup barrier below)
+    const int g = lane >> 4, c0 = 4 * (lane & 15);
     const int ld = 2 * C1;
     const float *P = pq + (long)b * N * ld;
     const float *Q = P + C1;
     const int beg = rowptr[(long)b * (N + 1) + j], end = rowptr[(long)b * (N + 1) + j + 1];
     const int32_t *cb = col + (long)b * N * k;
-    float ad = 0.f, aq = 0.f;
+    const float *db_ = du1 + (long)b * N * k * C1;
+    f2 ad[2] = {{0.f, 0.f}, {0.f, 0.f}}, aq[2] = {{0.f, 0.f}, {0.f, 0.f}}, own[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    constexpr int RU = 5;                        // rows in flight per group
+    // the point's own k rows (contiguous): the first round is requested before the in-edge loop, consumed behind it
+    const float *dj = db_ + ((long)j * k) * C1 + c0;
+    f4 ow[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) ow[u] = *reinterpret_cast<const f4 *>(dj + (long)min(4 * u + g, k - 1) * C1);
     for (int t0 = beg; t0 < end; t0 += 64) {
         const int mye = (t0 + lane < end) ? cb[t0 + lane] : 0;
         const int cnt = min(64, end - t0);
-        // eight in-edges per round: the du1 rows come from HBM (84 MB, written by the kernel before), so the number of
-        // independent loads in flight is what this loop costs; the sums keep the edge order (reproducible, same bits)
-        for (int t = 0; t < cnt; t += 8) {
-            float d[8], q[8];
+        // the du1 rows come from HBM (84 MB, written by the kernel before): the number of independent loads in flight is what
+        // this loop costs
+        for (int t = 0; t < cnt; t += 4 * RU) {
+            f4 d[RU], q[RU];
+            float m[RU];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = __builtin_amdgcn_readlane(mye, min(t + u, cnt - 1));
-                const long r = ((long)b * N + (e >> 6)) * k + (e & 63);
-                d[u] = du1[r * C1 + c];
-                q[u] = training ? Q[(long)(e >> 6) * ld + c] : 0.f;
+            for (int u = 0; u < RU; ++u) {
+                const int tt = t + 4 * u + g;
+                m[u] = tt < cnt ? 1.f : 0.f;
+                const int e = __builtin_amdgcn_ds_bpermute(4 * min(tt, cnt - 1), mye);
+                d[u] = *reinterpret_cast<const f4 *>(db_ + ((long)(e >> 6) * k + (e & 63)) * C1 + c0);
+                q[u] = training ? *reinterpret_cast<const f4 *>(Q + (long)(e >> 6) * ld + c0) : f4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (t + u < cnt) {
-                    ad += d[u];
-                    aq += q[u];
+            for (int u = 0; u < RU; ++u) {
+                const f2 mm = {m[u], m[u]};
+                ad[0] += f2{d[u][0], d[u][1]} * mm;
+                ad[1] += f2{d[u][2], d[u][3]} * mm;
+                if (training) {
+                    aq[0] += f2{q[u][0], q[u][1]} * mm;
+                    aq[1] += f2{q[u][2], q[u][3]} * mm;
                 }
+            }
         }
     }
-    float own = 0.f;
-    const float *dj = du1 + (((long)b * N + j) * k) * C1 + c;
-    for (int s0 = 0; s0 < k; s0 += 8) {   // eight rows in flight, summed in slot order
-        float t[8];
+    for (int s0 = 0; s0 < k; s0 += 4 * RU) {
+        if (s0 > 0) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = dj[(long)min(s0 + u, k - 1) * C1];
+            for (int u = 0; u < RU; ++u) ow[u] = *reinterpret_cast<const f4 *>(dj + (long)min(s0 + 4 * u + g, k - 1) * C1);
+        }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (s0 + u < k) own += t[u];
+        for (int u = 0; u < RU; ++u) {
+            const float mk = (s0 + 4 * u + g < k) ? 1.f : 0.f;
+            own[0] += f2{ow[u][0], ow[u][1]} * f2{mk, mk};
+            own[1] += f2{ow[u][2], ow[u][3]} * f2{mk, mk};
+        }
     }
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4) {
+        comb[wave][0][g][c0 + e4] = ad[e4 >> 1][e4 & 1];
+        comb[wave][1][g][c0 + e4] = aq[e4 >> 1][e4 & 1];
+        comb[wave][2][g][c0 + e4] = own[e4 >> 1][e4 & 1];
+    }
+    __builtin_amdgcn_wave_barrier();            // (a wave's own LDS operations complete in order)
+    const int c = lane;
+    auto fold = [&](int w) { return (comb[wave][w][0][c] + comb[wave][w][1][c]) + (comb[wave][w][2][c] + comb[wave][w][3][c]); };
+    const float ads = fold(0), aqs = fold(1), owns = fold(2);
     const float r = invstd1[c], coef = r * gamma1[c], mu = mean1[c];
-    float dp = ad, dq = own;
+    float dp = ads, dq = owns;
     if (training) {
         const float db = dbeta1[c] * invM, dg = dgamma1[c] * invM * r;
         const float deg = (float)(end - beg);
-        dp -= deg * db + dg * (deg * (P[(long)j * ld + c] - mu) + aq);
+        dp -= deg * db + dg * (deg * (P[(long)j * ld + c] - mu) + aqs);
         dq -= (float)k * db + dg * (ssum1[((long)b * N + j) * C1 + c] - (float)k * mu);
     }
     float *gp = grad_pq + ((long)b * N + j) * ld;

@@ -23,3 +23,5 @@ rows=list(csv.DictReader(open(f)))
 for r in rows[:45]:
     print(f"{r['Name'][:84]:84s} {r['Calls']:>6s} {float(r['AverageNs'])/1e3:8.2f} us {float(r['Percentage']):5.2f}%")
 PY
+# the raw trace is hundreds of MB: keep the statistics only (gpurun copies at most 64 MiB back)
+find $GRAFT_REPO_ROOT/gpurun_out/${TAG}_trace -type f ! -name "*kernel_stats.csv" -delete
