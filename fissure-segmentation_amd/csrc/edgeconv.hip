@@ -500,19 +500,36 @@ __global__ __launch_bounds__(256) void ec1_apply_kernel(const float *__restrict_
 // and the graph build starts at its main kernel (one launch and ~11 us less per feature-space graph).  Centre and scale of
 // the image come from the same fixed sample of 64 points (four runs of 16 at 0, N/4, N/2, 3N/4) that every workgroup of the
 // cloud evaluates identically from ysel -- any centre / scale is correct, a representative one keeps the nominee lists short.
+// PQ (round 4): the pass also emits the NEXT EdgeConv's per-point rows pq_next (B, N, 128) = x1 [W_rel | W_ctr - W_rel]^T for
+// the 64 points whose activations it holds in LDS -- the product that used to be a vendor-library GEMM launch (7.3 us + a launch
+// boundary per layer) rides here as 64 x 128 x 64 on v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fma chain per output,
+// reproducible): wave w owns output columns 32 w .. 32 w + 31 for both 32-point halves, the weight is staged transposed in LDS.
 typedef unsigned ec_u32x4 __attribute__((ext_vector_type(4)));
+typedef float ec_f32x16 __attribute__((ext_vector_type(16)));
+template <bool PQ>
 __global__ __launch_bounds__(256) void ec1_apply_prep_kernel(const float *__restrict__ ysel, const float *__restrict__ gamma,
                                                               const float *__restrict__ beta, const float *__restrict__ mean,
                                                               const float *__restrict__ invstd, int N, float slope,
                                                               float *__restrict__ out, float *__restrict__ out_pm,
                                                               float *__restrict__ xx, float *__restrict__ xs,
-                                                              ec_u32x4 *__restrict__ cand, float *__restrict__ cscale) {
-    constexpr int Co = 64, KS = 4;
+                                                              ec_u32x4 *__restrict__ cand, float *__restrict__ cscale,
+                                                              const float *__restrict__ w_next, float *__restrict__ pq_next) {
+    constexpr int Co = 64, KS = 4, CN = 128;
     __shared__ float tile[64][65];
     __shared__ float red[4][64], mu[64], wmax[4];
+    __shared__ float wt[PQ ? 64 : 1][PQ ? CN + 1 : 1];       // w_next transposed: wt[k][n] = w_next[n][k]
     const int b = blockIdx.x, i0 = blockIdx.y * 64;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane;
+    if (PQ) {     // (requested first: the weight is not on this kernel's dependency chain)
+        typedef float f4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int e = threadIdx.x; e < CN * 16; e += 256) {
+            const int n = e >> 4, k4 = 4 * (e & 15);
+            const f4 v = *reinterpret_cast<const f4 *>(w_next + (long)n * Co + k4);
+            wt[k4][n] = v[0]; wt[k4 + 1][n] = v[1]; wt[k4 + 2][n] = v[2]; wt[k4 + 3][n] = v[3];
+        }
+    }
     const float g = gamma[c] * invstd[c], sh = beta[c] - mean[c] * g;
     // the sample: wave w takes sample points 16 w .. 16 w + 15 (one of the four runs), lane = channel
     float sv[16], ssum = 0.f;
@@ -546,6 +563,27 @@ __global__ __launch_bounds__(256) void ec1_apply_prep_kernel(const float *__rest
 #pragma unroll 4
     for (int cc = wave; cc < 64; cc += 4) out[((long)b * Co + cc) * N + i0 + lane] = tile[cc][lane];
     __syncthreads();
+    if (PQ) {
+        // pq_next tile: rows = the 64 points, columns 32 wave .. 32 wave + 31; A = tile (lane m = point, k half = lane / 32),
+        // B = wt (lane n = column); D: lane (n, h) holds rows 8 (e / 4) + 4 h + e % 4
+        const int mn = lane & 31, kk = lane >> 5;
+        ec_f32x16 acc0, acc1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+#pragma unroll 8
+        for (int k0 = 0; k0 < Co; k0 += 2) {
+            const float a0 = tile[k0 + kk][mn], a1 = tile[k0 + kk][32 + mn], bb = wt[k0 + kk][32 * wave + mn];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bb, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bb, acc1, 0, 0, 0);
+        }
+        float *pr = pq_next + ((long)b * N + i0) * CN + 32 * wave + mn;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = 8 * (e >> 2) + 4 * kk + (e & 3);
+            pr[(long)row * CN] = acc0[e];
+            pr[(long)(32 + row) * CN] = acc1[e];
+        }
+    }
     const float maxdev = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
     // power of two that maps the sample's largest deviation into [2^9, 2^10) (as knn_split_prep_kernel)
     int e2 = 9 - ((int)((__float_as_uint(maxdev) >> 23) & 255u) - 127);
@@ -796,7 +834,7 @@ int fsg_knn_split_ws_pointers(void *ws, size_t ws_bytes, int B, int N, int c_knn
 // apply + the next graph build's prep (out_pm required, Co == 64, N % 64 == 0, N inside the coarse-sweep kernel's envelope)
 int fsg_ec_apply_prep_launch(const float *ysel, const float *gamma, const float *beta, const float *mean, const float *invstd,
                              int B, int N, int Co, float slope, float *out, float *out_pm, void *knn_ws, size_t knn_ws_bytes,
-                             hipStream_t st) {
+                             const float *w_next, float *pq_next, hipStream_t st) {
     float *xx, *xs, *cscale;
     void *cand;
     if (Co != 64 || N % 64 != 0 || !out_pm || !out ||
@@ -805,8 +843,12 @@ int fsg_ec_apply_prep_launch(const float *ysel, const float *gamma, const float 
                       "workspace of fsg_knn_dense_workspace_bytes(B, N, 64) bytes inside the coarse-sweep kernel's envelope");
         return FSG_ERR_ARG;
     }
-    hipLaunchKernelGGL(ec1_apply_prep_kernel, dim3(B, N / 64), dim3(256), 0, st, ysel, gamma, beta, mean, invstd, N, slope, out,
-                       out_pm, xx, xs, reinterpret_cast<ec_u32x4 *>(cand), cscale);
+    if (w_next)
+        hipLaunchKernelGGL(ec1_apply_prep_kernel<true>, dim3(B, N / 64), dim3(256), 0, st, ysel, gamma, beta, mean, invstd, N,
+                           slope, out, out_pm, xx, xs, reinterpret_cast<ec_u32x4 *>(cand), cscale, w_next, pq_next);
+    else
+        hipLaunchKernelGGL(ec1_apply_prep_kernel<false>, dim3(B, N / 64), dim3(256), 0, st, ysel, gamma, beta, mean, invstd, N,
+                           slope, out, out_pm, xx, xs, reinterpret_cast<ec_u32x4 *>(cand), cscale, nullptr, nullptr);
     FSG_CHECK_LAUNCH("fsg_edgeconv_apply_f32/prep");
     return FSG_OK;
 }
@@ -999,8 +1041,25 @@ extern "C" int fsg_edgeconv_apply_f32(const float *ysel, const float *gamma, con
     FSG_REQUIRE(B > 0 && N > 0 && Co > 0 && Co % 64 == 0 && B <= 65535, "fsg_edgeconv_apply_f32: bad shape B=%d N=%d Co=%d", B, N, Co);
     if (knn_workspace)
         return fsg_ec_apply_prep_launch(ysel, gamma, beta, mean, invstd, B, N, Co, slope, out, out_pm, knn_workspace,
-                                        knn_workspace_bytes, (hipStream_t)stream);
+                                        knn_workspace_bytes, nullptr, nullptr, (hipStream_t)stream);
     return fsg_ec_apply_launch(ysel, gamma, beta, mean, invstd, B, N, Co, slope, out, out_pm, (hipStream_t)stream);
+}
+
+// fsg_edgeconv_apply_f32 with a knn_workspace, PLUS the per-point rows of the NEXT fused EdgeConv over this block's output:
+// pq_next (B, N, 128) = out_pm w_next^T, w_next (128, 64) row-major = [W_rel ; W_ctr - W_rel] of the next block's first conv
+// (fsg_edge_weights_many_f32) -- the plain GEMM of fsg_edgeconv1_fwd_f32's contract, computed here on the tile the pass holds in
+// LDS (exact fp32 matrix instruction) instead of by a library launch.  Co == 64, N % 64 == 0, both layouts, next width 64.
+extern "C" int fsg_edgeconv_apply_pq_f32(const float *ysel, const float *gamma, const float *beta, const float *mean,
+                                         const float *invstd, int B, int N, int Co, float slope, float *out, float *out_pm,
+                                         void *knn_workspace, size_t knn_workspace_bytes, const float *w_next, int rows_next,
+                                         float *pq_next, fsg_stream_t stream) {
+    FSG_REQUIRE(ysel && gamma && beta && mean && invstd && out && out_pm && knn_workspace && w_next && pq_next,
+                "fsg_edgeconv_apply_pq_f32: NULL pointer");
+    FSG_REQUIRE(B > 0 && N > 0 && Co == 64 && rows_next == 128 && B <= 65535,
+                "fsg_edgeconv_apply_pq_f32: bad shape B=%d N=%d Co=%d rows_next=%d (Co must be 64, the next block 64 wide)", B, N, Co,
+                rows_next);
+    return fsg_ec_apply_prep_launch(ysel, gamma, beta, mean, invstd, B, N, Co, slope, out, out_pm, knn_workspace,
+                                    knn_workspace_bytes, w_next, pq_next, (hipStream_t)stream);
 }
 
 extern "C" int fsg_edgeconv1_bwd_f32(const float *grad_out, const float *grad_out_pm, int64_t ld_pm, const float *grad_out_pm2,

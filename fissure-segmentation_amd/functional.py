@@ -368,6 +368,30 @@ def _bias_grad(g2):
     return g2.sum(0)
 
 
+class _LinearPMGiven(torch.autograd.Function):
+    """y = x W^T whose VALUE another kernel has already computed (the previous EdgeConv's apply pass emits the next block's [P | Q]
+    rows from the tile it holds in LDS: fsg_edgeconv_apply_pq_f32): the forward hands that tensor through, the backward is the
+    ordinary one of the product (dX = dY W, dW = dY^T X)."""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, x, w, value):
+        ctx.save_for_backward(x, w)
+        return value.view_as(value)
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        x2 = x.reshape(-1, x.shape[-1])
+        gx = _linear_dx(g2, w).view_as(x) if ctx.needs_input_grad[0] else None
+        gw = _linear_dw(g2, x2 if x2.is_contiguous() else x2.contiguous()) if ctx.needs_input_grad[1] else None
+        return gx, gw, None
+
+
 def linear_pm(x, w, b=None):
     # (routing the EdgeConvs' per-point P/Q products -- M = B N rows, K = 64, N = 128 -- through fsg_pw_linear_f32 /
     # fsg_pw_tn_f32 was measured SLOWER than the vendor GEMM + split-K pair at these sizes: 1.212 vs 1.183 ms per config-2 step,
@@ -768,10 +792,27 @@ def _pm_grad(g, B, N, C):
     return _f32c(g), C
 
 
+def _apply_pass(ysel, gamma, beta, mean, invstd, B, N, Co, slope, out, out_pm, knn_ws, w_next):
+    """the BatchNorm + LeakyReLU pass of a fused EdgeConv when it also prepares the next layer's graph build (knn_ws) and, with
+    w_next (128, 64), emits the next fused EdgeConv's [P | Q] rows (returned; else None).  Inside a `with torch.cuda.device`."""
+    if knn_ws is None:
+        return None
+    nb = knn_ws.numel() * knn_ws.element_size()
+    if w_next is not None and Co == 64 and tuple(w_next.shape) == (128, 64):
+        w_next = _f32c(w_next.detach())
+        pq_next = torch.empty(B, N, 128, dtype=torch.float32, device=ysel.device)
+        _lib.call("fsg_edgeconv_apply_pq_f32", _p(ysel), _p(gamma), _p(beta), _p(mean), _p(invstd), B, N, Co, slope, _p(out),
+                  _p(out_pm), _p(knn_ws), nb, _p(w_next), 128, _p(pq_next), _stream())
+        return pq_next
+    _lib.call("fsg_edgeconv_apply_f32", _p(ysel), _p(gamma), _p(beta), _p(mean), _p(invstd), B, N, Co, slope, _p(out),
+              _p(out_pm), _p(knn_ws), nb, _stream())
+    return None
+
+
 class _EdgeConv1(torch.autograd.Function):
     @staticmethod
     @_amp_fwd
-    def forward(ctx, pq, idx, gamma, beta, running_mean, running_var, training, momentum, eps, slope, knn_ws=None):
+    def forward(ctx, pq, idx, gamma, beta, running_mean, running_var, training, momentum, eps, slope, knn_ws=None, w_next=None):
         pq = _f32c(pq)
         B, N, two_co = pq.shape
         Co, k, dev = two_co // 2, idx.shape[2], pq.device
@@ -794,19 +835,20 @@ class _EdgeConv1(torch.autograd.Function):
                       _p(running_mean if training else None), _p(running_var if training else None), B, N, k, Co,
                       int(training), momentum, eps, slope, _p(None if knn_ws is not None else out), _p(out_pm), _p(ysel), _p(arg),
                       _p(ssum), _p(mean), _p(invstd), _p(ws), _stream())
-            if knn_ws is not None:     # BatchNorm + LeakyReLU pass that also prepares the next layer's graph build
-                _lib.call("fsg_edgeconv_apply_f32", _p(ysel), _p(gamma), _p(beta), _p(mean), _p(invstd), B, N, Co, slope, _p(out),
-                          _p(out_pm), _p(knn_ws), knn_ws.numel() * knn_ws.element_size(), _stream())
+            pq_next = _apply_pass(ysel, gamma, beta, mean, invstd, B, N, Co, slope, out, out_pm, knn_ws, w_next)
         ctx.save_for_backward(pq, idx, gamma, beta, mean, invstd, ysel, arg, ssum)
         ctx.meta = (B, N, k, Co, bool(training), slope)
         ctx.set_materialize_grads(False)   # the layout that only feeds the next graph build gets None, not a zero tensor
         # the point-major output twice (second one an alias): two consumers -- the next layer and the concatenated
         # features -- then deliver their gradients separately and the backward kernel sums them (no ATen add, no copy)
-        return out, out_pm, out_pm.view(B, N, Co)
+        if pq_next is None:
+            return out, out_pm, out_pm.view(B, N, Co)
+        ctx.mark_non_differentiable(pq_next)     # (its gradient arrives through _LinearPMGiven on out_pm and the weight)
+        return out, out_pm, out_pm.view(B, N, Co), pq_next
 
     @staticmethod
     @_amp_bwd
-    def backward(ctx, g, g_pm, g_pm2):
+    def backward(ctx, g, g_pm, g_pm2, _g_pq_next=None):
         pq, idx, gamma, beta, mean, invstd, ysel, arg, ssum = ctx.saved_tensors
         B, N, k, Co, training, slope = ctx.meta
         dev = pq.device
@@ -824,14 +866,14 @@ class _EdgeConv1(torch.autograd.Function):
                       _p(beta), _p(mean),
                       _p(invstd), _p(ysel), _p(arg), _p(ssum), B, N, k, Co, int(training), slope, _p(gpq), _p(dgamma),
                       _p(dbeta), _p(h), _p(ws), _stream())
-        return gpq, None, dgamma, dbeta, None, None, None, None, None, None, None
+        return gpq, None, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def edgeconv1_supported(out_channels, k):
     return out_channels % 64 == 0 and k <= 64
 
 
-def edgeconv1(x, idx, conv_weight, bn, slope, x_pm=None, both=False, w_cat=None, knn_ws=None):
+def edgeconv1(x, idx, conv_weight, bn, slope, x_pm=None, both=False, w_cat=None, knn_ws=None, w_next=None, pq_given=None):
     """Fused single-layer EdgeConv: x (B,C,N), idx (B,N,k) int32, conv_weight (Co,2C,1,1), bn a BatchNorm2d module
     (its running statistics are updated in place like nn.BatchNorm2d does) -> (B,Co,N); with both=True also the
     point-major copy (B,N,Co).  x_pm: optional point-major (B,N,C) copy of x (saves the transpose for the GEMM)."""
@@ -842,7 +884,10 @@ def edgeconv1(x, idx, conv_weight, bn, slope, x_pm=None, both=False, w_cat=None,
         w_cat = _EdgeWeights.apply(conv_weight.reshape(Co, C2).to(torch.float32))
     if x_pm is None:
         x_pm = x.transpose(1, 2)
-    pq = linear_pm(x_pm.to(torch.float32).contiguous(), w_cat)                   # (B,N,2Co): one plain GEMM
+    if pq_given is not None:    # emitted by the previous block's apply pass (w_next): no GEMM launch, ordinary backward
+        pq = _LinearPMGiven.apply(x_pm.to(torch.float32), w_cat, pq_given)
+    else:
+        pq = linear_pm(x_pm.to(torch.float32).contiguous(), w_cat)               # (B,N,2Co): one plain GEMM
     training = bn.training or bn.running_mean is None
     momentum = 0.0
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
@@ -853,19 +898,18 @@ def edgeconv1(x, idx, conv_weight, bn, slope, x_pm=None, both=False, w_cat=None,
     idx = idx.contiguous()
     if torch.is_grad_enabled() and pq.requires_grad and _ASYNC_CSR:
         prefetch_reverse_graph(idx)
-    out, out_pm, out_pm2 = _EdgeConv1.apply(pq, idx, bn.weight, bn.bias,
-                                            bn.running_mean if (track or not training) else None,
-                                            bn.running_var if (track or not training) else None, training, float(momentum),
-                                            float(bn.eps), float(slope), knn_ws)
-    if both == "twice":      # (B,Co,N), (B,N,Co) and an alias of the latter for a second consumer (see _EdgeConv1)
-        return out, out_pm, out_pm2
-    return (out, out_pm) if both else out
+    res = _EdgeConv1.apply(pq, idx, bn.weight, bn.bias,
+                           bn.running_mean if (track or not training) else None,
+                           bn.running_var if (track or not training) else None, training, float(momentum),
+                           float(bn.eps), float(slope), knn_ws, w_next if knn_ws is not None else None)
+    return _edgeconv_outputs(res, both, w_next is not None)
 
 
 class _EdgeConv2(torch.autograd.Function):
     @staticmethod
     @_amp_fwd
-    def forward(ctx, pq, idx, w2, g1, b1, rm1, rv1, g2, b2, rm2, rv2, training, mom1, mom2, eps1, eps2, slope, knn_ws=None):
+    def forward(ctx, pq, idx, w2, g1, b1, rm1, rv1, g2, b2, rm2, rv2, training, mom1, mom2, eps1, eps2, slope, knn_ws=None,
+                w_next=None):
         pq, w2 = _f32c(pq), _f32c(w2)
         g1, b1, g2, b2 = _f32c(g1), _f32c(b1), _f32c(g2), _f32c(b2)
         B, N, _ = pq.shape
@@ -891,17 +935,18 @@ class _EdgeConv2(torch.autograd.Function):
                       _p(rv1 if t else None), _p(g2), _p(b2), _p(rm2 if t else None), _p(rv2 if t else None), B, N, k, C2,
                       int(t), mom1, mom2, eps1, eps2, slope, _p(None if knn_ws is not None else out), _p(out_pm), _p(ssum1), _p(mean1),
                       _p(invstd1), _p(ysel2), _p(arg2), _p(ssum2), _p(mean2), _p(invstd2), _p(ws), _stream())
-            if knn_ws is not None:     # BatchNorm + LeakyReLU pass that also prepares the next layer's graph build
-                _lib.call("fsg_edgeconv_apply_f32", _p(ysel2), _p(g2), _p(b2), _p(mean2), _p(invstd2), B, N, C2, slope, _p(out),
-                          _p(out_pm), _p(knn_ws), knn_ws.numel() * knn_ws.element_size(), _stream())
+            pq_next = _apply_pass(ysel2, g2, b2, mean2, invstd2, B, N, C2, slope, out, out_pm, knn_ws, w_next)
         ctx.save_for_backward(pq, idx, w2, g1, b1, mean1, invstd1, ssum1, g2, b2, mean2, invstd2, ysel2, arg2)
         ctx.meta = (B, N, k, C2, t, slope)
         ctx.set_materialize_grads(False)
-        return out, out_pm, out_pm.view(B, N, C2)    # alias for a second consumer, see _EdgeConv1
+        if pq_next is None:
+            return out, out_pm, out_pm.view(B, N, C2)    # alias for a second consumer, see _EdgeConv1
+        ctx.mark_non_differentiable(pq_next)
+        return out, out_pm, out_pm.view(B, N, C2), pq_next
 
     @staticmethod
     @_amp_bwd
-    def backward(ctx, g, g_pm, g_pm2):
+    def backward(ctx, g, g_pm, g_pm2, _g_pq_next=None):
         pq, idx, w2, g1, b1, mean1, invstd1, ssum1, g2, b2, mean2, invstd2, ysel2, arg2 = ctx.saved_tensors
         B, N, k, C2, training, slope = ctx.meta
         dev = pq.device
@@ -920,7 +965,7 @@ class _EdgeConv2(torch.autograd.Function):
                       _p(b1), _p(mean1), _p(invstd1), _p(ssum1), _p(g2), _p(b2), _p(mean2), _p(invstd2), _p(ysel2),
                       _p(arg2), B, N, k, C2, int(training), slope, _p(gpq), _p(gw2), _p(dg1), _p(db1), _p(dg2), _p(db2),
                       _p(ws), _stream())
-        return (gpq, None, gw2, dg1, db1, None, None, dg2, db2) + (None,) * 9
+        return (gpq, None, gw2, dg1, db1, None, None, dg2, db2) + (None,) * 10
 
 
 def edgeconv2_supported(c_mid, c_out, k):
@@ -936,7 +981,24 @@ def _bn_step(bn):
     return training, float(momentum)
 
 
-def edgeconv2(x, idx, conv1_weight, bn1, conv2_weight, bn2, slope, x_pm=None, both=False, w_cat=None, knn_ws=None):
+def _edgeconv_outputs(res, both, want_pq_next):
+    """(out, out_pm, alias[, pq_next]) of a fused EdgeConv Function -> what the module interface hands out; with w_next given the
+    next block's rows come last (None when the pass could not emit them: no knn workspace, other widths)"""
+    out, out_pm, out_pm2 = res[:3]
+    pq_next = res[3] if len(res) > 3 else None
+    if both == "twice":      # (B,Co,N), (B,N,Co) and an alias of the latter for a second consumer (see _EdgeConv1)
+        r = (out, out_pm, out_pm2)
+    elif both:
+        r = (out, out_pm)
+    else:
+        r = (out,)
+    if want_pq_next:
+        return r + (pq_next,)
+    return r if len(r) > 1 else r[0]
+
+
+def edgeconv2(x, idx, conv1_weight, bn1, conv2_weight, bn2, slope, x_pm=None, both=False, w_cat=None, knn_ws=None, w_next=None,
+              pq_given=None):
     """Fused two-layer EdgeConv (2C -> 64 -> 64|128): see csrc/edgeconv2.hip."""
     _need_gpu(x, idx, conv1_weight, conv2_weight)
     C1, CC = conv1_weight.shape[0], conv1_weight.shape[1]
@@ -945,7 +1007,10 @@ def edgeconv2(x, idx, conv1_weight, bn1, conv2_weight, bn2, slope, x_pm=None, bo
         w_cat = _EdgeWeights.apply(conv1_weight.reshape(C1, CC).to(torch.float32))
     if x_pm is None:
         x_pm = x.transpose(1, 2)
-    pq = linear_pm(x_pm.to(torch.float32).contiguous(), w_cat)                   # (B,N,128)
+    if pq_given is not None:
+        pq = _LinearPMGiven.apply(x_pm.to(torch.float32), w_cat, pq_given)
+    else:
+        pq = linear_pm(x_pm.to(torch.float32).contiguous(), w_cat)               # (B,N,128)
     w2 = conv2_weight.reshape(conv2_weight.shape[0], C1)
     t1, m1 = _bn_step(bn1)
     t2, m2 = _bn_step(bn2)
@@ -956,12 +1021,10 @@ def edgeconv2(x, idx, conv1_weight, bn1, conv2_weight, bn2, slope, x_pm=None, bo
     idx = idx.contiguous()
     if torch.is_grad_enabled() and pq.requires_grad and _ASYNC_CSR:
         prefetch_reverse_graph(idx)
-    out, out_pm, out_pm2 = _EdgeConv2.apply(pq, idx, w2, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
-                                            bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, t1, m1, m2,
-                                            float(bn1.eps), float(bn2.eps), float(slope), knn_ws)
-    if both == "twice":
-        return out, out_pm, out_pm2
-    return (out, out_pm) if both else out
+    res = _EdgeConv2.apply(pq, idx, w2, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
+                           bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, t1, m1, m2,
+                           float(bn1.eps), float(bn2.eps), float(slope), knn_ws, w_next if knn_ws is not None else None)
+    return _edgeconv_outputs(res, both, w_next is not None)
 
 
 # ------------------------------------------------------------------ point-wise layers on the bf16 matrix pipe, fp32-grade

@@ -93,11 +93,13 @@ class EdgeConv(nn.Module):
         it = iter(ws)
         return [next(it) if b.fused else None for b in blocks]
 
-    def forward(self, x, fixed_knn_graph=None, x_pm=None, both=False, w_cat=None, knn_ws=None):
+    def forward(self, x, fixed_knn_graph=None, x_pm=None, both=False, w_cat=None, knn_ws=None, w_next=None, pq_given=None):
         """x (B,C,N) -> (B,Cout,N) like the reference; `both=True` additionally returns the point-major copy
         (B,N,Cout) that the point-wise head consumes (`both="twice"`: that copy twice, for two consumers), `x_pm` is an
         optional point-major copy of the input, `knn_ws` a workspace in which the last pass of a fused block prepares the
-        NEXT layer's graph build over this block's output (functional.knn_prep_workspace)."""
+        NEXT layer's graph build over this block's output (functional.knn_prep_workspace); `w_next` (with knn_ws): the P/Q weight
+        of the NEXT fused block -- its [P | Q] rows are then emitted by this block's last pass and returned as one more output
+        (None if the pass cannot), to be handed to the next block as `pq_given` (no GEMM launch for its first conv)."""
         if len(self.shared_mlp) == 1 and len(self.shared_mlp[0].layers) == 3 and \
                 F_hip.edgeconv1_supported(self.shared_mlp[0].layers[0].out_channels, self.k):
             # fused path: no (B,2C,N,k) / (B,Cout,N,k) tensor is ever written (csrc/edgeconv.hip)
@@ -106,7 +108,7 @@ class EdgeConv(nn.Module):
                 graph = F_hip.knn_graph(x, self.k, c_knn=3 if self.first_layer else None, fix_diag=True)
             conv, bn, act = self.shared_mlp[0].layers
             return F_hip.edgeconv1(x, graph, conv.weight, bn, act.negative_slope, x_pm=x_pm, both=both, w_cat=w_cat,
-                                   knn_ws=knn_ws)
+                                   knn_ws=knn_ws, w_next=w_next, pq_given=pq_given)
         if len(self.shared_mlp) == 2 and all(len(m.layers) == 3 for m in self.shared_mlp) and \
                 F_hip.edgeconv2_supported(self.shared_mlp[0].layers[0].out_channels,
                                           self.shared_mlp[1].layers[0].out_channels, self.k):
@@ -115,7 +117,7 @@ class EdgeConv(nn.Module):
                 graph = F_hip.knn_graph(x, self.k, c_knn=3 if self.first_layer else None, fix_diag=True)
             (conv1, bn1, act), (conv2, bn2, _) = self.shared_mlp[0].layers, self.shared_mlp[1].layers
             return F_hip.edgeconv2(x, graph, conv1.weight, bn1, conv2.weight, bn2, act.negative_slope, x_pm=x_pm,
-                                   both=both, w_cat=w_cat, knn_ws=knn_ws)
+                                   both=both, w_cat=w_cat, knn_ws=knn_ws, w_next=w_next, pq_given=pq_given)
         e = create_neighbor_features(x, self.k, fixed_knn_graph, knn_only_over_coords=self.first_layer)
         for layer in self.shared_mlp:
             e = layer(e)
@@ -280,11 +282,12 @@ class DGCNNSeg(DGCNNBase):
             # norms and the coarse operand image of its output on the way (one launch less per build)
             ws2, ws3 = F_hip.knn_prep_workspace(B, N, 64, x.device), F_hip.knn_prep_workspace(B, N, 64, x.device)
             g1 = F_hip.knn_graph(x, self.k, c_knn=3, fix_diag=True, out=graphs[0])
-            x1, p1, p1c = self.ec1(x, g1, both="twice", w_cat=w1, knn_ws=ws2)
+            # (the apply pass of a block also emits the NEXT block's [P | Q] rows from the tile it holds in LDS: w_next / pq_given)
+            x1, p1, p1c, pq2 = self.ec1(x, g1, both="twice", w_cat=w1, knn_ws=ws2, w_next=w2)
             g2 = F_hip.knn_graph(x1, self.k, fix_diag=True, out=graphs[1], prepared=None if ws2 is None else (ws2, p1))
-            x2, p2, p2c = self.ec2(x1, g2, x_pm=p1, both="twice", w_cat=w2, knn_ws=ws3)
+            x2, p2, p2c, pq3 = self.ec2(x1, g2, x_pm=p1, both="twice", w_cat=w2, knn_ws=ws3, w_next=w3, pq_given=pq2)
             g3 = F_hip.knn_graph(x2, self.k, fix_diag=True, out=graphs[2], prepared=None if ws3 is None else (ws3, p2))
-            _, p3 = self.ec3(x2, g3, x_pm=p2, both=True, w_cat=w3)
+            _, p3 = self.ec3(x2, g3, x_pm=p2, both=True, w_cat=w3, pq_given=pq3)
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
                 F_hip.build_reverse_graphs([g1, g2, g3])
         else:

@@ -150,6 +150,18 @@ int fsg_edgeconv_apply_f32(const float *ysel, const float *gamma, const float *b
                            size_t knn_workspace_bytes, fsg_stream_t stream);
 
 /*
+ * The same pass (knn_workspace required) that ALSO emits the per-point rows of the next fused EdgeConv over this block's
+ * output: pq_next (B, N, rows_next) = out_pm w_next^T with w_next (rows_next, Co) row-major = the [W_rel ; W_ctr - W_rel] weight
+ * of the next block's first conv (fsg_edge_weights_many_f32) -- the "one plain GEMM" of fsg_edgeconv{1,2}_fwd_f32's contract
+ * (models/dgcnn.py:212-243: the next EdgeConv's first 1x1 conv, decomposed per point), computed on the tile the pass holds in
+ * LDS by the exact fp32 matrix instruction instead of by a library launch.  Co == 64, rows_next == 128, N % 64 == 0.
+ */
+int fsg_edgeconv_apply_pq_f32(const float *ysel, const float *gamma, const float *beta, const float *mean, const float *invstd,
+                              int B, int N, int Co, float slope, float *out, float *out_pm, void *knn_workspace,
+                              size_t knn_workspace_bytes, const float *w_next, int rows_next, float *pq_next,
+                              fsg_stream_t stream);
+
+/*
  * Fused EdgeConv with ONE shared-MLP layer: replaces models/dgcnn.py:234-241 (gather, 1x1 Conv2d, BatchNorm2d,
  * LeakyReLU, max over k) and the get_graph_feature -> conv -> max blocks of models/folding_net.py:120-133.
  * The caller supplies the per-point rows of the decomposed conv (W = [W_rel | W_ctr]):
