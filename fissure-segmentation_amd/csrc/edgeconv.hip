@@ -413,41 +413,72 @@ __global__ __launch_bounds__(512) void ec1_stats_select_kernel(const float *__re
 //   A = sum n, Bm = sum n*mean, Cm = sum (M2 + n*mean^2) over the records, then mean = Bm/A, M2 = Cm - Bm^2/A (fp64: the
 //   subtraction is benign), invstd, running-statistics update.  (A 64-thread workgroup reading all records alone took
 //   22 us for 1024 records: load latency, one record in flight per lane.)
-constexpr int FIN_S = 16;
+constexpr int FIN_S = 16;   // (slices of the first version: still sizes the unused stage area behind the records)
 
-// One launch: a 1024-thread workgroup per 64 channels; sixteen 64-lane groups stride over the records (Chan's merge in
-// fp64), the sixteen partial triples meet in LDS and the first group finalises.  (Two launches -- 16 workgroups of
-// partial sums, then a merge -- cost one more ~4 us dependent-launch boundary per BatchNorm.)
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restrict__ partials, int R, int Co, float eps,
-                                                            float momentum, float *__restrict__ mean_out,
-                                                            float *__restrict__ invstd_out,
-                                                            float *__restrict__ running_mean,
-                                                            float *__restrict__ running_var) {
-    __shared__ double red[3][FIN_S][64];
-    const int lane = threadIdx.x & 63, sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = blockIdx.x * 64 + lane;
+// One launch, ONE memory round trip per thread (round 4): a 1024-thread workgroup owns EIGHT channels, 128 slices of threads
+// stride over the records -- at the 512 records of a config-2 EdgeConv a thread reads four records (12 loads requested together),
+// where the first version (64 channels per workgroup, 16 slices) walked 32 records in eight dependent batches: 7.5 us for a
+// kernel that adds 393 KB, most of it L2 / Infinity-Cache round trips one behind the other, on ONE CU.  Eight workgroups (64
+// channels) now run beside each other, each finalising its own channels: no second stage.  Sums in fp64, folded in LDS in a
+// fixed order (reproducible).
+constexpr int FIN_CH = 8, FIN_SL = 128;
+__global__ __launch_bounds__(FIN_CH * FIN_SL) void bn_finalize_kernel(const float *__restrict__ partials, int R, int Co,
+                                                                      float eps, float momentum,
+                                                                      float *__restrict__ mean_out,
+                                                                      float *__restrict__ invstd_out,
+                                                                      float *__restrict__ running_mean,
+                                                                      float *__restrict__ running_var) {
+    __shared__ double red[3][FIN_SL][FIN_CH];
+    const int ch = threadIdx.x & (FIN_CH - 1), sl = threadIdx.x / FIN_CH;
+    const int c = blockIdx.x * FIN_CH + ch;
     double a = 0.0, bm = 0.0, cm = 0.0;
-#pragma unroll 4
-    for (int r = sub; r < R; r += FIN_S) {
-        const float *pr = partials + (long)r * 3 * Co;
-        const double n = pr[c], mu = pr[Co + c];
-        a += n;
-        bm += n * mu;
-        cm += (double)pr[2 * Co + c] + n * mu * mu;
+    for (int r0 = sl; r0 < R; r0 += 4 * FIN_SL) {       // four records per round: their loads go out together
+        float nv[4], mv[4], qv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = min(r0 + u * FIN_SL, R - 1);
+            const float *pr = partials + (long)r * 3 * Co + c;
+            nv[u] = pr[0];
+            mv[u] = pr[Co];
+            qv[u] = pr[2 * Co];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (r0 + u * FIN_SL < R) {
+                const double n = nv[u], mu = mv[u];
+                a += n;
+                bm += n * mu;
+                cm += (double)qv[u] + n * mu * mu;
+            }
     }
-    red[0][sub][lane] = a;
-    red[1][sub][lane] = bm;
-    red[2][sub][lane] = cm;
+    red[0][sl][ch] = a;
+    red[1][sl][ch] = bm;
+    red[2][sl][ch] = cm;
     __syncthreads();
-    if (sub != 0) return;
+    // fold the 128 slices: 16 threads per channel take 8 slices each, then one thread per channel the 16 partial sums
+    __shared__ double red2[3][16][FIN_CH];
+    if (sl < 16) {
+        double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            x0 += red[0][8 * sl + u][ch];
+            x1 += red[1][8 * sl + u][ch];
+            x2 += red[2][8 * sl + u][ch];
+        }
+        red2[0][sl][ch] = x0;
+        red2[1][sl][ch] = x1;
+        red2[2][sl][ch] = x2;
+    }
+    __syncthreads();
+    if (sl != 0) return;
     double n = 0.0;
     bm = 0.0;
     cm = 0.0;
 #pragma unroll
-    for (int s2 = 0; s2 < FIN_S; ++s2) {
-        n += red[0][s2][lane];
-        bm += red[1][s2][lane];
-        cm += red[2][s2][lane];
+    for (int s2 = 0; s2 < 16; ++s2) {
+        n += red2[0][s2][ch];
+        bm += red2[1][s2][ch];
+        cm += red2[2][s2][ch];
     }
     const double mu = n > 0.0 ? bm / n : 0.0;
     double M2 = n > 0.0 ? cm - bm * mu : 0.0;
@@ -698,22 +729,36 @@ __global__ __launch_bounds__(256) void ec1_bwd_point_kernel(const float *__restr
 // sums R records of `nvec` vectors of Co floats in fp64: out[v][c].  Sixteen 64-lane slices per 64 channels stride over the
 // records (with four slices a thread walked R/4 records one dependent L2 round trip after the other: 11 us at R = 1024),
 // merged in slice order -- fixed order, reproducible
-constexpr int SUMP_SLICES = 16;
-__global__ __launch_bounds__(64 * SUMP_SLICES) void sum_partials_kernel(const float *__restrict__ partials, int R, int Co,
-                                                                        int nvec, float *__restrict__ out0,
-                                                                        float *__restrict__ out1) {
-    __shared__ double red[SUMP_SLICES][64];
-    const int lane = threadIdx.x & 63, slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = blockIdx.x * 64 + lane, v = blockIdx.y;
+constexpr int SUMP_CH = 16, SUMP_SLICES = 64;   // round 4: 16 channels x 64 slices per workgroup (was 64 x 16): at 256 records a
+// thread reads four of them in ONE batch, and four workgroups per vector run beside each other
+__global__ __launch_bounds__(SUMP_CH * SUMP_SLICES) void sum_partials_kernel(const float *__restrict__ partials, int R, int Co,
+                                                                             int nvec, float *__restrict__ out0,
+                                                                             float *__restrict__ out1) {
+    __shared__ double red[SUMP_SLICES][SUMP_CH];
+    const int ch = threadIdx.x & (SUMP_CH - 1), slice = threadIdx.x / SUMP_CH;
+    const int c = blockIdx.x * SUMP_CH + ch, v = blockIdx.y;
     double acc = 0.0;
-#pragma unroll 4
-    for (int r = slice; r < R; r += SUMP_SLICES) acc += partials[((long)r * nvec + v) * Co + c];
-    red[slice][lane] = acc;
+    for (int r0 = slice; r0 < R; r0 += 4 * SUMP_SLICES) {
+        float t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = partials[((long)min(r0 + u * SUMP_SLICES, R - 1) * nvec + v) * Co + c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (r0 + u * SUMP_SLICES < R) acc += t[u];
+    }
+    red[slice][ch] = acc;
+    __syncthreads();
+    if (slice < 8) {           // eight threads per channel fold eight slices each, the first folds the eight partial sums
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += red[8 * slice + w][ch];
+        red[8 * slice][ch] = t;
+    }
     __syncthreads();
     if (slice == 0) {
-        double t = red[0][lane];
+        double t = 0.0;
 #pragma unroll
-        for (int w = 1; w < SUMP_SLICES; ++w) t += red[w][lane];
+        for (int w = 0; w < 8; ++w) t += red[8 * w][ch];
         (v == 0 ? out0 : out1)[c] = (float)t;
     }
 }
@@ -822,7 +867,7 @@ size_t fsg_ec_finalize_stage_floats(int Co) { return (size_t)FIN_S * 3 * Co * 2 
 
 int fsg_ec_finalize_launch(const float *partials, int R, int Co, float eps, float momentum, float *mean, float *invstd,
                            float *running_mean, float *running_var, hipStream_t st) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(Co / 64), dim3(1024), 0, st, partials, R, Co, eps, momentum, mean, invstd,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(Co / FIN_CH), dim3(FIN_CH * FIN_SL), 0, st, partials, R, Co, eps, momentum, mean, invstd,
                        running_mean, running_var);
     FSG_CHECK_LAUNCH("edgeconv/finalize");
     return FSG_OK;
@@ -870,14 +915,14 @@ int fsg_ec_bwd_point_launch(const float *gout, const float *gout_pm, long ld_pm,
                        ld_pm2, ysel, gamma,
                        beta, mean, invstd, N, Co, slope, h, partials);
     FSG_CHECK_LAUNCH("edgeconv/bwd_point");
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(Co / 64, 2), dim3(64 * SUMP_SLICES), 0, st, partials, B * tiles64, Co, 2, dbeta,
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(Co / SUMP_CH, 2), dim3(SUMP_CH * SUMP_SLICES), 0, st, partials, B * tiles64, Co, 2, dbeta,
                        dgamma);
     FSG_CHECK_LAUNCH("edgeconv/bwd_sum");
     return FSG_OK;
 }
 
 int fsg_ec_sum_launch(const float *partials, int R, int L, int nvec, float *out0, float *out1, hipStream_t st) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(L / 64, nvec), dim3(64 * SUMP_SLICES), 0, st, partials, R, L, nvec, out0, out1);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(L / SUMP_CH, nvec), dim3(SUMP_CH * SUMP_SLICES), 0, st, partials, R, L, nvec, out0, out1);
     FSG_CHECK_LAUNCH("edgeconv/sum");
     return FSG_OK;
 }
@@ -1081,7 +1126,7 @@ extern "C" int fsg_edgeconv1_bwd_f32(const float *grad_out, const float *grad_ou
     hipLaunchKernelGGL(ec1_bwd_point_kernel, dim3(B, tiles64, Co / 64), dim3(256), 0, st, grad_out, grad_out_pm, (long)ld_pm,
                        grad_out_pm2, (long)ld_pm2, ysel, gamma, beta, mean, invstd, N, Co, slope, h_scratch, workspace);
     FSG_CHECK_LAUNCH("fsg_edgeconv1_bwd_f32/point");
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(Co / 64, 2), dim3(64 * SUMP_SLICES), 0, st, workspace, B * tiles64, Co, 2, grad_beta,
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(Co / SUMP_CH, 2), dim3(SUMP_CH * SUMP_SLICES), 0, st, workspace, B * tiles64, Co, 2, grad_beta,
                        grad_gamma);
     FSG_CHECK_LAUNCH("fsg_edgeconv1_bwd_f32/sum");
     const float invM = 1.0f / ((float)B * (float)N * (float)k);
