@@ -936,14 +936,25 @@ extern "C" int fsg_debug_knn_refine_stamps(unsigned long long *out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(fsg_knn_refine_stamps), sizeof(fsg_knn_refine_stamps)) != hipSuccess;
 }
 
-template <int KS, bool PACK, bool HALF, bool RES>
+// RAW (<= 4 channels, 64 tiles, the coordinate build of DGCNN-seg): no prep launch at all -- the kernel reads the (B, C, N) points
+// themselves: a wave builds its eight operand tiles (two bf16 pieces per coordinate) and their squared norms in registers / LDS
+// from three coalesced loads per tile, the workgroup writes the point-major rows and norms of its OWN 64 points for the refine
+// launch (the 256 workgroups of a cloud cover it), the slow path evaluates its distances from the points directly.
+struct RawPoints {
+    const float *x;      // (B, C, N): x[b sb + c sc + j], 16-byte aligned rows
+    long sb, sc;
+    int c_knn;
+    float *xx_out, *xt_out;   // (B, Np) squared norms, (B, Np, 4) point-major rows: what the refine launch reads
+};
+template <int KS, bool PACK, bool HALF, bool RES, bool RAW>
 __global__ __launch_bounds__(WAVES * 64, 2) void knn_nominate_kernel(const float *__restrict__ xx, const float *__restrict__ xt,
                                                                      const u32x4 *__restrict__ cand,
                                                                      const float *__restrict__ xsg,
                                                                      const float *__restrict__ cscale, int N, int Np, int k,
                                                                      int flags, int PCAP, unsigned *__restrict__ bmg,
                                                                      int TS, int32_t *__restrict__ idx_out,
-                                                                     float *__restrict__ dist_out) {
+                                                                     float *__restrict__ dist_out, const RawPoints raw) {
+    static_assert(!RAW || (PACK && !HALF && RES), "RAW: the packed three-product form with resident tiles");
     constexpr int CP = PACK ? 4 : 16 * KS;
     constexpr bool PK3 = PACK && !HALF;
     constexpr int NOP = PK3 ? 1 : KS;
@@ -1014,13 +1025,45 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_nominate_kernel(const float
     float *xsw = xs + wave * TWC * 32;
     const int nsl = lane >> 3, npc = 4 * (lane & 7);   // this lane's tile slot (of 8 per round) and piece of its 32 norms
     f32x4 v0 = {INFINITY, INFINITY, INFINITY, INFINITY}, vo0 = v0;
+    const float *xrb = RAW ? raw.x + (long)b * raw.sb : nullptr;
+    // RAW: the oracle's squared norm (channel-ordered fma chain from +0; channels >= c_knn read as 0: fma(0, 0, a) = a) of 4 points
+    auto raw_norm4 = [&](int j) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < raw.c_knn) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(xrb + c * raw.sc + j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = __builtin_fmaf(v[e], v[e], a[e]);
+            }
+        }
+        return a;
+    };
     if (nsl < TW) {
-        v0 = *reinterpret_cast<const f32x4 *>(xsb + 32 * (wave + WAVES * nsl) + npc);
+        if (RAW) {
+            v0 = raw_norm4(32 * (wave + WAVES * nsl) + npc);
+        } else {
+            v0 = *reinterpret_cast<const f32x4 *>(xsb + 32 * (wave + WAVES * nsl) + npc);
+        }
         vo0 = v0;
         if (HALF) vo0 = *reinterpret_cast<const f32x4 *>(xxb + 32 * (wave + WAVES * nsl) + npc);
     }
-    // the oracle's norm of this lane's query of the tau phase (eight lanes per query)
-    const float xo_q = xxb[min(q0 + wave * QW + (lane >> 3), Np - 1)];
+    // the oracle's norm of this lane's query of the tau phase (eight lanes per query; the fp16 form's bound needs it)
+    const float xo_q = HALF ? xxb[min(q0 + wave * QW + (lane >> 3), Np - 1)] : 0.f;
+    // RAW: hi / lo bf16 pieces of point 32 t + (lane % 32), packed two channels per word
+    auto raw_pieces = [&](int t, unsigned (&hi)[2], unsigned (&lo)[2]) {
+        unsigned hh[4] = {0u, 0u, 0u, 0u}, ll[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < raw.c_knn) {
+                const Split sp = split2(xrb[c * raw.sc + 32 * t + n]);
+                hh[c] = sp.hi;
+                ll[c] = sp.lo;
+            }
+        }
+        hi[0] = hh[0] | (hh[1] << 16); hi[1] = hh[2] | (hh[3] << 16);
+        lo[0] = ll[0] | (ll[1] << 16); lo[1] = ll[2] | (ll[3] << 16);
+    };
     auto neg2 = [](u32x4 w) {
         u32x4 r;
 #pragma unroll
@@ -1034,6 +1077,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_nominate_kernel(const float
         if (HALF) {
 #pragma unroll
             for (int s = 0; s < NOP; ++s) qo[bk].hi[s] = p[s * 64];
+        } else if (RAW) {     // query block: lane (m, 0) = [hi | lo], lane (m, 1) = [hi | 0]
+            unsigned hi[2], lo[2];
+            raw_pieces(q0 / 32 + bk, hi, lo);
+            qo[bk].hi[0] = h == 0 ? u32x4{hi[0], hi[1], lo[0], lo[1]} : u32x4{hi[0], hi[1], 0u, 0u};
         } else if (PACK) {
             const u32x4 mine = p[0], other = p[(lane ^ 32) - lane];
             u32x4 q;
@@ -1051,7 +1098,29 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_nominate_kernel(const float
     OpsT tiles[RES ? RT : 1];
     if (RES) {
 #pragma unroll
-        for (int i = 0; i < RT; ++i) load_tile(tiles[i], tile_of(i));
+        for (int i = 0; i < RT; ++i) {
+            if (RAW) {        // candidate block: lane (m, 0) = [hi | hi], lane (m, 1) = [lo | 0]
+                unsigned hi[2], lo[2];
+                raw_pieces(tile_of(i), hi, lo);
+                tiles[i].hi[0] = h == 0 ? u32x4{hi[0], hi[1], hi[0], hi[1]} : u32x4{lo[0], lo[1], 0u, 0u};
+            } else {
+                load_tile(tiles[i], tile_of(i));
+            }
+        }
+    }
+    if (RAW && wave == 0) {   // this workgroup's own 64 points for the refine launch: point-major rows + norms
+        const int j = q0 + lane;
+        f32x4 row = {0.f, 0.f, 0.f, 0.f};
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < raw.c_knn) {
+                row[c] = xrb[c * raw.sc + j];
+                a = __builtin_fmaf(row[c], row[c], a);
+            }
+        }
+        *reinterpret_cast<f32x4 *>(raw.xt_out + ((long)b * Np + j) * 4) = row;
+        raw.xx_out[(long)b * Np + j] = a;
     }
     float mx = 0.f, mo = 0.f;
     bool outlier = false;
@@ -1376,21 +1445,44 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_nominate_kernel(const float
     while (sm) {
         const int q = __builtin_ctzll(sm);
         sm &= sm - 1;
+        // (RAW: rows and norms straight from the (B, C, N) points; other workgroups' point-major rows are not visible here)
+        auto raw_row = [&](int j, float &nrm) {
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
+            nrm = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c < raw.c_knn) {
+                    r[c] = xrb[c * raw.sc + j];
+                    nrm = __builtin_fmaf(r[c], r[c], nrm);
+                }
+            }
+            return r;
+        };
         const float *qr = xtb + (long)(q0 + q) * CP;
-        const float xq = xxb[q0 + q];
+        float xq = 0.f;
+        f32x4 qraw = {0.f, 0.f, 0.f, 0.f};
+        if (RAW) qraw = raw_row(q0 + q, xq);
+        else xq = xxb[q0 + q];
         __syncthreads();                            // the previous round's (and the sweeps') readers of the overlaid storage
         for (int j = tid; j < N; j += WAVES * 64) {
             const float *row = xtb + (long)j * CP;
-            float dot = 0.f;
-#pragma unroll 4
-            for (int c4 = 0; c4 < CP / 4; ++c4) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(row + 4 * c4);
-                const f32x4 qv = *reinterpret_cast<const f32x4 *>(qr + 4 * c4);
+            float dot = 0.f, xj = 0.f;
+            if (RAW) {
+                const f32x4 v = raw_row(j, xj);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dot = __builtin_fmaf(qv[e], v[e], dot);
+                for (int e = 0; e < 4; ++e) dot = __builtin_fmaf(qraw[e], v[e], dot);
+            } else {
+#pragma unroll 4
+                for (int c4 = 0; c4 < CP / 4; ++c4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(row + 4 * c4);
+                    const f32x4 qv = *reinterpret_cast<const f32x4 *>(qr + 4 * c4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dot = __builtin_fmaf(qv[e], v[e], dot);
+                }
+                xj = xxb[j];
             }
             const float tt = xq - 2.0f * dot;
-            float d = tt + xxb[j];
+            float d = tt + xj;
             if (fix_diag && j == q0 + q) d = 0.f;
             dl[j] = d;
         }
@@ -1892,7 +1984,7 @@ int fsg_knn_split_launch_ex(const float *x, const float *prepared_xt, int B, int
 #define FSG_KNN_SPLIT(KSV, PK, HF)                                                                                      \
     do {                                                                                                               \
         static FsgLdsGrant grant;                                                                                     \
-        if (!grant.raise((const void *)knn_nominate_kernel<KSV, PK, HF, false>, 160 * 1024)) {                        \
+        if (!grant.raise((const void *)knn_nominate_kernel<KSV, PK, HF, false, false>, 160 * 1024)) {                        \
             fsg_set_error("fsg_knn_dense_ws_f32: cannot raise dynamic LDS");                                          \
             return FSG_ERR_HIP;                                                                                       \
         }                                                                                                             \
@@ -1900,17 +1992,27 @@ int fsg_knn_split_launch_ex(const float *x, const float *prepared_xt, int B, int
             hipLaunchKernelGGL((knn_split_prep_kernel<KSV, PK, HF>), pgrid, dim3(256), 0, st, x, N, p.Np,              \
                                (long)stride_b, (long)stride_c, c_knn, xx, xt, cand, xs, cscale);                       \
         if (res && ((HF && KSV <= 4) || PK))                                                                           \
-            hipLaunchKernelGGL((knn_nominate_kernel<KSV, PK, HF, ((HF && KSV <= 4) || PK)>), grid, dim3(WAVES * 64),   \
-                               lds1, st, xx, xt, cand, xs, cscale, N, p.Np, k, flags, PCAP, bmg, TS, idx_out, dist_out); \
+            hipLaunchKernelGGL((knn_nominate_kernel<KSV, PK, HF, ((HF && KSV <= 4) || PK), false>), grid,              \
+                               dim3(WAVES * 64), lds1, st, xx, xt, cand, xs, cscale, N, p.Np, k, flags, PCAP, bmg, TS,  \
+                               idx_out, dist_out, RawPoints{});                                                        \
         else                                                                                                           \
-            hipLaunchKernelGGL((knn_nominate_kernel<KSV, PK, HF, false>), grid, dim3(WAVES * 64), lds1, st, xx, xt,    \
-                               cand, xs, cscale, N, p.Np, k, flags, PCAP, bmg, TS, idx_out, dist_out);                 \
+            hipLaunchKernelGGL((knn_nominate_kernel<KSV, PK, HF, false, false>), grid, dim3(WAVES * 64), lds1, st, xx, \
+                               xt, cand, xs, cscale, N, p.Np, k, flags, PCAP, bmg, TS, idx_out, dist_out, RawPoints{}); \
         hipLaunchKernelGGL((knn_refine_kernel<(PK ? 4 : 16 * KSV)>), rgrid, dim3(128), lds2, st, xx, xt, bmg, N, p.Np,  \
                            TS, k, flags, PCAP, idx_out, dist_out);                                                     \
     } while (0)
     // default above 4 channels: ONE fp16 product on the centred, scaled points; flag 1073741824: three bf16 products on the
     // points as they are (the first form of this kernel: A/B timing, cross-check of the centred path)
-    if ((flags & 1073741824) || p.pack) {   // up to 4 channels the three bf16 products share ONE k-step: nothing to gain
+    // <= 4 channels at 64 tiles, points directly addressable in 16-byte pieces: no prep launch (RAW, see the kernel)
+    const bool raw_ok = p.pack && res && !prepared_xt && p.Np == N && !(flags & 67108864) && stride_b % 4 == 0 &&
+                        stride_c % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    if (raw_ok) {
+        const RawPoints raw{x, (long)stride_b, (long)stride_c, c_knn, xx, xt};
+        hipLaunchKernelGGL((knn_nominate_kernel<1, true, false, true, true>), grid, dim3(WAVES * 64), lds1, st, xx, xt, cand, xs,
+                           cscale, N, p.Np, k, flags, PCAP, bmg, TS, idx_out, dist_out, raw);
+        hipLaunchKernelGGL((knn_refine_kernel<4>), rgrid, dim3(128), lds2, st, xx, xt, bmg, N, p.Np, TS, k, flags, PCAP, idx_out,
+                           dist_out);
+    } else if ((flags & 1073741824) || p.pack) {   // up to 4 channels the three bf16 products share ONE k-step: nothing to gain
         if (p.pack) FSG_KNN_SPLIT(1, true, false);
         else if (p.KS == 1) FSG_KNN_SPLIT(1, false, false);
         else if (p.KS == 2) FSG_KNN_SPLIT(2, false, false);
