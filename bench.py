@@ -552,8 +552,10 @@ def main():
                                                  "from MI355X_MICROARCH.md (2.5 PFLOP/s f16 matrix, 157.3 TFLOP/s fp32, 17.8 TB/s L2 -> CU)",
                         "traffic": knn_traffic,
                         "traffic_source": "profiles/hbm_traffic.json (PMC passes of an earlier run of the same command), not measured in this run",
-                        "kernel": f"feature-space graph build on {chans[li]} channels (csrc/knn_split.hip: knn_nominate_kernel + "
-                                  "knn_refine_kernel; its prep products are emitted by the producing EdgeConv's apply pass): two "
+                        "kernel": f"feature-space graph build on {chans[li]} channels (csrc/knn_split.hip: " +
+                                  ("knn_split_kernel, one launch -- the form kept for k > 32 at N > 4096" if (k > 32 and N > 4096 and chans[li] >= 64)
+                                   else "knn_nominate_kernel + knn_refine_kernel") +
+                                  "; its prep products are emitted by the producing EdgeConv's apply pass): two "
                                   "coarse sweeps on the matrix cores nominate candidates under a rigorous error bound; exact fp32 "
                                   "fma chains + ranking for the nominees (bit-identical to the fp32 oracle)",
                         "issued_matrix_flops_per_launch": issued, "l2_to_cu_bytes_per_launch": l2_bytes,

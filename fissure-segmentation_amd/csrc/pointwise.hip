@@ -615,7 +615,7 @@ struct TnArgs {
 };
 
 template <int T1, int T2, int NP = 3>
-__global__ __launch_bounds__(256) void pw_tn_kernel(const TnArgs p) {
+__global__ __launch_bounds__(256, 2) void pw_tn_kernel(const TnArgs p) {   // (<= 256 VGPRs: two workgroups = two waves per SIMD, one transforming while the other multiplies)
     constexpr int BT1 = 64 * T1, BT2 = 64 * T2;
     __shared__ __attribute__((aligned(16))) u32x4 Limg[(BT1 / 32) * 2 * NP * 64];
     __shared__ __attribute__((aligned(16))) u32x4 Rimg[(BT2 / 32) * 2 * NP * 64];

@@ -41,10 +41,10 @@ sq = os.path.join(src, "knn_sq_counters.txt")
 if os.path.exists(sq):
     with open(os.path.join(prof, f"{tag}_knn_sq_counters.txt"), "w") as f:
         f.write("# rocprofv3 --kernel-trace --pmc <4 counters per pass> -- python3 tools/knn_split_prof.py 8 64 2048 20 (fsg_knn_dense_ws_f32, B=8 N=2048 C=64 k=20);\n")
-        f.write("# means over the launches of knn_split_kernel<4,false>, summed over the device's SEs/XCDs as rocprofv3 reports them.\n")
+        f.write("# means over the launches of knn_nominate_kernel<4,false,true,true,false> and knn_refine_kernel<64> (two blocks), summed over the device's SEs/XCDs as rocprofv3 reports them.\n")
         f.write("# SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs) = matrix-pipe busy cycles per SIMD; SQ_BUSY_CYCLES / 32 = kernel cycles.\n")
         f.write(open(sq).read())
-for nm in ("knn_phase_stamps.txt", "knn_split_timing.txt"):
+for nm in ("knn_phase_stamps.txt", "knn_split_timing.txt", "step_sq_counters.txt"):
     if os.path.exists(os.path.join(src, nm)):
         shutil.copy(os.path.join(src, nm), os.path.join(prof, f"{tag}_{nm}"))
 rl = bench["roofline"]

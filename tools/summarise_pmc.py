@@ -32,7 +32,7 @@ def per_kernel(path, counter):
 def main():
     fetch, write, tag = sys.argv[1:4]
     f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
-    ours = sorted(k for k in f if re.match(r"(knn_|ec1_|ec2_|bn|csr_|sum_partials|nnu_|pt_|gemm_small|fps_|chamfer)", k))
+    ours = sorted(k for k in f if re.match(r"(knn_|ec1_|ec2_|ec2s_|bn|csr_|sum_partials|nnu_|pt_|pw_|gemm_small|fps_|chamfer|adam_)", k))
     kernels = {}
     for k in ours:
         fk = sum(f[k]) / len(f[k])
@@ -40,15 +40,19 @@ def main():
         kernels[k] = {"launches": len(f[k]), "fetch_size_kb_raw": round(fk, 1), "write_size_kb": round(wk, 1),
                       "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
     group = {}
-    for k in kernels:   # forward graph build + neighbour gather: per-step launch counts
-        if k.startswith("knn_split_kernel<1, true") or k.startswith("knn_split_prep_kernel<1, true"):
+    for k in kernels:   # forward graph build + neighbour gather: per-step launch counts (round 4 kernel set)
+        if k.startswith("knn_nominate_kernel<1, true") or k.startswith("knn_refine_kernel<4>") or k.startswith("knn_split_prep_kernel<1, true"):
             group[k] = 1
-        elif k.startswith("knn_split_kernel<4,") or k.startswith("knn_split_prep_kernel<4,"):
+        elif k.startswith("knn_nominate_kernel<4,") or k.startswith("knn_refine_kernel<64>"):
             group[k] = 2
-        elif k in ("ec1_stats_select_kernel", "ec1_apply_kernel"):
-            group[k] = 3
-        elif k.startswith("ec2_fwd_kernel"):
+        elif k.startswith("ec1_stats_select_kernel<true>"):
+            group[k] = 2
+        elif k.startswith("ec1_stats_select_kernel<false>") or k.startswith("ec2s_fwd_kernel") or k.startswith("ec1_apply_kernel"):
             group[k] = 1
+        elif k.startswith("ec1_apply_prep_kernel"):
+            group[k] = 2
+        elif k.startswith("bn_finalize_kernel"):
+            group[k] = 4
     total = sum(kernels[k]["hbm_bytes_per_launch"] * n for k, n in group.items())
     out = {"_comment": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, --kernel-trace only) over "
                        "`python3 bench.py --steps 5 --warmup 3 --eager --no-cpu-baseline`; HBM bytes per launch = "
