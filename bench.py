@@ -493,7 +493,8 @@ def main():
             with open(tpath) as f:
                 traffic_all = json.load(f)
         roofline, roofline_group = None, None
-        knn_calls = kernel_ms.get("fsg_knn_dense_ws_f32", [])
+        # (the coordinate build of DGCNN-seg goes through the entry that also emits the first block's [P | Q] rows)
+        knn_calls = kernel_ms.get("fsg_knn_dense_ws_f32", []) + kernel_ms.get("fsg_knn_dense_ws_pq_f32", [])
         knn_prep_calls = kernel_ms.get("fsg_knn_dense_prepared_f32", [])   # feature-space builds prepared by their producer
         if knn_calls and args.workload != "c2s":
             # DOMINANT KERNEL GROUP of the DGCNN-type workloads: the feature-space graph build (csrc/knn_split.hip, two launches:
@@ -565,8 +566,9 @@ def main():
                         "timed_as": timed_as}
         if dgcnn:
             # the north-star HBM view of the forward "kNN + gather" group, against BOTH byte counts of SURVEY 8(d)
-            grp = ["fsg_knn_dense_ws_f32", "fsg_knn_dense_prepared_f32", "fsg_edge_gather_fwd_f32", "fsg_edgeconv1_fwd_f32",
-                   "fsg_edgeconv2_fwd_f32", "fsg_edgeconv2_fwd_bf16", "fsg_edgeconv_apply_f32"]   # (bf16 operand mode: its own entry)
+            grp = ["fsg_knn_dense_ws_f32", "fsg_knn_dense_ws_pq_f32", "fsg_knn_dense_prepared_f32", "fsg_edge_gather_fwd_f32",
+                   "fsg_edgeconv1_fwd_f32", "fsg_edgeconv2_fwd_f32", "fsg_edgeconv2_fwd_bf16", "fsg_edgeconv_apply_f32",
+                   "fsg_edgeconv_apply_pq_f32"]   # (bf16 operand mode and the by-product variants: entries of their own)
             grp_ms = sum(sum(kernel_ms.get(n, [])) for n in grp) / n_timed
             ref_bytes = knn_gather_bytes_per_point(k) * B * N
             min_bytes = knn_gather_min_bytes_per_point(k) * B * N
@@ -576,7 +578,9 @@ def main():
                 "bound": "mfma+latency (graph builds: %.0f of %.0f us); the gather/MLP stages alone are L2/HBM-bound" % (
                     1e3 * (sum(knn_calls) + sum(knn_prep_calls)) / n_timed, 1e3 * grp_ms),
                 "kernel": "forward kNN graph + neighbour gather (+ fused edge MLP / BN / max) of the 3 EdgeConv layers: "
-                          "fsg_knn_dense_ws_f32 / fsg_knn_dense_prepared_f32 + fsg_edgeconv{1,2}_fwd_f32 + fsg_edgeconv_apply_f32",
+                          "fsg_knn_dense_ws[_pq]_f32 / fsg_knn_dense_prepared_f32 + fsg_edgeconv{1,2}_fwd_f32 + fsg_edgeconv_apply[_pq]_f32 "
+                          "(the HIP-event sum leaves out the library GEMMs of the per-point products that are not fused yet; the "
+                          "graph-replay figure times DGCNNSeg.edge_levels whole)",
                 "unit": "GB/s", "peak": HBM_PEAK_GBS,
                 "us_per_step_hip_events": round(1e3 * grp_ms, 1),
                 "us_per_step_graph_replay": None if group_us is None else round(group_us, 1),

@@ -23,6 +23,7 @@ SIGNATURES = {
     "fsg_knn_dense_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),
     "fsg_knn_dense_ws_f32": ([_P, _I, _I, _L, _L, _I, _I, _I, _P, _P, _P, ctypes.c_size_t, _P], _I),
     "fsg_knn_dense_prepared_f32": ([_P, _I, _I, _I, _I, _I, _P, _P, _P, ctypes.c_size_t, _P], _I),
+    "fsg_knn_dense_ws_pq_f32": ([_P, _I, _I, _L, _L, _I, _I, _I, _P, _P, _P, ctypes.c_size_t, _P, _I, _P, _P], _I),
     "fsg_edgeconv_apply_f32": ([_P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, ctypes.c_size_t, _P], _I),
     "fsg_edgeconv_apply_pq_f32": ([_P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, ctypes.c_size_t, _P, _I, _P, _P], _I),
     "fsg_edge_gather_fwd_f32": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),

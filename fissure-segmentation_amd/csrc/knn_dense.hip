@@ -150,6 +150,40 @@ extern "C" int fsg_knn_dense_ws_f32(const float *x, int B, int N, int64_t stride
 
 int fsg_knn_split_launch_ex(const float *x, const float *prepared_xt, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn,
                             int k, int flags, int32_t *idx_out, float *dist_out, void *ws, size_t ws_bytes, hipStream_t st);
+int fsg_knn_split_launch_pq(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k, int flags,
+                            int32_t *idx_out, float *dist_out, void *ws, size_t ws_bytes, hipStream_t st, const float *pq_w,
+                            int pq_rows, float *pq_out, bool *fused);
+int fsg_knn_pq_rows_launch(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, const float *pq_w,
+                           int pq_rows, float *pq_out, hipStream_t st);
+
+// fsg_knn_dense_ws_f32 over points of up to four channels PLUS their per-point product with a small weight:
+// pq_out (B, N, rows_pq) = x^T w_pq^T, w_pq (rows_pq, c_knn) row-major -- the "one plain GEMM" of the FIRST EdgeConv's contract
+// (models/dgcnn.py:212-243: its first 1x1 conv decomposed per point, fsg_edge_weights_many_f32 makes the weight), K = c_knn <= 4.
+// Inside the coarse-sweep kernel's no-prep path (N = 2048, 16-byte addressable rows) the rows come out of the graph build's first
+// launch, which holds the workgroup's points anyway; otherwise a small launch of its own follows the build.  256 % rows_pq == 0.
+extern "C" int fsg_knn_dense_ws_pq_f32(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k,
+                                       int flags, int32_t *idx_out, float *dist_out, void *workspace, size_t workspace_bytes,
+                                       const float *w_pq, int rows_pq, float *pq_out, fsg_stream_t stream) {
+    FSG_REQUIRE(x && idx_out && w_pq && pq_out, "fsg_knn_dense_ws_pq_f32: NULL pointer");
+    FSG_REQUIRE(c_knn >= 1 && c_knn <= 4 && rows_pq >= 1 && 256 % rows_pq == 0,
+                "fsg_knn_dense_ws_pq_f32: needs 1 <= c_knn <= 4 and rows_pq dividing 256; got c_knn=%d rows_pq=%d", c_knn, rows_pq);
+    const int drop = (flags & FSG_KNN_DROP_FIRST) ? 1 : 0;
+    FSG_REQUIRE(B >= 0 && N > 0 && k >= 1 && k + drop <= N && k + drop <= FSG_KNN_MAX_K, "fsg_knn_dense_ws_pq_f32: bad shape B=%d N=%d k=%d",
+                B, N, k);
+    if (B == 0) return FSG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (workspace && !(flags & (2097152 | FSG_KNN_FORCE_ROWS | FSG_KNN_FORCE_MFMA | 4096 | 16384 | 131072 | 2048 | 8192))) {
+        bool fused = false;
+        const int rc = fsg_knn_split_launch_pq(x, B, N, stride_b, stride_c, c_knn, k, flags, idx_out, dist_out, workspace,
+                                               workspace_bytes, st, w_pq, rows_pq, pq_out, &fused);
+        if (rc == FSG_OK) return fused ? FSG_OK : fsg_knn_pq_rows_launch(x, B, N, stride_b, stride_c, c_knn, w_pq, rows_pq, pq_out, st);
+        if (rc != FSG_ERR_UNSUPPORTED) return rc;
+    }
+    const int rc = fsg_knn_dense_ws_f32(x, B, N, stride_b, stride_c, c_knn, k, flags, idx_out, dist_out, workspace, workspace_bytes,
+                                        stream);
+    if (rc != FSG_OK) return rc;
+    return fsg_knn_pq_rows_launch(x, B, N, stride_b, stride_c, c_knn, w_pq, rows_pq, pq_out, st);
+}
 
 // The graph build of fsg_knn_dense_ws_f32 when the producer of the points has already PREPARED it (fsg_edgeconv_apply_f32 with a
 // knn_workspace): x_pm = the point-major (B, N, c_knn) copy of the points, workspace = the one handed to the producer.  Same

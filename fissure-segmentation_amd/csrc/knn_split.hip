@@ -1,8 +1,13 @@
-// Dense kNN graph build, "coarse sweep + exact refine" kernel behind fsg_knn_dense_ws_f32
-// (1024 <= N <= 8192, c_knn <= 128 -- above 64 channels N <= 4096, enforced by plan() --, k + drop <= 64).  Replaces
-// utils/general_utils.py:43-53,315-327 like the two-phase kernel of knn_rows_mfma.hip and returns the SAME bits (indices and
-// distances of oracle/fsg_oracle.c): the matrix cores only NOMINATE candidates, every distance that is ranked or returned is
-// the oracle's fp32 fma chain.
+// Dense kNN graph build, "coarse sweep + exact refine" behind fsg_knn_dense_ws_f32 / fsg_knn_dense_prepared_f32 /
+// fsg_knn_dense_ws_pq_f32 (1024 <= N <= 8192, c_knn <= 128 -- above 64 channels N <= 4096, enforced by plan() --, k + drop <= 64).
+// Replaces utils/general_utils.py:43-53,315-327 like the two-phase kernel of knn_rows_mfma.hip and returns the SAME bits (indices
+// and distances of oracle/fsg_oracle.c): the matrix cores only NOMINATE candidates, every distance that is ranked or returned
+// is the oracle's fp32 fma chain.
+//
+// Since round 4 the build is TWO launches (knn_nominate_kernel + knn_refine_kernel, second half of this file: read its header
+// first); the one-launch kernel of rounds 2-3 (knn_split_kernel, first half) is kept for the one shape class where it is still
+// ahead (k + drop > 32 at N > 4096 on 64+ channels: BASELINE config 4) and as an independent cross-check (flag 536870912).
+// The algorithm, common to both:
 //
 //   prep    one pass over the cloud: squared norms (the oracle's chain), a point-major fp32 copy (rows for the refine) and
 //           the coarse image of the points in the REGISTER LAYOUT of a 32x32x16 MFMA operand (one 1-KiB block per 32 points
@@ -13,6 +18,8 @@
 //           * up to 4 channels (and flag 1073741824): two bf16 pieces x = hi + lo + r, |r| <= 2^-16 |x| (round-to-nearest-
 //             even in integer arithmetic) of the points as they are, three products -- which share ONE k-step at <= 4 channels.
 //           A query operand is the same image times -2 (one exponent step, done in the main kernel).
+//           (Feature-space builds of DGCNN-seg: emitted by the EdgeConv pass that produces the points, edgeconv.hip; the
+//           coordinate build at N = 2048: built by the nominate kernel itself from the (B, C, N) points -- no prep launch.)
 //   sweep 1 a workgroup owns 64 queries (two 32-column blocks, resident as B operands); its 8 waves take the candidate
 //           tiles (32 rows, A operand) round-robin.  s~(i,j) = |x_j|^2 - 2 x_i.x_j in coarse arithmetic comes out of one fp16
 //           (three bf16) MFMAs per k-step with the squared norm as the accumulator's initial value.  Lane (n, h) holds 16
@@ -22,13 +29,12 @@
 //           |s~ - F| <= eps_i for every candidate (F = the oracle's distance, in the image's units, minus a per-query
 //           constant) the K-th smallest oracle distance is <= tau + eps_i and every true neighbour has s~ <= tau + 2 eps_i.
 //   sweep 2 the same MFMAs again (bit-identical values); s~ <= tau + 2 eps becomes one bit per candidate in a per-query
-//           bitmap in LDS -- branch-free; ~1.2 K bits set per query.
-//   refine  a wave owns 8 queries: bitmap rows -> registers, counts (popcount + DPP scan), decode into one candidate list;
-//           candidate rows are loaded WHOLE from the point-major copy into an LDS stage (48 rows per pass), one lane per
-//           candidate runs the oracle's distance d = (xx_i - 2 dot) + xx_j, dot = channel-ordered fmaf chain from +0; the
-//           (d, j) keys are ranked by counting inside the query's segment and ranks < K are written.
+//           bitmap in LDS -- branch-free; ~27 bits set per query at k = 20.
+//   refine  candidate rows are loaded WHOLE from the point-major copy into an LDS stage, one lane per candidate runs the
+//           oracle's distance d = (xx_i - 2 dot) + xx_j, dot = channel-ordered fmaf chain from +0; the (d, j) keys are ranked
+//           by counting inside the query's segment and ranks < K are written.
 //   slow    a query whose candidate list overflows (massive ties) -- and every query of a cloud with a marked outlier -- is
-//           redone by the whole workgroup from the oracle's distances of ALL candidates: exact, slow, rare.
+//           redone by a whole workgroup from the oracle's distances of ALL candidates: exact, slow, rare.
 //
 // Error bound of the bf16 form (n_i = |x_i|, R = max_j |x_j|, both rounded up; the fp16 form's terms are listed where eps is
 // computed, in the centred and scaled units):
@@ -36,10 +42,12 @@
 //   fp32 accumulation of 193 terms in the matrix core, any order, truncation allowed          -> 2.6e-5 (R^2 + 2.1 n_i R)
 //   the oracle's own fp32 chains against real arithmetic (dot, both norms, two roundings)     -> 9.2e-6 (n_i + R)^2
 //
-// Debug / measurement flags (bits of `flags`; tools/knn_split_check.py, tools/knn_split_stamps.py): 65536 plain workgroup
-// placement; 4194304 every query through the slow path; 1073741824 the bf16 form above 4 channels; 33554432 statistics
-// (fsg_debug_knn_split_stats); 268435456 cycle stamps (fsg_debug_knn_split_stamps); 67108864 / 8388608 / 16777216 return
-// after the setup / sweep 1 / sweep 2 (timing ablations: the outputs are NOT written).
+// Debug / measurement flags (bits of `flags`; tools/knn_split_check.py, tools/knn_nominate_stamps.py, tools/knn_split_stamps.py):
+// 65536 plain workgroup placement; 4194304 every query through the slow path; 1073741824 the bf16 form above 4 channels;
+// 33554432 statistics (fsg_debug_knn_split_stats); 268435456 cycle stamps (fsg_debug_knn_split_stamps / _refine_stamps; forces
+// the two-launch form unless 536870912 is set too); 536870912 the one-launch kernel; 134217728 two-launch form without resident
+// operand tiles; 67108864 two-launch form with the prep launch where the no-prep path would run (A/B) -- and, one-launch kernel
+// only: 67108864 / 8388608 / 16777216 return after the setup / sweep 1 / sweep 2 (timing ablations: the outputs are NOT written).
 #include <type_traits>
 
 #include "fsg_common.h"
@@ -945,7 +953,40 @@ struct RawPoints {
     long sb, sc;
     int c_knn;
     float *xx_out, *xt_out;   // (B, Np) squared norms, (B, Np, 4) point-major rows: what the refine launch reads
+    // optional by-product (fsg_knn_dense_ws_pq_f32): pq_out (B, N, rows_pq) = x^T w_pq^T, w_pq (rows_pq, c_knn) row-major -- the
+    // per-point rows of the FIRST EdgeConv's decomposed conv (K = c_knn <= 4: a product no matrix unit is needed for)
+    const float *w_pq;
+    int rows_pq;
+    float *pq_out;
 };
+
+// pq_out row of point j from its (up to four) coordinates: lane = output column, the weights in registers
+__device__ __forceinline__ void raw_pq_rows(const RawPoints &raw, const float *xrb, int N, long row0, int j0, int npts, int tid,
+                                            int nthreads) {
+    const int cols = raw.rows_pq;
+    const int groups = nthreads / cols;                // point groups working side by side (nthreads is a multiple of cols)
+    if (groups == 0 || tid >= groups * cols) return;
+    const int col = tid % cols, pg = tid / cols;
+    float w[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (c < raw.c_knn) w[c] = raw.w_pq[(long)col * raw.c_knn + c];
+    for (int p = pg; p < npts; p += groups) {
+        const int j = j0 + p;
+        if (j >= N) break;
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < raw.c_knn) a = __builtin_fmaf(xrb[c * raw.sc + j], w[c], a);
+        raw.pq_out[(row0 + j) * cols + col] = a;
+    }
+}
+
+// the same product on its own (shapes whose graph build does not run the RAW path): grid (ceil(N / 64), B), 256 threads
+__global__ __launch_bounds__(256) void knn_pq_rows_kernel(const RawPoints raw, int N) {
+    const int b = blockIdx.y;
+    raw_pq_rows(raw, raw.x + (long)b * raw.sb, N, (long)b * N, blockIdx.x * 64, 64, threadIdx.x, 256);
+}
 template <int KS, bool PACK, bool HALF, bool RES, bool RAW>
 __global__ __launch_bounds__(WAVES * 64, 2) void knn_nominate_kernel(const float *__restrict__ xx, const float *__restrict__ xt,
                                                                      const u32x4 *__restrict__ cand,
@@ -1122,6 +1163,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void knn_nominate_kernel(const float
         *reinterpret_cast<f32x4 *>(raw.xt_out + ((long)b * Np + j) * 4) = row;
         raw.xx_out[(long)b * Np + j] = a;
     }
+    if (RAW && raw.pq_out) raw_pq_rows(raw, xrb, N, (long)b * N, q0, QB, tid, WAVES * 64);   // this workgroup's 64 points
     float mx = 0.f, mo = 0.f;
     bool outlier = false;
     // (the first round of 8 slots is straight-line code, so that the compiler's load counters stay exact and -- RES -- the
@@ -1942,8 +1984,38 @@ int fsg_knn_split_launch(const float *x, int B, int N, int64_t stride_b, int64_t
 // prepared_xt != NULL: the workspace already holds the prep products (squared norms, centred norms, fp16 image, scale: written
 // by the producer of the points, ec1_apply_prep_kernel) and prepared_xt is the point-major (B, N, c_knn) copy of the points
 // (c_knn == 16 KS, N % 64 == 0): the prep kernel is skipped
+static int knn_split_launch_impl(const float *x, const float *prepared_xt, int B, int N, int64_t stride_b, int64_t stride_c,
+                                 int c_knn, int k, int flags, int32_t *idx_out, float *dist_out, void *ws, size_t ws_bytes,
+                                 hipStream_t st, const float *pq_w, int pq_rows, float *pq_out, bool *pq_fused);
+
 int fsg_knn_split_launch_ex(const float *x, const float *prepared_xt, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn,
                             int k, int flags, int32_t *idx_out, float *dist_out, void *ws, size_t ws_bytes, hipStream_t st) {
+    return knn_split_launch_impl(x, prepared_xt, B, N, stride_b, stride_c, c_knn, k, flags, idx_out, dist_out, ws, ws_bytes, st, nullptr,
+                                 0, nullptr, nullptr);
+}
+
+// graph build + the per-point product pq_out (B, N, pq_rows) = x^T pq_w^T (c_knn <= 4 channels): fused into the nominate launch
+// where the RAW path runs (*fused = true), otherwise the caller launches fsg_knn_pq_rows_launch itself
+int fsg_knn_split_launch_pq(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k, int flags,
+                            int32_t *idx_out, float *dist_out, void *ws, size_t ws_bytes, hipStream_t st, const float *pq_w,
+                            int pq_rows, float *pq_out, bool *fused) {
+    *fused = false;
+    return knn_split_launch_impl(x, nullptr, B, N, stride_b, stride_c, c_knn, k, flags, idx_out, dist_out, ws, ws_bytes, st, pq_w,
+                                 pq_rows, pq_out, fused);
+}
+
+int fsg_knn_pq_rows_launch(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, const float *pq_w,
+                           int pq_rows, float *pq_out, hipStream_t st) {
+    if (c_knn < 1 || c_knn > 4 || pq_rows < 1 || 256 % pq_rows != 0) return FSG_ERR_UNSUPPORTED;
+    const RawPoints raw{x, (long)stride_b, (long)stride_c, c_knn, nullptr, nullptr, pq_w, pq_rows, pq_out};
+    hipLaunchKernelGGL(knn_pq_rows_kernel, dim3(fsg_cdiv(N, 64), B), dim3(256), 0, st, raw, N);
+    FSG_CHECK_LAUNCH("fsg_knn_dense_ws_pq_f32/rows");
+    return FSG_OK;
+}
+
+static int knn_split_launch_impl(const float *x, const float *prepared_xt, int B, int N, int64_t stride_b, int64_t stride_c,
+                                 int c_knn, int k, int flags, int32_t *idx_out, float *dist_out, void *ws, size_t ws_bytes,
+                                 hipStream_t st, const float *pq_w, int pq_rows, float *pq_out, bool *pq_fused) {
     const int drop = (flags & FSG_KNN_DROP_FIRST) ? 1 : 0;
     const SplitPlan p = plan(B, N, c_knn);
     if (!p.ok || k + drop > 64 || ws == nullptr || ws_bytes < p.total) return FSG_ERR_UNSUPPORTED;
@@ -2007,7 +2079,9 @@ int fsg_knn_split_launch_ex(const float *x, const float *prepared_xt, int B, int
     const bool raw_ok = p.pack && res && !prepared_xt && p.Np == N && !(flags & 67108864) && stride_b % 4 == 0 &&
                         stride_c % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     if (raw_ok) {
-        const RawPoints raw{x, (long)stride_b, (long)stride_c, c_knn, xx, xt};
+        const RawPoints raw{x, (long)stride_b, (long)stride_c, c_knn, xx, xt, pq_w, pq_rows, pq_out};
+        if (pq_fused) *pq_fused = pq_out != nullptr && (WAVES * 64) % pq_rows == 0;
+        if (pq_out && (WAVES * 64) % pq_rows != 0) return FSG_ERR_UNSUPPORTED;
         hipLaunchKernelGGL((knn_nominate_kernel<1, true, false, true, true>), grid, dim3(WAVES * 64), lds1, st, xx, xt, cand, xs,
                            cscale, N, p.Np, k, flags, PCAP, bmg, TS, idx_out, dist_out, raw);
         hipLaunchKernelGGL((knn_refine_kernel<4>), rgrid, dim3(128), lds2, st, xx, xt, bmg, N, p.Np, TS, k, flags, PCAP, idx_out,

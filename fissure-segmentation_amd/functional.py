@@ -136,12 +136,15 @@ _KNN_EXPERIMENT_FLAGS = 8   # the first MFMA design (libfsg_hip_experiments.so):
 
 
 def knn_graph(x, k, c_knn=None, fix_diag=True, drop_first=False, return_dist=False, force_rows_kernel=False,
-              _debug_flags=0, out=None, prepared=None):
+              _debug_flags=0, out=None, prepared=None, pq_weight=None):
     """x: (B,C,N) -> idx (B,N,k) int32 [, dist (B,N,k) fp32].  Channel slices are passed by stride.  `out`: a contiguous
     (B,N,k) int32 tensor to write the graph into (e.g. a slice of one buffer holding all graphs of a step, so that their
     reverse graphs can be built in one launch: build_reverse_graphs).  `prepared` = (workspace, x_pm): the producer of x has
     already emitted the build's prep products into `workspace` (edgeconv1 / edgeconv2 with knn_ws=) and x_pm is its point-major
-    copy (B,N,C): the build starts at its main kernel (include/fsg_hip.h: fsg_knn_dense_prepared_f32)."""
+    copy (B,N,C): the build starts at its main kernel (include/fsg_hip.h: fsg_knn_dense_prepared_f32).
+    `pq_weight` (rows, C) with C = c_knn <= 4 (the [W_rel ; W_ctr - W_rel] weight of the FIRST EdgeConv's first conv): the build
+    also emits that block's per-point rows pq (B, N, rows) = x^T pq_weight^T (fsg_knn_dense_ws_pq_f32) -> returns (idx, pq); pq is
+    None when the shape does not qualify (then the caller runs the product itself)."""
     _need_gpu(x)
     if x.dim() != 3:
         raise ValueError(f"expected (B,C,N), got {tuple(x.shape)}")
@@ -169,6 +172,15 @@ def knn_graph(x, k, c_knn=None, fix_diag=True, drop_first=False, return_dist=Fal
         return idx
     ws_bytes = _lib.lib.fsg_knn_dense_workspace_bytes(B, N, c_knn)
     xx = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=x.device)
+    if pq_weight is not None:
+        rows = pq_weight.shape[0]
+        if (C == c_knn and c_knn <= 4 and tuple(pq_weight.shape) == (rows, C) and 256 % rows == 0 and not return_dist and
+                not (_debug_flags & _KNN_EXPERIMENT_FLAGS)):
+            pq = torch.empty(B, N, rows, dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                _lib.call("fsg_knn_dense_ws_pq_f32", _p(x), B, N, x.stride(0), x.stride(1), c_knn, k, flags, _p(idx), None, _p(xx),
+                          ws_bytes, _p(_f32c(pq_weight.detach())), rows, _p(pq), _stream())
+            return idx, pq
     with torch.cuda.device(x.device):
         if _debug_flags & _KNN_EXPERIMENT_FLAGS:   # superseded designs (tests / tools): libfsg_hip_experiments.so
             xl = _lib.experiments()
@@ -181,6 +193,8 @@ def knn_graph(x, k, c_knn=None, fix_diag=True, drop_first=False, return_dist=Fal
             flags &= ~_KNN_EXPERIMENT_FLAGS
         _lib.call("fsg_knn_dense_ws_f32", _p(x), B, N, x.stride(0), x.stride(1), c_knn, k, flags, _p(idx), _p(dist), _p(xx),
                   ws_bytes, _stream())
+    if pq_weight is not None:
+        return idx, None
     return (idx, dist) if return_dist else idx
 
 

@@ -281,9 +281,10 @@ class DGCNNSeg(DGCNNBase):
             # the feature-space graph builds are PREPARED by the block that produces their points: its last pass emits the
             # norms and the coarse operand image of its output on the way (one launch less per build)
             ws2, ws3 = F_hip.knn_prep_workspace(B, N, 64, x.device), F_hip.knn_prep_workspace(B, N, 64, x.device)
-            g1 = F_hip.knn_graph(x, self.k, c_knn=3, fix_diag=True, out=graphs[0])
+            # the coordinate build also emits the first block's [P | Q] rows when the cloud IS the coordinates (K = 3 product)
+            g1, pq1 = F_hip.knn_graph(x, self.k, c_knn=3, fix_diag=True, out=graphs[0], pq_weight=w1)
             # (the apply pass of a block also emits the NEXT block's [P | Q] rows from the tile it holds in LDS: w_next / pq_given)
-            x1, p1, p1c, pq2 = self.ec1(x, g1, both="twice", w_cat=w1, knn_ws=ws2, w_next=w2)
+            x1, p1, p1c, pq2 = self.ec1(x, g1, both="twice", w_cat=w1, knn_ws=ws2, w_next=w2, pq_given=pq1)
             g2 = F_hip.knn_graph(x1, self.k, fix_diag=True, out=graphs[1], prepared=None if ws2 is None else (ws2, p1))
             x2, p2, p2c, pq3 = self.ec2(x1, g2, x_pm=p1, both="twice", w_cat=w2, knn_ws=ws3, w_next=w3, pq_given=pq2)
             g3 = F_hip.knn_graph(x2, self.k, fix_diag=True, out=graphs[2], prepared=None if ws3 is None else (ws3, p2))

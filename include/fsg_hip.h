@@ -71,6 +71,18 @@ int fsg_knn_dense_ws_f32(const float *x, int B, int N, int64_t stride_b, int64_t
                          size_t workspace_bytes, fsg_stream_t stream);
 
 /*
+ * fsg_knn_dense_ws_f32 over points of up to FOUR channels, plus their per-point product with a small weight:
+ * pq_out (B, N, rows_pq) = x^T w_pq^T with w_pq (rows_pq, c_knn) row-major -- the "one plain GEMM" of the FIRST EdgeConv's
+ * contract (models/dgcnn.py:212-243: its first 1x1 conv, decomposed per point; fsg_edge_weights_many_f32 makes the weight), a
+ * K <= 4 product no matrix unit is needed for.  Where the graph build reads the (B, C, N) points itself (N = 2048, rows
+ * addressable in 16-byte pieces) the rows come out of its first launch; otherwise a small launch follows the build.
+ * 1 <= c_knn <= 4, rows_pq divides 256.
+ */
+int fsg_knn_dense_ws_pq_f32(const float *x, int B, int N, int64_t stride_b, int64_t stride_c, int c_knn, int k, int flags,
+                            int32_t *idx_out, float *dist_out, void *workspace, size_t workspace_bytes, const float *w_pq,
+                            int rows_pq, float *pq_out, fsg_stream_t stream);
+
+/*
  * The same graph build when the PRODUCER of the points has already prepared it: fsg_edgeconv_apply_f32 (below) with a
  * knn_workspace emits the squared norms, the centred norms and the fp16 operand image of its output on the way, so the build
  * starts at its main kernel (one launch and ~11 us less per feature-space graph of DGCNN-seg).  x_pm = the point-major

@@ -168,6 +168,32 @@ def test_knn_split_kernel_equals_two_phase_kernel_at_full_size(fsg, device, B, C
     assert torch.equal(a[1].view(torch.int32), r[1].view(torch.int32))
 
 
+@pytest.mark.parametrize("B,C,Np,k,rows", [(8, 3, 2048, 20, 128), (2, 3, 1024, 16, 128), (2, 4, 2048, 20, 64), (1, 2, 1500, 8, 256),
+                                          (2, 3, 4096, 20, 128)])
+def test_knn_graph_emits_first_edgeconv_rows(fsg, device, B, C, Np, k, rows):
+    """fsg_knn_dense_ws_pq_f32: the graph build over the coordinates also hands out the per-point rows of the first EdgeConv's
+    decomposed conv, pq = x^T W^T (models/dgcnn.py:212-243) -- fused into the build's first launch at N = 2048 (the no-prep
+    path), a small launch of its own elsewhere.  The graph must be the plain build's, bit for bit; the rows are a K <= 4 fma
+    chain: 1e-6 of their scale against float64."""
+    F_hip = fsg.functional
+    g = np.random.default_rng(B * 100 + C + Np)
+    x = g.uniform(-1, 1, (B, C, Np)).astype(np.float32)
+    w = g.standard_normal((rows, C)).astype(np.float32)
+    xt, wt = G(x, device), G(w, device)
+    idx, pq = F_hip.knn_graph(xt, k, fix_diag=True, pq_weight=wt)
+    assert pq is not None and tuple(pq.shape) == (B, Np, rows)
+    ref_idx = F_hip.knn_graph(xt, k, fix_diag=True)
+    assert torch.equal(idx, ref_idx)
+    io, _ = c_api.knn_dense(x, k, fix_diag=True)
+    assert np.array_equal(N(idx), io)
+    want = np.einsum("bcn,rc->bnr", x.astype(np.float64), w.astype(np.float64))
+    assert np.abs(N(pq).astype(np.float64) - want).max() <= 1e-6 * max(1.0, np.abs(want).max())
+    # a cloud that is NOT just its coordinates (features behind them): no by-product, the caller runs the product itself
+    x6 = G(np.concatenate([x[:, :min(C, 3)], x[:, :min(C, 3)]], 1), device)
+    idx6, none = F_hip.knn_graph(x6, k, c_knn=min(C, 3), fix_diag=True, pq_weight=G(g.standard_normal((rows, x6.shape[1])).astype(np.float32), device))
+    assert none is None and idx6.shape == (B, Np, k)
+
+
 def test_knn_massive_ties_take_the_slow_exact_path(fsg, device):
     """2000 identical points + a few distinct ones: every distance ties, far more than 128 survivors per row."""
     x = np.zeros((2, 3, 2100), np.float32)

@@ -1,4 +1,5 @@
-"""In-kernel cycle stamps of the coarse-sweep kNN kernel (flag 268435456): per phase, mean over waves and workgroups.
+"""In-kernel cycle stamps of the MONOLITHIC coarse-sweep kNN kernel (flags 268435456 | 536870912; the two-launch form of round 4:
+tools/knn_nominate_stamps.py): per phase, mean over waves and workgroups.
 python3 tools/knn_split_stamps.py B C N k"""
 import ctypes
 import os
@@ -18,7 +19,7 @@ p = torch.rand(B, 3, N, generator=g)
 w = torch.randn(C, 3, generator=g)
 x = (torch.tanh(torch.einsum("cd,bdn->bcn", w, p)) + 1.0).contiguous().cuda() if C > 3 else (p * 2 - 1).cuda()
 for _ in range(3):
-    F.knn_graph(x, k, _debug_flags=268435456 | extra)
+    F.knn_graph(x, k, _debug_flags=268435456 | 536870912 | extra)
 torch.cuda.synchronize()
 lib = fsg._lib.lib
 buf = (ctypes.c_ulonglong * (256 * 8 * 16))()
