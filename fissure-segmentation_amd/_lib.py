@@ -95,6 +95,8 @@ SIGNATURES = {
     "fsg_pw_bn_finalize_f32": ([_P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P], _I),
     "fsg_pw_cloud_linear_f32": ([_P, _P, _L, _I, _I, _I, _P, _P], _I),
     "fsg_pw_max_finish_f32": ([_P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P], _I),
+    "fsg_pw_bn_finalize_max_f32": ([_P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P,
+                                   _P], _I),
     "fsg_pw_bnbwd_finalize_f32": ([_P, _I, _I, _I, _L, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P], _I),
     "fsg_pw_logits_bwd_f32": ([_P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _P, _P], _I),
     "fsg_pw_gf_prep_f32": ([_P, _P, _L, _I, _P, _P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _F, _P, _P, _P, _P, _P, _P, _L, _I, _P, _L,

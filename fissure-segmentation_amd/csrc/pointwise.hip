@@ -816,7 +816,19 @@ __global__ __launch_bounds__(256) void pw_tn_reduce_kernel(const float *__restri
 //   alpha[c] = gamma r,  delta[b][c] = alpha (shift[b][c] - mean) + beta,  emu[b][c] = mean - shift[b][c]
 // 4 channels per workgroup, 64 contiguous record slices per channel (two to eight records each), LDS merge.
 constexpr int FS = 64, FC = 4;   // record slices and channels per workgroup: few dependent round trips per thread
-__global__ __launch_bounds__(256) void pw_bn_finalize_kernel(const float *__restrict__ rec, int R, int ldn, int c0, int C,
+// optional tail (round 4): the global max-pool's finish (pw_max_finish_kernel) for the same channels, in the same launch -- the
+// BatchNorm whose statistics this is feeds a max over the points through the monotone BatchNorm + LeakyReLU, and the (cloud,
+// channel) maxima need exactly the alpha / delta this workgroup has just computed
+struct MaxFinish {
+    const float *sel_val;
+    const int *sel_arg;
+    const float *sgn;
+    int tiles;
+    float slope;
+    float *out, *ysel;
+    int *arg;
+};
+__global__ __launch_bounds__(256) void pw_bn_finalize_kernel(const MaxFinish mf, const float *__restrict__ rec, int R, int ldn, int c0, int C,
                                                              const float *__restrict__ shift, int B, int training,
                                                              const float *__restrict__ gamma, const float *__restrict__ beta,
                                                              float eps, float momentum, float *__restrict__ running_mean,
@@ -861,6 +873,26 @@ __global__ __launch_bounds__(256) void pw_bn_finalize_kernel(const float *__rest
                 shl[b0 + sl][ch] = t;
             }
             __syncthreads();
+        }
+    }
+    // max-pool finish, first half (independent of the statistics, so its loads fly with the records'): slice sl takes (cloud,
+    // tile group) pairs -- up to 8 groups of row blocks per cloud -- and leaves (best value, lowest row) per pair in LDS
+    __shared__ float pbv[FS * 8][FC];
+    __shared__ int pba[FS * 8][FC];
+    if (mf.sel_val && live) {
+        const int TG = mf.tiles < 8 ? mf.tiles : 8;
+        const int tper = (mf.tiles + TG - 1) / TG;
+        for (int pr0 = sl; pr0 < B * TG; pr0 += FS) {
+            const int b = pr0 / TG, tg = pr0 - b * TG;
+            float bv = -INFINITY;
+            int ba = 0x7fffffff;
+            for (int t = tg * tper; t < min(mf.tiles, (tg + 1) * tper); ++t) {
+                const float v = mf.sel_val[((long)b * mf.tiles + t) * C + c];
+                const int a = mf.sel_arg[((long)b * mf.tiles + t) * C + c];
+                if (v > bv || (v == bv && a < ba)) { bv = v; ba = a; }
+            }
+            pbv[pr0][ch] = bv;
+            pba[pr0][ch] = ba;
         }
     }
     const int rpc = B > 0 ? R / B : R;                  // records per cloud
@@ -930,6 +962,24 @@ __global__ __launch_bounds__(256) void pw_bn_finalize_kernel(const float *__rest
         const float sh = shift ? shift_of(b) : 0.f;
         delta[(long)b * C + c] = __builtin_fmaf(al, sh - mu, beta[c]);
         if (emu) emu[(long)b * C + c] = mu - sh;
+    }
+    if (mf.sel_val) {       // (never together with a shift: delta has one row) -- one slice per cloud folds its tile groups in order
+        const int TG = mf.tiles < 8 ? mf.tiles : 8;
+        const float de = __builtin_fmaf(al, -mu, beta[c]);
+        for (int b = sl; b < B; b += FS) {
+            float bv = -INFINITY;
+            int ba = 0x7fffffff;
+            for (int tg = 0; tg < TG; ++tg) {
+                const float v = pbv[b * TG + tg][ch];
+                const int a = pba[b * TG + tg][ch];
+                if (v > bv || (v == bv && a < ba)) { bv = v; ba = a; }
+            }
+            const float yv = (mf.sgn[c] < 0.f ? -1.f : 1.f) * bv;
+            mf.ysel[(long)b * C + c] = yv;
+            mf.arg[(long)b * C + c] = ba == 0x7fffffff ? 0 : ba;
+            const float u = __builtin_fmaf(yv, al, de);
+            mf.out[(long)b * C + c] = u > 0.f ? u : u * mf.slope;
+        }
     }
     if (cloud_mean && training) {                        // unshifted per-cloud mean of the records (first head layer's backward)
         const bool aligned = per > 0 && rpc % per == 0 && R % per == 0;
@@ -1779,10 +1829,29 @@ extern "C" int fsg_pw_bn_finalize_f32(const float *rec, int R, int ldn, int c0, 
     FSG_REQUIRE(C > 0 && (!training || (rec && R > 0 && ldn >= c0 + C)) && (!shift || (B > 0 && R % B == 0)) &&
                     (!cloud_mean || (B > 0 && R % B == 0)),
                 "fsg_pw_bn_finalize_f32: bad shape R=%d ldn=%d c0=%d C=%d B=%d", R, ldn, c0, C, B);
-    hipLaunchKernelGGL(pw_bn_finalize_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, (hipStream_t)stream, rec, R, ldn, c0, C, shift, B,
-                       training, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, alpha, delta, emu, cloud_mean,
-                       gfeat, Wglob, (long)ldwg, CG, shift_out);
+    hipLaunchKernelGGL(pw_bn_finalize_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, (hipStream_t)stream, MaxFinish{}, rec, R, ldn, c0, C,
+                       shift, B, training, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, alpha, delta, emu,
+                       cloud_mean, gfeat, Wglob, (long)ldwg, CG, shift_out);
     FSG_CHECK_LAUNCH("fsg_pw_bn_finalize_f32");
+    return FSG_OK;
+}
+
+// fsg_pw_bn_finalize_f32 (no shift) + fsg_pw_max_finish_f32 in ONE launch: the statistics of the BatchNorm in front of a global
+// max-pool and the pool's finish from the SEL records of the same product (models/dgcnn.py:134-137,156).  B <= 64.
+extern "C" int fsg_pw_bn_finalize_max_f32(const float *rec, int R, int ldn, int c0, int C, int B, int training, const float *gamma,
+                                          const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                                          float *mean, float *invstd, float *alpha, float *delta, const float *sel_val,
+                                          const int32_t *sel_arg, const float *sgn, int tiles, float slope, float *out, float *ysel,
+                                          int32_t *arg, fsg_stream_t stream) {
+    FSG_REQUIRE(gamma && beta && mean && invstd && alpha && delta && sel_val && sel_arg && sgn && out && ysel && arg,
+                "fsg_pw_bn_finalize_max_f32: NULL pointer");
+    FSG_REQUIRE(C > 0 && B > 0 && B <= 64 && tiles > 0 && (!training || (rec && R > 0 && ldn >= c0 + C)),
+                "fsg_pw_bn_finalize_max_f32: bad shape R=%d ldn=%d c0=%d C=%d B=%d tiles=%d", R, ldn, c0, C, B, tiles);
+    const MaxFinish mf{sel_val, sel_arg, sgn, tiles, slope, out, ysel, arg};
+    hipLaunchKernelGGL(pw_bn_finalize_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, (hipStream_t)stream, mf, rec, R, ldn, c0, C,
+                       nullptr, B, training, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, alpha, delta, nullptr,
+                       nullptr, nullptr, nullptr, 0L, 0, nullptr);
+    FSG_CHECK_LAUNCH("fsg_pw_bn_finalize_max_f32");
     return FSG_OK;
 }
 

@@ -1272,13 +1272,23 @@ class _SegHead(torch.autograd.Function):
         pw_rowgemm(PRO_NONE, PW_STORE | PW_STATS | PW_SEL, 1, A1=levels, lda1=levels.stride(0), K1=KL, K2=0, Bimg=img0, M=M,
                    N=CG + C0, rows_per_cloud=Npts, C=y0, ldc=C0, store_n0=CG, rec=rec0, sgn=sgn, sel_val=sel_val,
                    sel_arg=sel_arg, sel_n=CG)
-        mean_g, inv_g, al_g, de_g, _, _ = _pw_bn_finalize(rec0, R0, CG + C0, 0, CG, None, B, bn_g, tr_g, mom_g)
+        # BatchNorm statistics of the global-feature layer AND the finish of its max-pool (one launch: fsg_pw_bn_finalize_max_f32)
         g = torch.empty(B, CG, **f32)
         ysel = torch.empty(B, CG, **f32)
         arg = torch.empty(B, CG, dtype=torch.int32, device=dev)
+        al_g, de_g = torch.empty(CG, **f32), torch.empty(1, CG, **f32)
+        if tr_g:
+            mean_g, inv_g = torch.empty(CG, **f32), torch.empty(CG, **f32)
+            track = bn_g.track_running_stats and bn_g.running_mean is not None
+            rm_g, rv_g = (bn_g.running_mean, bn_g.running_var) if track else (None, None)
+        else:
+            mean_g = bn_g.running_mean.detach().float().contiguous()
+            inv_g = torch.rsqrt(bn_g.running_var.detach().float() + bn_g.eps).contiguous()
+            rm_g = rv_g = None
         with torch.cuda.device(dev):
-            _lib.call("fsg_pw_max_finish_f32", _p(sel_val), _p(sel_arg), _p(sgn), _p(al_g), _p(de_g), B, Npts // 128, CG,
-                      slope, _p(g), _p(ysel), _p(arg), _stream())
+            _lib.call("fsg_pw_bn_finalize_max_f32", _p(rec0), R0, CG + C0, 0, CG, B, int(tr_g), _p(bn_g.weight), _p(bn_g.bias),
+                      float(bn_g.eps), float(mom_g), _p(rm_g), _p(rv_g), _p(mean_g), _p(inv_g), _p(al_g), _p(de_g), _p(sel_val),
+                      _p(sel_arg), _p(sgn), Npts // 128, slope, _p(g), _p(ysel), _p(arg), _stream())
         c = torch.empty(B, C0, **f32)     # g W0_global^T: the global part of the first head layer, one wave per output
         with torch.cuda.device(dev):
             _lib.call("fsg_pw_cloud_linear_f32", _p(g), _p(W0[:, KL:]), W0.stride(0), B, C0, CG, _p(c), _stream())

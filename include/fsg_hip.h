@@ -653,6 +653,13 @@ int fsg_pw_bn_finalize_f32(const float *rec, int R, int ldn, int c0, int C, cons
 int fsg_pw_cloud_linear_f32(const float *x, const float *W, int64_t ldw, int B, int C0, int CG, float *out, fsg_stream_t stream);
 int fsg_pw_max_finish_f32(const float *sel_val, const int32_t *sel_arg, const float *sgn, const float *alpha, const float *delta,
                           int B, int tiles, int C, float slope, float *out, float *ysel, int32_t *arg, fsg_stream_t stream);
+/* fsg_pw_bn_finalize_f32 (no per-cloud shift) and fsg_pw_max_finish_f32 as ONE launch: the statistics of the BatchNorm in front
+ * of the global max-pool and the pool's finish from the SEL records of the same product (models/dgcnn.py:134-137,156); B <= 64. */
+int fsg_pw_bn_finalize_max_f32(const float *rec, int R, int ldn, int c0, int C, int B, int training, const float *gamma,
+                               const float *beta, float eps, float momentum, float *running_mean, float *running_var, float *mean,
+                               float *invstd, float *alpha, float *delta, const float *sel_val, const int32_t *sel_arg,
+                               const float *sgn, int tiles, float slope, float *out, float *ysel, int32_t *arg, fsg_stream_t stream);
+
 int fsg_pw_bnbwd_finalize_f32(const float *rec2, int R, int C, int B, int64_t M, int training, const float *alpha,
                               const float *invstd, const float *emu, int emu_per_cloud, const float *cloud_mean, float *dbeta,
                               float *dgamma, float *P, float *Q, float *dc, fsg_stream_t stream);

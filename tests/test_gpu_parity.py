@@ -1759,7 +1759,7 @@ class GraphTape:
 
         def recording(x, k, c_knn=None, fix_diag=True, drop_first=False, return_dist=False, **kw):
             out = real(x, k, c_knn=c_knn, fix_diag=fix_diag, drop_first=drop_first, return_dist=return_dist, **kw)
-            idx = out[0] if return_dist else out
+            idx = out[0] if (return_dist or kw.get("pq_weight") is not None) else out
             self.calls.append(dict(x=N(x), k=k, c_knn=c_knn, fix_diag=fix_diag, drop_first=drop_first, idx=N(idx)))
             return out
         monkeypatch.setattr(fsg.functional, "knn_graph", recording)
@@ -2853,3 +2853,32 @@ def test_knn_prepared_by_edgeconv_equals_plain_build(fsg, device, B, Np, k, two_
             o_b, p_b = ec(x2, g0, both=True, knn_ws=ws)
         assert torch.equal(F_hip.knn_graph(o_a, k), F_hip.knn_graph(o_b, k, prepared=(ws, p_b)))
     assert F_hip.knn_prep_workspace(B, 1000, 64, device) is None and F_hip.knn_prep_workspace(B, Np, 32, device) is None
+    # round 4: with the NEXT block's [W_rel ; W_ctr - W_rel] weight the same pass also emits that block's per-point rows
+    # (fsg_edgeconv_apply_pq_f32): outputs and prep unchanged bit for bit, rows = out_pm W^T (exact fp32 matrix instruction:
+    # an fp32 fma chain's error against float64), and a block handed those rows computes what it computes from its own product
+    nxt = fill_state_dict(EdgeConv(64, [64], k), 92).to(device).train()
+    (w_next,) = EdgeConv.pq_weights([nxt])
+    with torch.no_grad():
+        out_c, pm_c, pq_next = ec(x, g0, both=True, knn_ws=ws, w_next=w_next)
+    assert torch.equal(out_c, out_a) and torch.equal(pm_c, pm_a) and pq_next is not None and tuple(pq_next.shape) == (B, Np, 128)
+    assert torch.equal(F_hip.knn_graph(out_c, k, prepared=(ws, pm_c)), plain)
+    want_pq = pm_a.double() @ w_next.detach().double().t()
+    assert float((pq_next.double() - want_pq).abs().max()) <= 2e-6 * float(want_pq.abs().max())
+    xa = out_a.clone().requires_grad_(True)
+    xb = out_a.clone().requires_grad_(True)
+    with F_hip.deferred_bn_counters():
+        ya = nxt(xa, plain, x_pm=xa.transpose(1, 2).contiguous())
+    for p_ in nxt.parameters():
+        p_.grad = None
+    ga = torch.randn_like(ya)
+    ya.backward(ga)
+    grads_a = [p_.grad.clone() for p_ in nxt.parameters()]
+    for p_ in nxt.parameters():
+        p_.grad = None
+    with F_hip.deferred_bn_counters():
+        yb = nxt(xb, plain, x_pm=xb.transpose(1, 2).contiguous(), pq_given=pq_next)
+    yb.backward(ga)
+    assert float((ya - yb).abs().max()) <= 1e-5 * float(ya.abs().max())
+    for a_, p_ in zip(grads_a, nxt.parameters()):
+        assert float((a_ - p_.grad).norm()) <= 1e-4 * float(a_.norm()) + 1e-8
+    assert float((xa.grad - xb.grad).norm()) <= 1e-4 * float(xa.grad.norm())
