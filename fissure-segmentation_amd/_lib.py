@@ -7,7 +7,8 @@ import torch  # noqa: F401  -- must come first: brings torch's libamdhip64 into 
 #                              library's DT_NEEDED libamdhip64.so.7 then resolves to (one HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfsg_hip.so")
+# (FSG_HIP_LIB: another BUILD of the same library -- tools/ use it to A/B compile-time variants on one box; still no fallback)
+LIB_PATH = os.environ.get("FSG_HIP_LIB") or os.path.join(_HERE, "libfsg_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -71,6 +72,8 @@ SIGNATURES = {
     "fsg_gemm_small_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),
     "fsg_gemm_small_f32": ([_P, _L, _L, _P, _L, _L, _P, _P, _L, _I, _I, _I, _P, _P], _I),
     "fsg_gemm_small_rowsum_f32": ([_P, _L, _L, _P, _L, _L, _P, _P, _L, _I, _I, _I, _P, _P, _P], _I),
+    "fsg_gemm_small_deferred_f32": ([_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, _P, _P, _P, _P], _I),
+    "fsg_gemm_small_reduce_many_f32": ([_P, _P], _I),
     "fsg_pt_attn_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),
     "fsg_pt_attn_fwd_f32": ([_P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P], _I),
     "fsg_pt_attn_bwd_f32": ([_P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P], _I),
@@ -134,6 +137,16 @@ class PTLayerParams(ctypes.Structure):
     _fields_ = [(n, _P) for n in ("lp1_w", "lp1_b", "bnp_g", "bnp_b", "bnp_rm", "bnp_rv", "lp2_w", "lp2_b", "bn1_g", "bn1_b",
                                   "bn1_rm", "bn1_rv", "lw1_w", "lw1_b", "bn2_g", "bn2_b", "bn2_rm", "bn2_rv", "lw2_w",
                                   "lw2_b")] + [(n, _F) for n in ("eps_p", "eps_1", "eps_2", "mom_p", "mom_1", "mom_2")]
+
+
+GEMM_REDUCE_MAX_JOBS = 48
+
+
+class GemmReduceJobs(ctypes.Structure):
+    """include/fsg_hip.h: fsg_gemm_reduce_jobs"""
+    _fields_ = [("part", _P * GEMM_REDUCE_MAX_JOBS), ("C", _P * GEMM_REDUCE_MAX_JOBS), ("rowsum", _P * GEMM_REDUCE_MAX_JOBS),
+                ("ldc", _L * GEMM_REDUCE_MAX_JOBS), ("S", _I * GEMM_REDUCE_MAX_JOBS), ("I", _I * GEMM_REDUCE_MAX_JOBS),
+                ("J", _I * GEMM_REDUCE_MAX_JOBS), ("blocks", _I * GEMM_REDUCE_MAX_JOBS), ("n", _I)]
 
 
 class EdgeWeightJobs(ctypes.Structure):

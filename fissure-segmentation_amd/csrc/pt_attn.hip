@@ -20,12 +20,21 @@
 // LDS; the per-wave partial products are summed in wave order.
 #include "fsg_common.h"
 
+#ifndef FSG_PT_GMAX_SCALE
+#define FSG_PT_GMAX_SCALE 1
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef fsg_pt_layer_params Prm;
 
 constexpr int MAXNS = 16;
+
+// workgroups per launch at most (each leaves one record per BatchNorm / parameter sum): four per CU -- a tile is a chain of
+// barrier-separated phases with dependent gathers, and with one workgroup per CU (round 3) nothing hid them: 7.58 -> 6.84 ms per
+// config-3 step; 8 and 16 per CU measure 6.90.  FSG_PT_GMAX_SCALE (tools only) scales it.
+constexpr int pt_gmax(int c) { return (c <= 128 ? 1024 : (c == 256 ? 512 : 256)) * FSG_PT_GMAX_SCALE; }
 
 template <int C>
 struct Geo {
@@ -39,7 +48,7 @@ struct Geo {
     static constexpr int CSP = OB * 16;
     static constexpr int HS = C + 4;           // LDS row stride of the h1 tile
     static constexpr int EMAX = PT * MAXNS;
-    static constexpr int GMAX = C <= 128 ? 256 : (C == 256 ? 128 : 64);
+    static constexpr int GMAX = pt_gmax(C);
 };
 
 struct Stats {

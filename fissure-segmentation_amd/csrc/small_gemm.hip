@@ -156,6 +156,31 @@ __global__ __launch_bounds__(256) void gemm_small_reduce_kernel(const float *__r
     }
 }
 
+// the reductions of up to FSG_GEMM_REDUCE_MAX_JOBS deferred products in ONE launch (fsg_gemm_small_reduce_many_f32): the weight
+// gradients of a backward pass are read by nobody until the optimizer runs, so their split sums need not sit between the
+// products on the stream.  One thread per output, splits summed in split order (fixed: reproducible).
+__global__ __launch_bounds__(256) void gemm_small_reduce_many_kernel(fsg_gemm_reduce_jobs jobs) {
+    int j = 0;
+    long b = blockIdx.x;
+    while (j < jobs.n - 1 && b >= jobs.blocks[j]) { b -= jobs.blocks[j]; ++j; }
+    const float *part = jobs.part[j];
+    const int S = jobs.S[j], I = jobs.I[j], J = jobs.J[j];
+    const long IJ = (long)I * J, t = b * 256 + threadIdx.x;
+    float *rowsum = jobs.rowsum[j];
+    if (rowsum && t >= IJ && t < IJ + I) {
+        float a = 0.f;
+        for (int s = 0; s < S; ++s) a += part[(long)S * IJ + (long)s * I + (t - IJ)];
+        rowsum[t - IJ] = a;
+    }
+    if (t >= IJ) return;
+    float a = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < S; ++s) a += part[(long)s * IJ + t];
+    const long row = t / J;
+    const int col = (int)(t - row * J);
+    jobs.C[j][row * jobs.ldc[j] + col] = a;
+}
+
 // number of reduction splits: several workgroups per CU (the kernel is latency-bound: co-resident workgroups hide
 // the operand loads), at least FSG_GEMM_SPLIT_MIN (default 64) reduction steps each (measured on the PointTransformer step: 32: 8.9, 64: 8.9, 128: 9.05, 256: 9.5 ms)
 inline int splits_for(int I, int J, int K) {
@@ -187,9 +212,48 @@ extern "C" int fsg_gemm_small_f32(const float *A, int64_t sa_i, int64_t sa_k, co
     return fsg_gemm_small_rowsum_f32(A, sa_i, sa_k, B, sb_k, sb_j, bias, C, ldc, I, J, K, nullptr, workspace, stream);
 }
 
+namespace {
+int gemm_small_launch(const float *A, int64_t sa_i, int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_j, const float *bias,
+                      float *C, int64_t ldc, int I, int J, int K, float *rowsum, void *workspace, int *deferred_splits,
+                      fsg_stream_t stream);
+}
+
 extern "C" int fsg_gemm_small_rowsum_f32(const float *A, int64_t sa_i, int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_j,
                                          const float *bias, float *C, int64_t ldc, int I, int J, int K, float *rowsum,
                                          void *workspace, fsg_stream_t stream) {
+    return gemm_small_launch(A, sa_i, sa_k, B, sb_k, sb_j, bias, C, ldc, I, J, K, rowsum, workspace, nullptr, stream);
+}
+
+// The product WITHOUT its split reduction: *splits = S > 1 when the partial products [S][I*J] (+ row-sum partials [S][I]) were
+// left in `workspace` for fsg_gemm_small_reduce_many_f32 (the caller keeps the workspace alive until then), 0 when the shape
+// needed no split and C (and rowsum) are final.  No bias (a deferred product is a gradient).
+extern "C" int fsg_gemm_small_deferred_f32(const float *A, int64_t sa_i, int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_j,
+                                           float *C, int64_t ldc, int I, int J, int K, float *rowsum, void *workspace, int *splits,
+                                           fsg_stream_t stream) {
+    FSG_REQUIRE(splits, "fsg_gemm_small_deferred_f32: NULL splits");
+    return gemm_small_launch(A, sa_i, sa_k, B, sb_k, sb_j, nullptr, C, ldc, I, J, K, rowsum, workspace, splits, stream);
+}
+
+extern "C" int fsg_gemm_small_reduce_many_f32(const fsg_gemm_reduce_jobs *jobs, fsg_stream_t stream) {
+    FSG_REQUIRE(jobs && jobs->n >= 1 && jobs->n <= FSG_GEMM_REDUCE_MAX_JOBS, "fsg_gemm_small_reduce_many_f32: bad job count");
+    fsg_gemm_reduce_jobs j = *jobs;
+    long total = 0;
+    for (int i = 0; i < j.n; ++i) {
+        FSG_REQUIRE(j.part[i] && j.C[i] && j.S[i] >= 1 && j.I[i] > 0 && j.J[i] > 0 && j.ldc[i] >= j.J[i],
+                    "fsg_gemm_small_reduce_many_f32: bad job %d", i);
+        j.blocks[i] = (int)fsg_cdiv((long)j.I[i] * j.J[i] + (j.rowsum[i] ? j.I[i] : 0), 256L);
+        total += j.blocks[i];
+    }
+    FSG_REQUIRE(total < (1L << 31), "fsg_gemm_small_reduce_many_f32: too many outputs");
+    hipLaunchKernelGGL(gemm_small_reduce_many_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, j);
+    FSG_CHECK_LAUNCH("fsg_gemm_small_reduce_many_f32");
+    return FSG_OK;
+}
+
+namespace {
+int gemm_small_launch(const float *A, int64_t sa_i, int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_j, const float *bias,
+                      float *C, int64_t ldc, int I, int J, int K, float *rowsum, void *workspace, int *deferred_splits,
+                      fsg_stream_t stream) {
     FSG_REQUIRE(A && B && C, "fsg_gemm_small_f32: NULL pointer");
     FSG_REQUIRE(I > 0 && J > 0 && K > 0 && ldc >= J, "fsg_gemm_small_f32: bad shape I=%d J=%d K=%d ldc=%ld", I, J, K, (long)ldc);
     FSG_REQUIRE(fsg_cdiv(J, TJ) <= 65535, "fsg_gemm_small_f32: J too large");
@@ -202,6 +266,10 @@ extern "C" int fsg_gemm_small_rowsum_f32(const float *A, int64_t sa_i, int64_t s
     hipLaunchKernelGGL(gemm_small_kernel, dim3(fsg_cdiv(I, TI), fsg_cdiv(J, TJ), S_eff), dim3(256), 0, st, A, (long)sa_i,
                        (long)sa_k, B, (long)sb_k, (long)sb_j, bias, C, (long)ldc, I, J, K, kchunk, part, rowsum);
     FSG_CHECK_LAUNCH("fsg_gemm_small_f32");
+    if (deferred_splits) {
+        *deferred_splits = part ? S_eff : 0;
+        return FSG_OK;
+    }
     if (part) {
         const long IJ = (long)I * J, outs = IJ + (rowsum ? I : 0);
         if (S_eff >= 16)
@@ -214,3 +282,4 @@ extern "C" int fsg_gemm_small_rowsum_f32(const float *A, int64_t sa_i, int64_t s
     }
     return FSG_OK;
 }
+}  // namespace

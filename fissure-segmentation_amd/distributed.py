@@ -158,6 +158,9 @@ class BucketedGradAverager:
             b["pending"], b["flat"], b["work"] = len(b["params"]), None, None
 
     def _launch(self, b, side):
+        if self.params[0].is_cuda:      # weight gradients whose split sums were left for the end of the backward pass
+            from . import functional as F_hip
+            F_hip.flush_deferred_reduces()
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b["params"]]
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())

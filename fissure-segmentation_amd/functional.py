@@ -258,17 +258,83 @@ def edge_features(x, idx):
 SMALL_GEMM_FLOPS = 6e8   # below this the vendor GEMM tends to pick one huge macro-tile (one workgroup): use fsg_gemm_small_f32
 
 
-def gemm_small(a, sa_i, sa_k, b, sb_k, sb_j, bias, I, J, K, rowsum=False):
+def gemm_small(a, sa_i, sa_k, b, sb_k, sb_j, bias, I, J, K, rowsum=False, defer=False):
     """C (I,J) = A(i,k) B(k,j) (+ bias[j]) with explicit element strides -- include/fsg_hip.h: fsg_gemm_small_f32.
-    rowsum=True: also sum_k A(i,k) (fsg_gemm_small_rowsum_f32: the bias gradient next to a weight gradient) -> (C, rowsum)"""
+    rowsum=True: also sum_k A(i,k) (fsg_gemm_small_rowsum_f32: the bias gradient next to a weight gradient) -> (C, rowsum).
+    defer=True (no bias): the split reduction is left to ONE launch for all deferred products of the running backward pass
+    (fsg_gemm_small_reduce_many_f32 from an end-of-backward callback of the autograd engine; at once outside a backward pass):
+    the returned tensors are complete when `loss.backward()` returns -- for weight gradients, which nothing reads before."""
     out = torch.empty(I, J, dtype=torch.float32, device=a.device)
     nbytes = _lib.lib.fsg_gemm_small_workspace_bytes(I, J, K)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=a.device) if nbytes else None
     rs = torch.empty(I, dtype=torch.float32, device=a.device) if rowsum else None
     with torch.cuda.device(a.device):
-        _lib.call("fsg_gemm_small_rowsum_f32", _p(a), sa_i, sa_k, _p(b), sb_k, sb_j, _p(bias), _p(out), J, I, J, K, _p(rs), _p(ws),
-                  _stream())
+        if defer and bias is None:
+            splits = ctypes.c_int(0)
+            _lib.call("fsg_gemm_small_deferred_f32", _p(a), sa_i, sa_k, _p(b), sb_k, sb_j, _p(out), J, I, J, K, _p(rs), _p(ws),
+                      ctypes.byref(splits), _stream())
+            if splits.value > 1:
+                # raw addresses, not the tensors: AccumulateGrad takes a gradient over as `.grad` only when nobody else holds it
+                # (it would copy -- the unreduced bytes -- otherwise); `.grad` then keeps the memory alive past the flush
+                _defer_reduce((ws, out.data_ptr(), rs.data_ptr() if rs is not None else None, splits.value, I, J, a.device))
+        else:
+            _lib.call("fsg_gemm_small_rowsum_f32", _p(a), sa_i, sa_k, _p(b), sb_k, sb_j, _p(bias), _p(out), J, I, J, K, _p(rs),
+                      _p(ws), _stream())
     return (out, rs) if rowsum else out
+
+
+_pending_reduces = []     # (partials, &C, &rowsum | None, S, I, J, device) of the running backward pass
+_defer_weight_grads = True
+
+
+def set_deferred_weight_grads(flag):
+    """Weight gradients of the small Linears that go straight to a leaf parameter are summed over their reduction splits by ONE
+    launch at the end of the backward pass (default on).  Turn off when something reads parameter gradients DURING the backward
+    pass (gradient hooks that copy them, e.g. torch's DistributedDataParallel buckets); this package's own
+    BucketedGradAverager flushes before it reads."""
+    global _defer_weight_grads
+    _defer_weight_grads = bool(flag)
+
+
+def _grad_targets(w):
+    """the leaf parameters that the gradient of `w` ends in WITHOUT being read on the way, or None: `w` itself when it is a leaf;
+    the parameters a producer names in `w._fsg_grad_unread` when its backward only hands views of the gradient on (_PackQKV)"""
+    if w.is_leaf:
+        return (w,)
+    return getattr(w, "_fsg_grad_unread", None)
+
+
+def _may_defer(targets):
+    """Deferring a weight gradient's split sum to the end of the backward pass is sound when the autograd engine merely STORES the
+    tensor until then: it goes to parameters whose `.grad` is empty (AccumulateGrad adopts the tensor; with a gradient already
+    there it would add -- unreduced bytes), outside create_graph, and the switch is on."""
+    return (_defer_weight_grads and targets is not None and not torch.is_grad_enabled() and
+            all(p.grad is None for p in targets))
+
+
+def flush_deferred_reduces():
+    """sum the split partials of every deferred gemm_small product (see gemm_small(defer=True)); idempotent"""
+    global _pending_reduces
+    jobs, _pending_reduces = _pending_reduces, []
+    for i0 in range(0, len(jobs), _lib.GEMM_REDUCE_MAX_JOBS):
+        chunk = jobs[i0:i0 + _lib.GEMM_REDUCE_MAX_JOBS]
+        tab = _lib.GemmReduceJobs()
+        for i, (ws, out, rs, S, I, J, _dev) in enumerate(chunk):
+            tab.part[i], tab.C[i], tab.rowsum[i] = ws.data_ptr(), out, rs
+            tab.ldc[i], tab.S[i], tab.I[i], tab.J[i] = J, S, I, J
+        tab.n = len(chunk)
+        with torch.cuda.device(chunk[0][6]):
+            _lib.call("fsg_gemm_small_reduce_many_f32", ctypes.byref(tab), _stream())
+
+
+def _defer_reduce(job):
+    _pending_reduces.append(job)
+    # (queued per product, not once per pass: a pass that dies half-way never runs its callbacks, and a flag would then keep the
+    # next pass from queueing; the first callback to run does the work, the others find the list empty)
+    try:     # runs when the engine has finished this backward pass, with the caller's current stream
+        torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_reduces)
+    except RuntimeError:     # not inside a backward pass
+        flush_deferred_reduces()
 
 
 def _small(I, J, K, *tensors):
@@ -293,6 +359,8 @@ class _LinearPM(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         ctx.bf16 = ctx.pw16 = False
+        tw, tb = _grad_targets(w), (_grad_targets(b) if b is not None else ())
+        ctx.defer_targets = tw + tb if (tw is not None and tb is not None) else None
         x2 = x.reshape(-1, x.shape[-1])
         N, K = w.shape
         M = x2.shape[0]
@@ -333,7 +401,7 @@ class _LinearPM(torch.autograd.Function):
             gx = _linear_dx(g2, w, bf16=ctx.bf16).view_as(x)
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            gw = _linear_dw(g2, x2, bf16=ctx.bf16, with_bias_grad=want_gb)
+            gw = _linear_dw(g2, x2, bf16=ctx.bf16, with_bias_grad=want_gb, defer=_may_defer(ctx.defer_targets))
             if isinstance(gw, tuple):      # the small-GEMM path hands the bias gradient (row sums of dY^T) over with the product
                 gw, gb = gw
         if want_gb and gb is None:
@@ -353,16 +421,17 @@ def _linear_dx(g2, w, out=None, bf16=False):
     return gemm_small(g2, N, 1, w, K, 1, None, M, K, N) if _small(M, K, N, g2, w) else g2 @ w
 
 
-def _linear_dw(g2, x2, bf16=False, with_bias_grad=False):
+def _linear_dw(g2, x2, bf16=False, with_bias_grad=False, defer=False):
     """dW = dY^T X: a tiny output behind a long reduction (see _LinearPM).  with_bias_grad: the small-GEMM path returns
-    (dW, db) -- db = column sums of dY as a by-product of the same launch; the other paths return dW alone"""
+    (dW, db) -- db = column sums of dY as a by-product of the same launch; the other paths return dW alone.
+    defer: the caller knows that nothing reads the result inside this backward pass (gemm_small(defer=True))"""
     M, N = g2.shape
     K = x2.shape[1]
     if bf16:
         return _bf16_mm(g2.t(), x2)
     S = 16 if (M % 16 == 0 and M >= 4096) else 1
     if _small(N, K, M, g2, x2):
-        return gemm_small(g2, 1, N, x2, K, 1, None, N, K, M, rowsum=with_bias_grad)
+        return gemm_small(g2, 1, N, x2, K, 1, None, N, K, M, rowsum=with_bias_grad, defer=defer)
     if S > 1 and x2.is_contiguous():
         return torch.bmm(g2.view(S, M // S, -1).transpose(1, 2), x2.view(S, M // S, -1)).sum(0)
     return g2.t() @ x2
@@ -1812,6 +1881,70 @@ def vec_attn(v, pos, w, idx):
     if pos.shape != (v.shape[0], idx.shape[1], v.shape[1]) or w.shape[:2] != pos.shape[:2] or v.shape[1] % w.shape[2]:
         raise ValueError(f"vec_attn: inconsistent shapes v{tuple(v.shape)} pos{tuple(pos.shape)} w{tuple(w.shape)}")
     return _VecAttn.apply(v, pos, w, idx.to(torch.int32).contiguous())
+
+
+# ------------------------------------------------------------------ [Wq ; Wk ; Wv] of every PointTransformerLayer, one launch
+class _PackQKV(torch.autograd.Function):
+    """inputs: (Wq, Wk, Wv, bq, bk, bv) per layer -> outputs: (W_qkv (3c, c), b_qkv (3c)) per layer, all views of ONE buffer that
+    one torch.cat fills (ATen copies up to 128 pieces per launch).  The backward hands views of the incoming gradients on: no
+    launch, and it does not read them -- which is what lets the products' weight gradients be reduced late (gemm_small defer)."""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, *ts):
+        L = len(ts) // 6
+        ctx.cs = [ts[6 * i].shape for i in range(L)]
+        arena = torch.cat([t.reshape(-1) for t in ts])
+        outs, off = [], 0
+        for i in range(L):
+            co, ci = ctx.cs[i]
+            outs.append(arena[off:off + 3 * co * ci].view(3 * co, ci))
+            off += 3 * co * ci
+            outs.append(arena[off:off + 3 * co])
+            off += 3 * co
+        return tuple(outs)
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, *gs):
+        res = []
+        for i, (co, ci) in enumerate(ctx.cs):
+            gw, gb = gs[2 * i], gs[2 * i + 1]
+            res += [None] * 3 if gw is None else [gw[0:co], gw[co:2 * co], gw[2 * co:3 * co]]
+            res += [None] * 3 if gb is None else [gb[0:co], gb[co:2 * co], gb[2 * co:3 * co]]
+        return tuple(res)
+
+
+_qkv_packs = None      # {id(layer): (W_qkv, b_qkv)} inside qkv_pack()
+
+
+@_contextlib.contextmanager
+def qkv_pack(layers):
+    """packs the q / k / v weights and biases of `layers` (modules with linear_q / linear_k / linear_v of equal output width) for
+    the duration of one forward; PointTransformerLayer.forward picks its pair up through packed_qkv(layer)"""
+    global _qkv_packs
+    outer = _qkv_packs
+    ok = [m for m in layers if m.linear_q.weight.is_cuda and m.linear_q.bias is not None and
+          m.linear_q.weight.shape == m.linear_k.weight.shape == m.linear_v.weight.shape]
+    ts = [t for m in ok for t in (m.linear_q.weight, m.linear_k.weight, m.linear_v.weight, m.linear_q.bias, m.linear_k.bias,
+                                  m.linear_v.bias)]
+    packs = {}
+    if ts:
+        outs = _PackQKV.apply(*ts)
+        for i, m in enumerate(ok):
+            w, b = outs[2 * i], outs[2 * i + 1]
+            w._fsg_grad_unread = (m.linear_q.weight, m.linear_k.weight, m.linear_v.weight)
+            b._fsg_grad_unread = (m.linear_q.bias, m.linear_k.bias, m.linear_v.bias)
+            packs[id(m)] = (w, b)
+    _qkv_packs = packs
+    try:
+        yield
+    finally:
+        _qkv_packs = outer
+
+
+def packed_qkv(layer):
+    return _qkv_packs.get(id(layer)) if _qkv_packs is not None else None
 
 
 # ------------------------------------------------------------------ fused PointTransformerLayer body (seg_model.py:38-53)

@@ -70,8 +70,9 @@ def furthestsampling(xyz, offset, new_offset):
     return F_hip.fps(xyz, offset, new_offset, host_offsets(new_offset)[-1])
 
 
-def knnquery(nsample, xyz, new_xyz, offset, new_offset):
-    """pointops.py:42-62 -> (idx (m,nsample) int32, distance (m,nsample)); not differentiable."""
+def knn_squared(nsample, xyz, new_xyz, offset, new_offset):
+    """the query behind knnquery -> (idx (m,nsample) int32, SQUARED distance (m,nsample)); memoised inside knn_cache().
+    Callers that only want the indices (the attention layers, queryandgroup) use this and skip the square-root launch."""
     if new_xyz is None:
         new_xyz = xyz
     assert xyz.is_contiguous() and new_xyz.is_contiguous()
@@ -79,11 +80,16 @@ def knnquery(nsample, xyz, new_xyz, offset, new_offset):
            new_xyz.shape[0], nsample)
     if _knn_memo is not None and key in _knn_memo:
         return _knn_memo[key]
-    idx, d2 = F_hip.knn_segment(nsample, xyz, new_xyz, offset, new_offset)
-    out = (idx, torch.sqrt(d2))
+    out = F_hip.knn_segment(nsample, xyz, new_xyz, offset, new_offset)
     if _knn_memo is not None:
         _knn_memo[key] = out
     return out
+
+
+def knnquery(nsample, xyz, new_xyz, offset, new_offset):
+    """pointops.py:42-62 -> (idx (m,nsample) int32, distance (m,nsample)); not differentiable."""
+    idx, d2 = knn_squared(nsample, xyz, new_xyz, offset, new_offset)
+    return idx, torch.sqrt(d2)
 
 
 def grouping(input, idx):
@@ -97,7 +103,7 @@ def queryandgroup(nsample, xyz, new_xyz, feat, idx, offset, new_offset, use_xyz=
         new_xyz = xyz
     assert xyz.is_contiguous() and new_xyz.is_contiguous() and feat.is_contiguous()
     if idx is None:
-        idx, _ = knnquery(nsample, xyz, new_xyz, offset, new_offset)
+        idx, _ = knn_squared(nsample, xyz, new_xyz, offset, new_offset)
     grouped_feat = grouping(feat, idx)
     if not use_xyz:
         return grouped_feat

@@ -71,12 +71,14 @@ class PointTransformerLayer(nn.Module):
 
     def forward(self, pxo):
         p, x, o = pxo
-        idx, _ = pointops.knnquery(self.nsample, p, p, o, o)  # one graph for keys and values
+        idx, _ = pointops.knn_squared(self.nsample, p, p, o, o)  # one graph for keys and values
         if self.fused and self.out_planes in F_hip.PT_ATTN_PLANES and self.nsample <= 16 and self.share_planes == 8:
             # q, k, v as ONE GEMM, then everything up to the aggregate in the fused HIP layer (no (n,ns,c) tensor in HBM)
-            w_qkv = torch.cat([self.linear_q.weight, self.linear_k.weight, self.linear_v.weight], 0)
-            b_qkv = torch.cat([self.linear_q.bias, self.linear_k.bias, self.linear_v.bias], 0)
-            return F_hip.pt_attn(p, idx, F_hip.linear_pm(x, w_qkv, b_qkv), self.linear_p, self.linear_w)
+            packed = F_hip.packed_qkv(self)
+            if packed is None:      # outside PointTransformerSeg.forward: this layer's own two cats
+                packed = (torch.cat([self.linear_q.weight, self.linear_k.weight, self.linear_v.weight], 0),
+                          torch.cat([self.linear_q.bias, self.linear_k.bias, self.linear_v.bias], 0))
+            return F_hip.pt_attn(p, idx, F_hip.linear_pm(x, *packed), self.linear_p, self.linear_w)
         q, k, v = _lin(self.linear_q, x), _lin(self.linear_k, x), _lin(self.linear_v, x)
         rel = pointops.grouping(p, idx) - p.unsqueeze(1)       # (n, ns, 3)
         gk = pointops.grouping(k, idx)                         # (n, ns, c)
@@ -207,7 +209,9 @@ class PointTransformerSeg(nn.Module):
         if not p0.is_cuda:
             raise RuntimeError("PointTransformer (HIP path) needs its input on the GPU")
         x0 = p0 if self.c == 3 else torch.cat((p0, x0), 1)
-        with pointops.knn_cache():
+        layers = [m for m in self.modules() if isinstance(m, PointTransformerLayer)]
+        # [Wq ; Wk ; Wv] and [bq ; bk ; bv] of ALL layers by one copy launch (two cats per layer before)
+        with pointops.knn_cache(), F_hip.qkv_pack(layers):
             levels = [self.enc1([p0, x0, o0])]
             for lvl in range(2, 6):
                 levels.append(getattr(self, f'enc{lvl}')(levels[-1]))

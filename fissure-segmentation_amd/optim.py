@@ -70,6 +70,9 @@ class FlatAdam:
     def gather_grads(self):
         """concatenate the parameters' gradients into the flat gradient buffer (`self.flat.grad`); under data parallelism
         that buffer is what gets all-reduced -- one collective, no unflatten"""
+        if self.flat.is_cuda:      # (a no-op after a finished backward pass: the engine's end-of-pass callback has run)
+            from . import functional as F_hip
+            F_hip.flush_deferred_reduces()
         grads = [p.grad.reshape(-1) if p.grad is not None else torch.zeros_like(v) for p, v in zip(self.params, self._views)]
         torch.cat(grads, out=self.flat.grad)
         return self.flat.grad

@@ -394,6 +394,26 @@ int fsg_gemm_small_rowsum_f32(const float *A, int64_t sa_i, int64_t sa_k, const 
                               const float *bias, float *C, int64_t ldc, int I, int J, int K, float *rowsum, void *workspace,
                               fsg_stream_t stream);
 
+/* Deferred split reduction (PointTransformer backward: 50 weight gradients per step, each a tiny output behind a reduction over
+ * all points).  fsg_gemm_small_deferred_f32 runs the product only: *splits = S > 1 when the S partial products (and row-sum
+ * partials) were left in `workspace`, which the caller keeps alive; 0 when C / rowsum are already final.
+ * fsg_gemm_small_reduce_many_f32 then sums up to FSG_GEMM_REDUCE_MAX_JOBS such products in ONE launch, in split order
+ * (reproducible).  `blocks` is filled by the callee. */
+#define FSG_GEMM_REDUCE_MAX_JOBS 48
+typedef struct fsg_gemm_reduce_jobs {
+    const float *part[FSG_GEMM_REDUCE_MAX_JOBS];
+    float *C[FSG_GEMM_REDUCE_MAX_JOBS];
+    float *rowsum[FSG_GEMM_REDUCE_MAX_JOBS];
+    int64_t ldc[FSG_GEMM_REDUCE_MAX_JOBS];
+    int32_t S[FSG_GEMM_REDUCE_MAX_JOBS], I[FSG_GEMM_REDUCE_MAX_JOBS], J[FSG_GEMM_REDUCE_MAX_JOBS], blocks[FSG_GEMM_REDUCE_MAX_JOBS];
+    int32_t n;
+} fsg_gemm_reduce_jobs;
+int fsg_gemm_small_deferred_f32(const float *A, int64_t sa_i, int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_j, float *C,
+                                int64_t ldc, int I, int J, int K, float *rowsum, void *workspace, int *splits,
+                                fsg_stream_t stream);
+int fsg_gemm_small_reduce_many_f32(const fsg_gemm_reduce_jobs *jobs, fsg_stream_t stream);
+
+
 /*
  * Fused PointTransformerLayer body: replaces models/pointtransformer/seg_model.py:38-53 after the three
  * q/k/v Linears (:37), i.e. neighbour grouping of keys, values and coordinates, linear_p (Linear(3,3) -> BatchNorm1d(3)

@@ -541,9 +541,33 @@ def test_linear_pm_routing_and_grads(fsg, device):
         y = fsg.functional.linear_pm(xt, wt, bt)
         y.backward(G(g.astype(np.float32), device))
         timed = fsg._lib.stop_timing()
-        assert len(timed.get("fsg_gemm_small_f32", [])) + len(timed.get("fsg_gemm_small_rowsum_f32", [])) == n_small, (M, Nn, K)
+        assert sum(len(timed.get(f"fsg_gemm_small_{e}f32", [])) for e in ("", "rowsum_", "deferred_")) == n_small, (M, Nn, K)
         for got, ref in [(y, x @ w.T + b), (xt.grad, g @ w), (wt.grad, g.T @ x), (bt.grad, g.sum(0))]:
             assert np.abs(N(got) - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+        # the weight gradient of a leaf parameter leaves its split sum to the end of the backward pass (one launch for all deferred
+        # products: fsg_gemm_small_reduce_many_f32); same partial products, summed in split order (fp32 rounding apart)
+        if "fsg_gemm_small_deferred_f32" in timed:
+            assert len(timed.get("fsg_gemm_small_reduce_many_f32", [])) == 1
+            fsg.functional.set_deferred_weight_grads(False)
+            try:
+                x2, w2, b2 = (v.detach().clone().requires_grad_(True) for v in (xt, wt, bt))
+                fsg.functional.linear_pm(x2, w2, b2).backward(G(g.astype(np.float32), device))
+            finally:
+                fsg.functional.set_deferred_weight_grads(True)
+            close = lambda a, b: float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())  # noqa: E731
+            assert close(w2.grad, wt.grad) and close(b2.grad, bt.grad)
+            # a weight that is NOT a leaf (its gradient is read by the producer's backward) is reduced at once
+            x3, w3 = xt.detach().clone().requires_grad_(True), wt.detach().clone().requires_grad_(True)
+            fsg._lib.start_timing()
+            fsg.functional.linear_pm(x3, w3 * 1.0, None).backward(G(g.astype(np.float32), device))
+            assert "fsg_gemm_small_deferred_f32" not in fsg._lib.stop_timing()
+            assert close(w3.grad, wt.grad)
+            # ... and so is one that ACCUMULATES into a gradient that is already there (AccumulateGrad adds on the spot)
+            first = wt.grad.clone()
+            fsg._lib.start_timing()
+            fsg.functional.linear_pm(xt, wt, bt).backward(G(g.astype(np.float32), device))
+            assert "fsg_gemm_small_deferred_f32" not in fsg._lib.stop_timing()
+            assert close(wt.grad, 2 * first)
 
 
 @pytest.mark.parametrize("M,C,relu,res,train", [(16384, 32, True, False, True), (4096, 64, True, True, True),
