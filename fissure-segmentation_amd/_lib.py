@@ -74,6 +74,7 @@ SIGNATURES = {
     "fsg_gemm_small_rowsum_f32": ([_P, _L, _L, _P, _L, _L, _P, _P, _L, _I, _I, _I, _P, _P, _P], _I),
     "fsg_gemm_small_deferred_f32": ([_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, _P, _P, _P, _P], _I),
     "fsg_gemm_small_reduce_many_f32": ([_P, _P], _I),
+    "fsg_gemm_small_bf16": ([_P, _L, _L, _P, _L, _L, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P], _I),
     "fsg_pt_attn_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),
     "fsg_pt_attn_fwd_f32": ([_P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P], _I),
     "fsg_pt_attn_bwd_f32": ([_P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P], _I),

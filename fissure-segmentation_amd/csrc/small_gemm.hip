@@ -100,6 +100,91 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const float *__restrict
     }
 }
 
+// bf16 operand mode (BASELINE config 3 names bf16): the same tiling, split and epilogue, but both operands are rounded to bf16
+// (round to nearest even, as torch's .bfloat16()) on their way into LDS and the products run on v_mfma_f32_32x32x16_bf16 with
+// fp32 accumulation -- two matrix instructions per 32-deep tile and wave instead of sixteen.  LDS tiles are row-major [64][32 + 8]
+// bf16 (a fragment = eight consecutive k of one row = one 16-byte read).  The row-sum by-product sums the ROUNDED values.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+constexpr int LDH = TK + 8;   // bf16 row stride (80 bytes: 16-byte aligned fragments, rows spread over the banks)
+__device__ __forceinline__ u16 to_bf16(float x) {
+    const __bf16 h = (__bf16)x;
+    return __builtin_bit_cast(u16, h);
+}
+__global__ __launch_bounds__(256) void gemm_small_bf16_kernel(const float *__restrict__ A, long sai, long sak,
+                                                              const float *__restrict__ B, long sbk, long sbj,
+                                                              const float *__restrict__ bias, float *__restrict__ C, long ldc,
+                                                              int I, int J, int K, int kchunk, float *__restrict__ part,
+                                                              float *__restrict__ rowsum) {
+    __shared__ __attribute__((aligned(16))) u16 As[TI * LDH], Bs[TJ * LDH];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, ql = lane & 31, half = lane >> 5;
+    const int i0 = blockIdx.x * TI, j0 = blockIdx.y * TJ;
+    const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    const bool a_kfast = sak == 1, b_kfast = sbk == 1;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    float av[LPT], bv[LPT];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int r = 0; r < LPT; ++r) {
+            const int t = r * 256 + tid;
+            const int ai = a_kfast ? t / TK : t % TI, ak = a_kfast ? t % TK : t / TI;
+            const int bj = b_kfast ? t / TK : t % TJ, bk = b_kfast ? t % TK : t / TJ;
+            av[r] = (i0 + ai < I && k0 + ak < kend) ? A[(long)(i0 + ai) * sai + (long)(k0 + ak) * sak] : 0.f;
+            bv[r] = (j0 + bj < J && k0 + bk < kend) ? B[(long)(k0 + bk) * sbk + (long)(j0 + bj) * sbj] : 0.f;
+        }
+    };
+    const bool do_rs = rowsum != nullptr && blockIdx.y == 0 && tid < TI;
+    float rs = 0.f;
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += TK) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < LPT; ++r) {
+            const int t = r * 256 + tid;
+            const int ai = a_kfast ? t / TK : t % TI, ak = a_kfast ? t % TK : t / TI;
+            const int bj = b_kfast ? t / TK : t % TJ, bk = b_kfast ? t % TK : t / TJ;
+            As[ai * LDH + ak] = to_bf16(av[r]);
+            Bs[bj * LDH + bk] = to_bf16(bv[r]);
+        }
+        __syncthreads();
+        if (k0 + TK < kend) fetch(k0 + TK);
+        if (do_rs) {
+#pragma unroll
+            for (int kk = 0; kk < TK; ++kk) rs += __uint_as_float((unsigned)As[tid * LDH + kk] << 16);
+        }
+#pragma unroll
+        for (int s = 0; s < TK / 16; ++s) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&As[(wi + ql) * LDH + 16 * s + 8 * half]);
+            const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[(wj + ql) * LDH + 16 * s + 8 * half]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+    }
+    if (do_rs && i0 + tid < I) {
+        if (part) part[(long)gridDim.z * I * J + (long)blockIdx.z * I + i0 + tid] = rs;
+        else rowsum[i0 + tid] = rs;
+    }
+    const int col = j0 + wj + ql;
+    if (col >= J) return;
+    if (part) {
+        float *dst = part + (long)blockIdx.z * I * J;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = i0 + wi + (e & 3) + 8 * (e >> 2) + 4 * half;
+            if (row < I) dst[(long)row * J + col] = acc[e];
+        }
+    } else {
+        const float bb = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = i0 + wi + (e & 3) + 8 * (e >> 2) + 4 * half;
+            if (row < I) C[(long)row * ldc + col] = acc[e] + bb;
+        }
+    }
+}
+
 // partial products [S][I*J] -> C: 16 outputs x 16 slices of the split range per workgroup (the slices of one output are
 // combined in slice order through LDS: fixed order, reproducible)
 __global__ __launch_bounds__(256) void gemm_small_reduce_flat_kernel(const float *__restrict__ part, int S, long IJ, int J,
@@ -215,7 +300,7 @@ extern "C" int fsg_gemm_small_f32(const float *A, int64_t sa_i, int64_t sa_k, co
 namespace {
 int gemm_small_launch(const float *A, int64_t sa_i, int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_j, const float *bias,
                       float *C, int64_t ldc, int I, int J, int K, float *rowsum, void *workspace, int *deferred_splits,
-                      fsg_stream_t stream);
+                      fsg_stream_t stream, bool bf16 = false);
 }
 
 extern "C" int fsg_gemm_small_rowsum_f32(const float *A, int64_t sa_i, int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_j,
@@ -232,6 +317,15 @@ extern "C" int fsg_gemm_small_deferred_f32(const float *A, int64_t sa_i, int64_t
                                            fsg_stream_t stream) {
     FSG_REQUIRE(splits, "fsg_gemm_small_deferred_f32: NULL splits");
     return gemm_small_launch(A, sa_i, sa_k, B, sb_k, sb_j, nullptr, C, ldc, I, J, K, rowsum, workspace, splits, stream);
+}
+
+// bf16 operand mode of the two entry points above (operands rounded to bf16 in the kernel, fp32 accumulation and output);
+// `splits` NULL: reduce at once (bias allowed), else deferred as in fsg_gemm_small_deferred_f32 (bias must be NULL)
+extern "C" int fsg_gemm_small_bf16(const float *A, int64_t sa_i, int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_j,
+                                   const float *bias, float *C, int64_t ldc, int I, int J, int K, float *rowsum, void *workspace,
+                                   int *splits, fsg_stream_t stream) {
+    FSG_REQUIRE(!(splits && bias), "fsg_gemm_small_bf16: a deferred product takes no bias");
+    return gemm_small_launch(A, sa_i, sa_k, B, sb_k, sb_j, bias, C, ldc, I, J, K, rowsum, workspace, splits, stream, true);
 }
 
 extern "C" int fsg_gemm_small_reduce_many_f32(const fsg_gemm_reduce_jobs *jobs, fsg_stream_t stream) {
@@ -253,7 +347,7 @@ extern "C" int fsg_gemm_small_reduce_many_f32(const fsg_gemm_reduce_jobs *jobs, 
 namespace {
 int gemm_small_launch(const float *A, int64_t sa_i, int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_j, const float *bias,
                       float *C, int64_t ldc, int I, int J, int K, float *rowsum, void *workspace, int *deferred_splits,
-                      fsg_stream_t stream) {
+                      fsg_stream_t stream, bool bf16) {
     FSG_REQUIRE(A && B && C, "fsg_gemm_small_f32: NULL pointer");
     FSG_REQUIRE(I > 0 && J > 0 && K > 0 && ldc >= J, "fsg_gemm_small_f32: bad shape I=%d J=%d K=%d ldc=%ld", I, J, K, (long)ldc);
     FSG_REQUIRE(fsg_cdiv(J, TJ) <= 65535, "fsg_gemm_small_f32: J too large");
@@ -263,8 +357,12 @@ int gemm_small_launch(const float *A, int64_t sa_i, int64_t sa_k, const float *B
     int kchunk = fsg_cdiv(fsg_cdiv(K, S), TK) * TK;
     const int S_eff = fsg_cdiv(K, kchunk);  // every split non-empty
     float *part = S_eff > 1 ? (float *)workspace : nullptr;
-    hipLaunchKernelGGL(gemm_small_kernel, dim3(fsg_cdiv(I, TI), fsg_cdiv(J, TJ), S_eff), dim3(256), 0, st, A, (long)sa_i,
-                       (long)sa_k, B, (long)sb_k, (long)sb_j, bias, C, (long)ldc, I, J, K, kchunk, part, rowsum);
+    if (bf16)
+        hipLaunchKernelGGL(gemm_small_bf16_kernel, dim3(fsg_cdiv(I, TI), fsg_cdiv(J, TJ), S_eff), dim3(256), 0, st, A, (long)sa_i,
+                           (long)sa_k, B, (long)sb_k, (long)sb_j, bias, C, (long)ldc, I, J, K, kchunk, part, rowsum);
+    else
+        hipLaunchKernelGGL(gemm_small_kernel, dim3(fsg_cdiv(I, TI), fsg_cdiv(J, TJ), S_eff), dim3(256), 0, st, A, (long)sa_i,
+                           (long)sa_k, B, (long)sb_k, (long)sb_j, bias, C, (long)ldc, I, J, K, kchunk, part, rowsum);
     FSG_CHECK_LAUNCH("fsg_gemm_small_f32");
     if (deferred_splits) {
         *deferred_splits = part ? S_eff : 0;

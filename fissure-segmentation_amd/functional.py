@@ -258,12 +258,13 @@ def edge_features(x, idx):
 SMALL_GEMM_FLOPS = 6e8   # below this the vendor GEMM tends to pick one huge macro-tile (one workgroup): use fsg_gemm_small_f32
 
 
-def gemm_small(a, sa_i, sa_k, b, sb_k, sb_j, bias, I, J, K, rowsum=False, defer=False):
+def gemm_small(a, sa_i, sa_k, b, sb_k, sb_j, bias, I, J, K, rowsum=False, defer=False, bf16=False):
     """C (I,J) = A(i,k) B(k,j) (+ bias[j]) with explicit element strides -- include/fsg_hip.h: fsg_gemm_small_f32.
     rowsum=True: also sum_k A(i,k) (fsg_gemm_small_rowsum_f32: the bias gradient next to a weight gradient) -> (C, rowsum).
     defer=True (no bias): the split reduction is left to ONE launch for all deferred products of the running backward pass
     (fsg_gemm_small_reduce_many_f32 from an end-of-backward callback of the autograd engine; at once outside a backward pass):
-    the returned tensors are complete when `loss.backward()` returns -- for weight gradients, which nothing reads before."""
+    the returned tensors are complete when `loss.backward()` returns -- for weight gradients, which nothing reads before.
+    bf16=True: operands rounded to bf16 inside the kernel, bf16 matrix instruction, fp32 accumulation (fsg_gemm_small_bf16)."""
     out = torch.empty(I, J, dtype=torch.float32, device=a.device)
     nbytes = _lib.lib.fsg_gemm_small_workspace_bytes(I, J, K)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=a.device) if nbytes else None
@@ -271,12 +272,19 @@ def gemm_small(a, sa_i, sa_k, b, sb_k, sb_j, bias, I, J, K, rowsum=False, defer=
     with torch.cuda.device(a.device):
         if defer and bias is None:
             splits = ctypes.c_int(0)
-            _lib.call("fsg_gemm_small_deferred_f32", _p(a), sa_i, sa_k, _p(b), sb_k, sb_j, _p(out), J, I, J, K, _p(rs), _p(ws),
-                      ctypes.byref(splits), _stream())
+            if bf16:
+                _lib.call("fsg_gemm_small_bf16", _p(a), sa_i, sa_k, _p(b), sb_k, sb_j, None, _p(out), J, I, J, K, _p(rs), _p(ws),
+                          ctypes.byref(splits), _stream())
+            else:
+                _lib.call("fsg_gemm_small_deferred_f32", _p(a), sa_i, sa_k, _p(b), sb_k, sb_j, _p(out), J, I, J, K, _p(rs), _p(ws),
+                          ctypes.byref(splits), _stream())
             if splits.value > 1:
                 # raw addresses, not the tensors: AccumulateGrad takes a gradient over as `.grad` only when nobody else holds it
                 # (it would copy -- the unreduced bytes -- otherwise); `.grad` then keeps the memory alive past the flush
                 _defer_reduce((ws, out.data_ptr(), rs.data_ptr() if rs is not None else None, splits.value, I, J, a.device))
+        elif bf16:
+            _lib.call("fsg_gemm_small_bf16", _p(a), sa_i, sa_k, _p(b), sb_k, sb_j, _p(bias), _p(out), J, I, J, K, _p(rs), _p(ws), None,
+                      _stream())
         else:
             _lib.call("fsg_gemm_small_rowsum_f32", _p(a), sa_i, sa_k, _p(b), sb_k, sb_j, _p(bias), _p(out), J, I, J, K, _p(rs),
                       _p(ws), _stream())
@@ -364,9 +372,14 @@ class _LinearPM(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         N, K = w.shape
         M = x2.shape[0]
+        ctx.gs16 = (_bf16_linear and bf16_operands() and M > 0 and
+                    all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in (x2, w)))
+        if ctx.gs16:     # bf16 operand mode: every product of the Linear on fsg_gemm_small_bf16 (same launches as the fp32 route)
+            y = gemm_small(x2, K, 1, w, 1, K, b.contiguous() if b is not None else None, M, N, K, bf16=True)
+            return y if x.dim() == 2 else y.view(*x.shape[:-1], N)     # (no view of a 2-D result: an in-place ReLU may follow)
         if not (_bf16_linear and bf16_operands()) and _small(M, N, K, x2, w):
             y = gemm_small(x2, K, 1, w, 1, K, b.contiguous() if b is not None else None, M, N, K)
-            return y.view(*x.shape[:-1], N)
+            return y if x.dim() == 2 else y.view(*x.shape[:-1], N)
         ctx.pw16 = _pw_bf16_ok(x2, w)
         if ctx.pw16:     # bf16 operand mode on the hand-written kernel: one bf16 piece per operand, fp32 accumulation
             y = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)      # final shape: no view leaves the Function
@@ -389,6 +402,20 @@ class _LinearPM(torch.autograd.Function):
         gx = gw = gb = None
         if not g2.is_contiguous():
             g2 = g2.contiguous()
+        if ctx.gs16:     # dX = bf16(dY) bf16(W), dW = bf16(dY)^T bf16(X) (+ the bias gradient: row sums of the rounded dY^T)
+            N, K = w.shape
+            M = g2.shape[0]
+            if ctx.needs_input_grad[0]:
+                gx = gemm_small(g2, N, 1, w, K, 1, None, M, K, N, bf16=True).view_as(x)
+            want_gb = ctx.has_bias and ctx.needs_input_grad[2]
+            if ctx.needs_input_grad[1]:
+                x2c = x2 if x2.is_contiguous() else x2.contiguous()
+                gw = gemm_small(g2, 1, N, x2c, K, 1, None, N, K, M, rowsum=want_gb, defer=_may_defer(ctx.defer_targets), bf16=True)
+                if want_gb:
+                    gw, gb = gw
+            elif want_gb:
+                gb = _bias_grad(g2)
+            return gx, gw, gb
         if ctx.pw16:     # both gradients on bf16 operands too: dX = bf16(dY) bf16(W), dW = bf16(dY)^T bf16(X)
             if ctx.needs_input_grad[0]:
                 gx = (pw_linear_bf16(g2, w.t(), None) if w.shape[0] % 32 == 0 else g2 @ w).view_as(x)

@@ -412,6 +412,12 @@ int fsg_gemm_small_deferred_f32(const float *A, int64_t sa_i, int64_t sa_k, cons
                                 int64_t ldc, int I, int J, int K, float *rowsum, void *workspace, int *splits,
                                 fsg_stream_t stream);
 int fsg_gemm_small_reduce_many_f32(const fsg_gemm_reduce_jobs *jobs, fsg_stream_t stream);
+/* bf16 operand mode of fsg_gemm_small_rowsum_f32 (splits == NULL) / fsg_gemm_small_deferred_f32 (splits != NULL, bias NULL): both
+ * operands are rounded to bf16 (nearest even) on their way into LDS, products on v_mfma_f32_32x32x16_bf16, fp32 accumulation,
+ * fp32 output.  The nn.Linear products of the PointTransformer in bf16 mode (reference: autocast, model_trainer.py:75-76,157). */
+int fsg_gemm_small_bf16(const float *A, int64_t sa_i, int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_j, const float *bias,
+                        float *C, int64_t ldc, int I, int J, int K, float *rowsum, void *workspace, int *splits,
+                        fsg_stream_t stream);
 
 
 /*

@@ -2798,15 +2798,44 @@ def test_pw_bf16_operand_mode_matches_rounded_operands(fsg, device, M, N, K):
     assert torch.equal(dw, dw2)                                                                         # fixed slice order
 
 
+@pytest.mark.parametrize("M,N,K", [(16384, 96, 32), (256, 256, 256), (1000, 77, 64), (64, 512, 512), (4096, 64, 67)])
+def test_gemm_small_bf16_matches_rounded_operands(fsg, device, M, N, K):
+    """fsg_gemm_small_bf16 (the nn.Linear products of the PointTransformer in bf16 mode): operands rounded to bf16 inside the
+    kernel, fp32 accumulation.  Forward x W^T + b, input gradient dY W and weight gradient dY^T X with its row-sum by-product must
+    be the products of the bf16-ROUNDED operands (torch's .bfloat16(), nearest even) up to fp32 summation order -- 2e-6 of
+    sum |a||w| -- and differ from the fp32 products (it IS the bf16 product)."""
+    F_hip = fsg.functional
+    g = np.random.default_rng(M + N + K)
+    at, wt, bt, gt = (G(v.astype(np.float32), device) for v in (g.standard_normal((M, K)), 0.2 * g.standard_normal((N, K)),
+                                                                g.standard_normal(N), g.standard_normal((M, N))))
+    r = lambda t: t.bfloat16().double()  # noqa: E731
+
+    def check(got, want, mag, lim=2e-6):
+        assert float(((got.double() - want).abs() / mag).max()) <= lim
+    y = F_hip.gemm_small(at, K, 1, wt, 1, K, bt, M, N, K, bf16=True)
+    check(y, r(at) @ r(wt).t() + bt.double(), r(at).abs() @ r(wt).abs().t() + bt.abs().double())
+    assert float((y.double() - (at.double() @ wt.double().t() + bt.double())).abs().max()) > 1e-4
+    dx = F_hip.gemm_small(gt, N, 1, wt, K, 1, None, M, K, N, bf16=True)
+    check(dx, r(gt) @ r(wt), r(gt).abs() @ r(wt).abs())
+    dw, db = F_hip.gemm_small(gt, 1, N, at, K, 1, None, N, K, M, rowsum=True, bf16=True)
+    check(dw, r(gt).t() @ r(at), r(gt).abs().t() @ r(at).abs(), 4e-6)
+    check(db, r(gt).sum(0), r(gt).abs().sum(0), 4e-6)
+    dw2, db2 = F_hip.gemm_small(gt, 1, N, at, K, 1, None, N, K, M, rowsum=True, bf16=True)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)                                                # fixed split order
+
+
 def test_pointtransformer_bf16_mode_vs_fp32_oracle(fsg, device):
     """BASELINE config 3 names bf16 (the reference trains PointTransformer under autocast, model_trainer.py:75-76,157).  With
-    functional.mfma_operands("bf16") + set_bf16_linear(True) every nn.Linear of seg_model.py whose reduction length is a multiple
-    of 32 -- q/k/v, linear1/linear3, TransitionUp, the classifier -- runs forward AND backward on bf16 operands with fp32
-    accumulation (fsg_pw_linear_bf16 / fsg_pw_tn_bf16); graphs, BatchNorm statistics, the attention layer's internal c -> c/8
-    contraction and all stored tensors stay fp32.  MEASURED against the fp32 oracle on 2 x 2048 points: mean |logit error| 0.095,
-    max 0.86 on logits of scale ~1, parameter-gradient cosine 0.36 (fp32 mode: 0.9999) -- eight mantissa bits through 60
-    BatchNorms and 18 softmax layers.  That is why the mode is an opt-in and BASELINE config 3 is run and labelled fp32; this
-    test pins the behaviour (bounds 0.15 / 1.5 / 0.25: gross breakage, not closeness) and that the default stays fp32-exact."""
+    functional.mfma_operands("bf16") + set_bf16_linear(True) every nn.Linear of seg_model.py -- q/k/v, linear1/linear3, the
+    transitions, the classifier -- runs forward AND backward on bf16 operands with fp32 accumulation (fsg_gemm_small_bf16);
+    graphs, BatchNorm statistics, the attention layer's internal c -> c/8 contraction and all stored tensors stay fp32.
+    THIS test: fill_state_dict weights, where the architecture amplifies any operand rounding (60 BatchNorms, 18 softmax layers):
+    measured against the fp32 oracle on 2 x 2048 points mean |logit error| 0.13, max 1.36 on logits of scale ~1, parameter-
+    gradient cosine 0.17 (fp32 mode: 0.9999) -- and the ORACLE ITSELF under the reference's autocast measures 0.041 / 0.50 / 0.76
+    (fp16) and 0.16 / 1.7 / -0.10 (bf16) at these weights (tools/pt_autocast_oracle.py): the gradient direction of a bf16 run
+    means nothing here, for the reference either.  It pins the behaviour (bounds 0.2 / 2.0 on the logits, the oracle's own bf16
+    autocast figures: gross breakage, not closeness) and that the default stays fp32-exact; the parity bar for the mode is held at
+    weights a training run visits, in test_pointtransformer_bf16_mode_after_training_vs_fp32_oracle below."""
     from fissure_segmentation_amd.models.pointtransformer.seg_model import PointTransformerCompatibility
     ref = fill_state_dict(ref_cpu.PointTransformerCompatibility(6, 4), 803).train()
     net = PointTransformerCompatibility(6, 4)
@@ -2841,7 +2870,60 @@ def test_pointtransformer_bf16_mode_vs_fp32_oracle(fsg, device):
     print("\nBF16 PointTransformer (2 x 2048): logit error mean", float(d.mean()), "max", float(d.max()), "gradient cosine", cos,
           "(fp32 mode:", cos32, ")")
     assert cos32 >= 0.999
-    assert float(d.mean()) <= 0.15 and float(d.max()) <= 1.5 and cos >= 0.25
+    assert float(d.mean()) <= 0.2 and float(d.max()) <= 2.0 and np.isfinite(cos)
+
+
+def test_pointtransformer_bf16_mode_after_training_vs_fp32_oracle(fsg, device):
+    """The bf16 operand mode of the PointTransformer (see the test above) at weights a training run actually visits: the oracle
+    net, torch's default initialisation, 20 Adam steps (lr 1e-3, cross-entropy on random labels, CPU, fp32), then HIP bf16 mode
+    against the fp32 oracle at those weights on 2 x 2048 points.
+    Why not at fill_state_dict weights: there the architecture itself amplifies any operand rounding -- the ORACLE under
+    torch.autocast (the reference's own mixed-precision step, model_trainer.py:75-76,157) measures, against its fp32 run,
+        fill_state_dict weights:  fp16 autocast mean |logit error| 0.041, max 0.50, gradient cosine 0.76;  bf16 autocast 0.16 / 1.7 / -0.10
+        default initialisation:   fp16 0.013 / 0.11 / 0.88;   bf16 0.064 / 0.62 / 0.13
+        after 20 Adam steps:      fp16 0.0010 / 0.006 / 0.996;  bf16 0.0080 / 0.075 / 0.964
+    (CPU, same inputs; tools/pt_autocast_oracle.py prints them).  The bar here is the one the round-3 review set: mean |logit
+    error| <= 3e-2 and parameter-gradient cosine >= 0.95 against the fp32 oracle."""
+    from fissure_segmentation_amd.models.pointtransformer.seg_model import PointTransformerCompatibility
+    torch.manual_seed(0)
+    ref = ref_cpu.PointTransformerCompatibility(6, 4).train()
+    x = cloud(4310, 2, 6, 2048)
+    xr = torch.from_numpy(x)
+    lab = torch.randint(0, 4, (2, 2048))
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    for _ in range(20):
+        opt.zero_grad()
+        torch.nn.functional.cross_entropy(ref(xr), lab).backward()
+        opt.step()
+    net = PointTransformerCompatibility(6, 4)
+    net.load_state_dict(ref.state_dict())
+    net = net.to(device).train()
+    gr = np.random.default_rng(4311).standard_normal((2, 4, 2048)).astype(np.float32)
+    for p in ref.parameters():
+        p.grad = None
+    yr = ref(xr)
+    yr.backward(torch.from_numpy(gr))
+    gref = torch.cat([p.grad.reshape(-1) for p in ref.parameters()]).double()
+
+    def run(mode, linear):
+        for p in net.parameters():
+            p.grad = None
+        old = fsg.functional.set_bf16_linear(linear)
+        try:
+            with fsg.functional.mfma_operands(mode):
+                y = net(G(x, device))
+            y.backward(G(gr, device))
+        finally:
+            fsg.functional.set_bf16_linear(old)
+        g = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).double().cpu()
+        d = (y.detach().cpu() - yr.detach()).abs()
+        return float(d.mean()), float(d.max()), float(g @ gref / (g.norm() * gref.norm()))
+    m16, x16, c16 = run("bf16", True)
+    m32, x32, c32 = run("f32", False)
+    print("\nBF16 PointTransformer after 20 Adam steps (2 x 2048): logit error mean %.4g max %.4g, gradient cosine %.4f; fp32 mode: "
+          "%.3g / %.3g / %.6f" % (m16, x16, c16, m32, x32, c32))
+    assert c32 >= 0.9999 and m32 <= 1e-4
+    assert m16 <= 3e-2 and c16 >= 0.95
 
 
 @pytest.mark.parametrize("B,Np,k,two_layer", [(2, 2048, 20, True), (3, 1024, 20, False), (1, 8192, 40, False)])
