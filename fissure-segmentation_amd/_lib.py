@@ -82,6 +82,8 @@ SIGNATURES = {
     "fsg_fps_f32": ([_P, _P, _P, _I, _I, _P, _P, _P], _I),
     "fsg_group_gather_fwd_f32": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
     "fsg_group_gather_bwd_f32": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "fsg_interp_fwd_f32": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "fsg_interp_bwd_f32": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "fsg_vec_attn_fwd_f32": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "fsg_vec_attn_bwd_f32": ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "fsg_pw_weight_image_bytes": ([_I, _I], ctypes.c_size_t),

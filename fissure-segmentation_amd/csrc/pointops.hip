@@ -257,6 +257,47 @@ __global__ __launch_bounds__(BLOCK) void group_bwd_kernel(const float *__restric
     }
 }
 
+// pointops.interpolation (models/pointtransformer/pointops.py:198-215 of the reference): inverse-distance weights of the k nearest
+// coarse points, w_j = 1 / (dist_j + 1e-8) normalised to sum 1, out[i] = sum_j feat[idx[i, j]] w_j -- the reference's eight
+// element-wise / reduce launches as one.  The weights are recomputed per thread from the k squared distances of its point (same
+// operations and order as the reference's tensor expression: sqrt, + 1e-8, reciprocal, sequential sum, divide, product, sum).
+constexpr int INTERP_MAXK = 8;
+__device__ __forceinline__ void interp_weights(const float *__restrict__ d2, int k, float (&w)[INTERP_MAXK]) {
+    float s = 0.f;
+    for (int j = 0; j < k; ++j) {
+        w[j] = 1.0f / (sqrtf(d2[j]) + 1e-8f);
+        s += w[j];
+    }
+    for (int j = 0; j < k; ++j) w[j] = w[j] / s;
+}
+__global__ __launch_bounds__(BLOCK) void interp_fwd_kernel(const float *__restrict__ feat, const int32_t *__restrict__ idx,
+                                                            const float *__restrict__ d2, float *__restrict__ out, int c, int k,
+                                                            long total) {
+    for (long t = (long)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (long)gridDim.x * BLOCK) {
+        const long i = t / c;
+        const int ch = (int)(t - i * c);
+        float w[INTERP_MAXK];
+        interp_weights(d2 + i * k, k, w);
+        float acc = 0.f;
+        for (int j = 0; j < k; ++j) acc += feat[(long)idx[i * k + j] * c + ch] * w[j];
+        out[t] = acc;
+    }
+}
+// gradient of the features (the weights carry none: the reference's kNN distances are not differentiable): atomics into a
+// zeroed buffer, like the grouping backward
+__global__ __launch_bounds__(BLOCK) void interp_bwd_kernel(const float *__restrict__ go, const int32_t *__restrict__ idx,
+                                                            const float *__restrict__ d2, float *__restrict__ gf, int c, int k,
+                                                            long total) {
+    for (long t = (long)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (long)gridDim.x * BLOCK) {
+        const long i = t / c;
+        const int ch = (int)(t - i * c);
+        float w[INTERP_MAXK];
+        interp_weights(d2 + i * k, k, w);
+        const float g = go[t];
+        for (int j = 0; j < k; ++j) atomicAdd(gf + (long)idx[i * k + j] * c + ch, g * w[j]);
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void vec_attn_fwd_kernel(const float *__restrict__ v, const float *__restrict__ pos,
                                                               const float *__restrict__ w,
                                                               const int32_t *__restrict__ idx, float *__restrict__ out,
@@ -372,6 +413,30 @@ extern "C" int fsg_group_gather_bwd_f32(const float *grad_out, const int32_t *id
     hipLaunchKernelGGL(group_bwd_kernel, dim3(grid_for(total)), dim3(BLOCK), 0, (hipStream_t)stream, grad_out, idx,
                        grad_feat, c, total);
     FSG_CHECK_LAUNCH("fsg_group_gather_bwd_f32");
+    return FSG_OK;
+}
+
+extern "C" int fsg_interp_fwd_f32(const float *feat, const int32_t *idx, const float *dist2, float *out, int n, int c, int m, int k,
+                                  fsg_stream_t stream) {
+    FSG_REQUIRE(feat && idx && dist2 && out, "fsg_interp_fwd_f32: NULL pointer");
+    FSG_REQUIRE(n > 0 && c > 0 && m >= 0 && k > 0 && k <= INTERP_MAXK, "fsg_interp_fwd_f32: bad shape n=%d c=%d m=%d k=%d", n, c, m, k);
+    const long total = (long)m * c;
+    if (total == 0) return FSG_OK;
+    hipLaunchKernelGGL(interp_fwd_kernel, dim3(grid_for(total)), dim3(BLOCK), 0, (hipStream_t)stream, feat, idx, dist2, out, c, k,
+                       total);
+    FSG_CHECK_LAUNCH("fsg_interp_fwd_f32");
+    return FSG_OK;
+}
+
+extern "C" int fsg_interp_bwd_f32(const float *grad_out, const int32_t *idx, const float *dist2, float *grad_feat, int n, int c,
+                                  int m, int k, fsg_stream_t stream) {
+    FSG_REQUIRE(grad_out && idx && dist2 && grad_feat, "fsg_interp_bwd_f32: NULL pointer");
+    FSG_REQUIRE(n > 0 && c > 0 && m >= 0 && k > 0 && k <= INTERP_MAXK, "fsg_interp_bwd_f32: bad shape n=%d c=%d m=%d k=%d", n, c, m, k);
+    const long total = (long)m * c;
+    if (total == 0) return FSG_OK;
+    hipLaunchKernelGGL(interp_bwd_kernel, dim3(grid_for(total)), dim3(BLOCK), 0, (hipStream_t)stream, grad_out, idx, dist2,
+                       grad_feat, c, k, total);
+    FSG_CHECK_LAUNCH("fsg_interp_bwd_f32");
     return FSG_OK;
 }
 

@@ -1840,6 +1840,56 @@ def fps(xyz, offset, new_offset, m):
     return idx
 
 
+# ------------------------------------------------------------------ zeroed scratch of a backward pass, one fill
+class ZeroArena:
+    """Backward kernels that accumulate with atomics (grouping, interpolation, the attention layer's dk / dv / dp) need zeroed
+    buffers: 30 fill launches per PointTransformer step.  Inside `zero_arena()` the forward of each such Function RESERVES its
+    size; the first backward that asks gets ONE torch.zeros over all reservations and every Function its slice of it."""
+
+    def __init__(self):
+        self.total, self.buf, self.taken = 0, None, set()
+
+    def reserve(self, numel):
+        if self.buf is not None:          # a forward running after a backward of the same arena has started (checkpointing)
+            return None
+        off = self.total
+        self.total += (int(numel) + 63) // 64 * 64      # 256-byte aligned slices
+        return off
+
+    def take(self, off, numel, device):
+        if off is None or off in self.taken:            # second backward through the same graph: its own fresh zeros
+            return torch.zeros(numel, dtype=torch.float32, device=device)
+        if self.buf is None:
+            self.buf = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.taken.add(off)
+        return self.buf[off:off + numel]
+
+
+_zero_arena = None
+
+
+@_contextlib.contextmanager
+def zero_arena():
+    global _zero_arena
+    outer, _zero_arena = _zero_arena, ZeroArena()
+    try:
+        yield _zero_arena
+    finally:
+        _zero_arena = outer
+
+
+def _reserve_zeros(numel):
+    """forward side: -> token for _take_zeros (None outside zero_arena())"""
+    return (_zero_arena, _zero_arena.reserve(numel)) if _zero_arena is not None else None
+
+
+def _take_zeros(token, numel, device):
+    """backward side: a zeroed fp32 buffer of `numel` elements"""
+    if token is None:
+        return torch.zeros(numel, dtype=torch.float32, device=device)
+    return token[0].take(token[1], numel, device)
+
+
 class _GroupGather(torch.autograd.Function):
     @staticmethod
     @_amp_fwd
@@ -1852,6 +1902,7 @@ class _GroupGather(torch.autograd.Function):
             _lib.call("fsg_group_gather_fwd_f32", _p(f), _p(idx), _p(out), n, c, m, ns, _stream())
         ctx.save_for_backward(idx)
         ctx.nc = (n, c)
+        ctx.zeros = _reserve_zeros(n * c) if ctx.needs_input_grad[0] else None
         return out
 
     @staticmethod
@@ -1861,7 +1912,7 @@ class _GroupGather(torch.autograd.Function):
         n, c = ctx.nc
         m, ns = idx.shape
         g = _f32c(g)
-        gf = torch.zeros(n, c, dtype=torch.float32, device=g.device)
+        gf = _take_zeros(ctx.zeros, n * c, g.device).view(n, c)
         with torch.cuda.device(g.device):
             _lib.call("fsg_group_gather_bwd_f32", _p(g), _p(idx), _p(gf), n, c, m, ns, _stream())
         return gf, None
@@ -1871,6 +1922,43 @@ def group_gather(feat, idx):
     """feat (n,c), idx (m,ns) int32 -> (m,ns,c) = feat[idx]."""
     _need_gpu(feat, idx)
     return _GroupGather.apply(feat, idx.to(torch.int32).contiguous())
+
+
+class _Interp(torch.autograd.Function):
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, feat, idx, d2):
+        f = _f32c(feat)
+        n, c = f.shape
+        m, k = idx.shape
+        out = torch.empty(m, c, dtype=torch.float32, device=f.device)
+        with torch.cuda.device(f.device):
+            _lib.call("fsg_interp_fwd_f32", _p(f), _p(idx), _p(d2), _p(out), n, c, m, k, _stream())
+        ctx.save_for_backward(idx, d2)
+        ctx.nc = (n, c)
+        ctx.zeros = _reserve_zeros(n * c)
+        return out
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, g):
+        idx, d2 = ctx.saved_tensors
+        n, c = ctx.nc
+        m, k = idx.shape
+        g = _f32c(g)
+        gf = _take_zeros(ctx.zeros, n * c, g.device).view(n, c)
+        with torch.cuda.device(g.device):
+            _lib.call("fsg_interp_bwd_f32", _p(g), _p(idx), _p(d2), _p(gf), n, c, m, k, _stream())
+        return gf, None, None
+
+
+def interpolate(feat, idx, dist2):
+    """pointops.interpolation's arithmetic as one launch: feat (n, c), idx / dist2 (m, k <= 8) of the k nearest coarse points
+    (squared distances, as fsg_knn_segment_f32 returns them) -> (m, c) inverse-distance weighted mean of feat[idx]."""
+    _need_gpu(feat, idx, dist2)
+    if idx.shape != dist2.shape or idx.shape[1] > 8:
+        raise ValueError(f"interpolate: idx {tuple(idx.shape)} / dist2 {tuple(dist2.shape)}: equal shapes, k <= 8")
+    return _Interp.apply(feat, idx.to(torch.int32).contiguous(), _f32c(dist2))
 
 
 class _VecAttn(torch.autograd.Function):
@@ -2020,6 +2108,7 @@ class _PTAttn(torch.autograd.Function):
                       _p(stats), _p(u1), _p(sm), _p(ws), _stream())
         ctx.save_for_backward(p, idx, qkv, stats, u1, sm, *params)
         ctx.meta = (n, ns, c, training, (bnp.eps, bn1.eps, bn2.eps))
+        ctx.zeros = _reserve_zeros(n * 3 * c + (n * 3 if ctx.needs_input_grad[0] else 0))
         return out
 
     @staticmethod
@@ -2042,7 +2131,7 @@ class _PTAttn(torch.autograd.Function):
             off += sz
         # dk / dv / dp are accumulated with atomics: ONE zero fill for both buffers (two fill launches per layer and step before)
         need_dp = ctx.needs_input_grad[0]
-        zbuf = torch.zeros(n * 3 * c + (n * 3 if need_dp else 0), dtype=torch.float32, device=dev)
+        zbuf = _take_zeros(ctx.zeros, n * 3 * c + (n * 3 if need_dp else 0), dev)
         dqkv = zbuf[:n * 3 * c].view(n, 3 * c)
         dp = zbuf[n * 3 * c:].view(n, 3) if need_dp else None
         ws = torch.empty(_lib.lib.fsg_pt_attn_workspace_bytes(n, ns, c) // 8 + 1, dtype=torch.float64, device=dev)

@@ -119,7 +119,9 @@ def aggregation(input, position, weight, idx):
 def interpolation(xyz, new_xyz, feat, offset, new_offset, k=3):
     """pointops.py:198-215: inverse-distance interpolation from the k nearest coarse points."""
     assert xyz.is_contiguous() and new_xyz.is_contiguous() and feat.is_contiguous()
-    idx, dist = knnquery(k, xyz, new_xyz, offset, new_offset)
-    w = 1.0 / (dist + 1e-8)
+    idx, d2 = knn_squared(k, xyz, new_xyz, offset, new_offset)
+    if k <= 8:       # one launch each way (fsg_interp_fwd_f32 / fsg_interp_bwd_f32) instead of eight element-wise / reduce ones
+        return F_hip.interpolate(feat, idx, d2)
+    w = 1.0 / (torch.sqrt(d2) + 1e-8)
     w = w / w.sum(dim=1, keepdim=True)
     return (grouping(feat, idx) * w.unsqueeze(-1)).sum(dim=1)

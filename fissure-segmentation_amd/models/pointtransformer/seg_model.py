@@ -211,7 +211,7 @@ class PointTransformerSeg(nn.Module):
         x0 = p0 if self.c == 3 else torch.cat((p0, x0), 1)
         layers = [m for m in self.modules() if isinstance(m, PointTransformerLayer)]
         # [Wq ; Wk ; Wv] and [bq ; bk ; bv] of ALL layers by one copy launch (two cats per layer before)
-        with pointops.knn_cache(), F_hip.qkv_pack(layers):
+        with pointops.knn_cache(), F_hip.qkv_pack(layers), F_hip.zero_arena():
             levels = [self.enc1([p0, x0, o0])]
             for lvl in range(2, 6):
                 levels.append(getattr(self, f'enc{lvl}')(levels[-1]))

@@ -342,6 +342,15 @@ int fsg_group_gather_fwd_f32(const float *feat, const int32_t *idx, float *out, 
 int fsg_group_gather_bwd_f32(const float *grad_out, const int32_t *idx, float *grad_feat, int n,
                              int c, int m, int ns, fsg_stream_t stream);
 
+/* pointops.interpolation (reference: models/pointtransformer/pointops.py:198-215) as one launch each way: out (m, c) =
+ * sum_j feat[idx[i, j]] w_ij with w_ij = 1 / (sqrt(dist2[i, j]) + 1e-8) normalised over the k neighbours (k <= 8); idx / dist2
+ * (m, k) from fsg_knn_segment_f32.  Backward: grad_feat (n, c) must be ZEROED by the caller (atomic accumulation). */
+int fsg_interp_fwd_f32(const float *feat, const int32_t *idx, const float *dist2, float *out, int n, int c, int m, int k,
+                       fsg_stream_t stream);
+int fsg_interp_bwd_f32(const float *grad_out, const int32_t *idx, const float *dist2, float *grad_feat, int n, int c, int m, int k,
+                       fsg_stream_t stream);
+
+
 /*
  * Vector-attention aggregate: replaces models/pointtransformer/seg_model.py:50-52 (and
  * pointops_cuda.aggregation_*, pointops.py:161-195), fused with the value gather:
