@@ -82,6 +82,10 @@ SIGNATURES = {
     "fsg_fps_f32": ([_P, _P, _P, _I, _I, _P, _P, _P], _I),
     "fsg_group_gather_fwd_f32": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
     "fsg_group_gather_bwd_f32": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "fsg_group_xyz_feat_fwd_f32": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "fsg_group_xyz_feat_bwd_f32": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "fsg_rows_max_fwd_f32": ([_P, _P, _P, _I, _I, _I, _P], _I),
+    "fsg_rows_max_bwd_f32": ([_P, _P, _P, _I, _I, _I, _P], _I),
     "fsg_interp_fwd_f32": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "fsg_interp_bwd_f32": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "fsg_vec_attn_fwd_f32": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),

@@ -180,7 +180,11 @@ __global__ __launch_bounds__(FW * 64) void fps_kernel_mw(const float *__restrict
     const int s = blockIdx.x;
     const int st = s ? offset[s - 1] : 0, en = offset[s];
     const int qs = s ? new_offset[s - 1] : 0, qe = new_offset[s];
-    if (qe <= qs || en <= st) return;
+    if (qe > qs && en <= st) {       // samples asked of an empty segment: index 0 (the caller's buffer is not pre-filled)
+        for (int t = qs + (int)threadIdx.x; t < qe; t += FW * 64) idx[t] = 0;
+        return;
+    }
+    if (qe <= qs) return;
     const int len = en - st;   // host guarantees len <= 2048 for this kernel (it only knows n: n <= 2048 * segments is
                                // not enough, so oversized segments are left to the generic kernel via the flag array)
     if (len > 2048) return;
@@ -198,6 +202,8 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int st = s ? offset[s - 1] : 0, en = offset[s];
     const int qs = s ? new_offset[s - 1] : 0, qe = new_offset[s];
+    if (qe > qs && en <= st && !mw_done)       // (see fps_kernel_mw, which has done it when it ran)
+        for (int t = qs + tid; t < qe; t += BLOCK) idx[t] = 0;
     if (qe <= qs || en <= st) return;
     if (en - st <= 2048) {
         if (mw_done) return;   // already sampled by fps_kernel_mw (eight waves per segment)
@@ -254,6 +260,58 @@ __global__ __launch_bounds__(BLOCK) void group_bwd_kernel(const float *__restric
         const long r = t / c;
         const int ch = (int)(t - r * c);
         atomicAdd(gf + (long)idx[r] * c + ch, go[t]);
+    }
+}
+
+// pointops.queryandgroup with use_xyz (models/pointtransformer/pointops.py:100-123 of the reference): out (m, ns, 3 + c) =
+// [ xyz[idx] - new_xyz | feat[idx] ] in one launch (the reference: two gathers, a subtraction, a concatenation); the backward
+// scatters the feature columns of the (m, ns, 3 + c) gradient as they lie (no contiguous copy of the slice first)
+__global__ __launch_bounds__(BLOCK) void group_xyz_feat_fwd_kernel(const float *__restrict__ xyz, const float *__restrict__ nxyz,
+                                                                    const float *__restrict__ feat, const int32_t *__restrict__ idx,
+                                                                    float *__restrict__ out, int c, int ns, long total) {
+    const int w = c + 3;
+    for (long t = (long)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (long)gridDim.x * BLOCK) {
+        const long r = t / w;
+        const int col = (int)(t - r * w);
+        const long j = idx[r];
+        out[t] = col < 3 ? xyz[3 * j + col] - nxyz[3 * (r / ns) + col] : feat[j * c + (col - 3)];
+    }
+}
+__global__ __launch_bounds__(BLOCK) void group_xyz_feat_bwd_kernel(const float *__restrict__ go, const int32_t *__restrict__ idx,
+                                                                    float *__restrict__ gf, int c, long total) {
+    for (long t = (long)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (long)gridDim.x * BLOCK) {
+        const long r = t / c;
+        const int ch = (int)(t - r * c);
+        atomicAdd(gf + (long)idx[r] * c + ch, go[r * (c + 3) + 3 + ch]);
+    }
+}
+
+// max over the ns neighbour rows of x (m, ns, c) (TransitionDown's MaxPool1d, seg_model.py:77-83 of the reference) with the arg-max
+// kept, so that the backward is ONE launch writing the whole (m, ns, c) gradient (torch: a fill and a scatter); first row on ties
+__global__ __launch_bounds__(BLOCK) void rows_max_fwd_kernel(const float *__restrict__ x, float *__restrict__ out,
+                                                              int32_t *__restrict__ arg, int ns, int c, long total) {
+    for (long t = (long)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (long)gridDim.x * BLOCK) {
+        const long i = t / c;
+        const int ch = (int)(t - i * c);
+        const float *src = x + i * ns * c + ch;
+        float best = src[0];
+        int ba = 0;
+        for (int s = 1; s < ns; ++s) {
+            const float v = src[(long)s * c];
+            if (v > best || v != v) { if (!(best != best)) { best = v; ba = s; } }     // NaN wins and stays (torch's rule)
+        }
+        out[t] = best;
+        arg[t] = ba;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void rows_max_bwd_kernel(const float *__restrict__ go, const int32_t *__restrict__ arg,
+                                                              float *__restrict__ gx, int ns, int c, long total) {
+    for (long t = (long)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (long)gridDim.x * BLOCK) {     // t over (m, ns, c)
+        const long r = t / c;
+        const int ch = (int)(t - r * c);
+        const long i = r / ns;
+        const int s = (int)(r - i * ns);
+        gx[t] = arg[i * c + ch] == s ? go[i * c + ch] : 0.f;
     }
 }
 
@@ -413,6 +471,52 @@ extern "C" int fsg_group_gather_bwd_f32(const float *grad_out, const int32_t *id
     hipLaunchKernelGGL(group_bwd_kernel, dim3(grid_for(total)), dim3(BLOCK), 0, (hipStream_t)stream, grad_out, idx,
                        grad_feat, c, total);
     FSG_CHECK_LAUNCH("fsg_group_gather_bwd_f32");
+    return FSG_OK;
+}
+
+extern "C" int fsg_group_xyz_feat_fwd_f32(const float *xyz, const float *new_xyz, const float *feat, const int32_t *idx, float *out,
+                                          int n, int c, int m, int ns, fsg_stream_t stream) {
+    FSG_REQUIRE(xyz && new_xyz && feat && idx && out, "fsg_group_xyz_feat_fwd_f32: NULL pointer");
+    FSG_REQUIRE(n > 0 && c > 0 && m >= 0 && ns > 0, "fsg_group_xyz_feat_fwd_f32: bad shape");
+    const long total = (long)m * ns * (c + 3);
+    if (total == 0) return FSG_OK;
+    hipLaunchKernelGGL(group_xyz_feat_fwd_kernel, dim3(grid_for(total)), dim3(BLOCK), 0, (hipStream_t)stream, xyz, new_xyz, feat, idx,
+                       out, c, ns, total);
+    FSG_CHECK_LAUNCH("fsg_group_xyz_feat_fwd_f32");
+    return FSG_OK;
+}
+
+extern "C" int fsg_group_xyz_feat_bwd_f32(const float *grad_out, const int32_t *idx, float *grad_feat, int n, int c, int m, int ns,
+                                          fsg_stream_t stream) {
+    FSG_REQUIRE(grad_out && idx && grad_feat, "fsg_group_xyz_feat_bwd_f32: NULL pointer");
+    FSG_REQUIRE(n > 0 && c > 0 && m >= 0 && ns > 0, "fsg_group_xyz_feat_bwd_f32: bad shape");
+    const long total = (long)m * ns * c;
+    if (total == 0) return FSG_OK;
+    hipLaunchKernelGGL(group_xyz_feat_bwd_kernel, dim3(grid_for(total)), dim3(BLOCK), 0, (hipStream_t)stream, grad_out, idx, grad_feat,
+                       c, total);
+    FSG_CHECK_LAUNCH("fsg_group_xyz_feat_bwd_f32");
+    return FSG_OK;
+}
+
+extern "C" int fsg_rows_max_fwd_f32(const float *x, float *out, int32_t *arg, int m, int ns, int c, fsg_stream_t stream) {
+    FSG_REQUIRE(x && out && arg, "fsg_rows_max_fwd_f32: NULL pointer");
+    FSG_REQUIRE(m >= 0 && ns > 0 && c > 0, "fsg_rows_max_fwd_f32: bad shape");
+    const long total = (long)m * c;
+    if (total == 0) return FSG_OK;
+    hipLaunchKernelGGL(rows_max_fwd_kernel, dim3(grid_for(total)), dim3(BLOCK), 0, (hipStream_t)stream, x, out, arg, ns, c, total);
+    FSG_CHECK_LAUNCH("fsg_rows_max_fwd_f32");
+    return FSG_OK;
+}
+
+extern "C" int fsg_rows_max_bwd_f32(const float *grad_out, const int32_t *arg, float *grad_x, int m, int ns, int c,
+                                    fsg_stream_t stream) {
+    FSG_REQUIRE(grad_out && arg && grad_x, "fsg_rows_max_bwd_f32: NULL pointer");
+    FSG_REQUIRE(m >= 0 && ns > 0 && c > 0, "fsg_rows_max_bwd_f32: bad shape");
+    const long total = (long)m * ns * c;
+    if (total == 0) return FSG_OK;
+    hipLaunchKernelGGL(rows_max_bwd_kernel, dim3(grid_for(total)), dim3(BLOCK), 0, (hipStream_t)stream, grad_out, arg, grad_x, ns, c,
+                       total);
+    FSG_CHECK_LAUNCH("fsg_rows_max_bwd_f32");
     return FSG_OK;
 }
 

@@ -1833,7 +1833,7 @@ def fps(xyz, offset, new_offset, m):
     xyz = _f32c(xyz)
     offset, new_offset = offset.to(torch.int32).contiguous(), new_offset.to(torch.int32).contiguous()
     n = xyz.shape[0]
-    idx = torch.zeros(m, dtype=torch.int32, device=xyz.device)
+    idx = torch.empty(m, dtype=torch.int32, device=xyz.device)     # every entry is written (empty segments: zeros, by the kernel)
     tmp = torch.empty(n, dtype=torch.float32, device=xyz.device)
     with torch.cuda.device(xyz.device):
         _lib.call("fsg_fps_f32", _p(xyz), _p(offset), _p(new_offset), offset.shape[0], n, _p(tmp), _p(idx), _stream())
@@ -1922,6 +1922,73 @@ def group_gather(feat, idx):
     """feat (n,c), idx (m,ns) int32 -> (m,ns,c) = feat[idx]."""
     _need_gpu(feat, idx)
     return _GroupGather.apply(feat, idx.to(torch.int32).contiguous())
+
+
+class _GroupXyzFeat(torch.autograd.Function):
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, xyz, new_xyz, feat, idx):
+        xyz, new_xyz, f = _f32c(xyz), _f32c(new_xyz), _f32c(feat)
+        n, c = f.shape
+        m, ns = idx.shape
+        out = torch.empty(m, ns, 3 + c, dtype=torch.float32, device=f.device)
+        with torch.cuda.device(f.device):
+            _lib.call("fsg_group_xyz_feat_fwd_f32", _p(xyz), _p(new_xyz), _p(f), _p(idx), _p(out), n, c, m, ns, _stream())
+        ctx.save_for_backward(idx)
+        ctx.nc = (n, c)
+        ctx.zeros = _reserve_zeros(n * c) if ctx.needs_input_grad[2] else None
+        return out
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        n, c = ctx.nc
+        m, ns = idx.shape
+        g = _f32c(g)
+        gf = _take_zeros(ctx.zeros, n * c, g.device).view(n, c)
+        with torch.cuda.device(g.device):
+            _lib.call("fsg_group_xyz_feat_bwd_f32", _p(g), _p(idx), _p(gf), n, c, m, ns, _stream())
+        return None, None, gf, None
+
+
+def group_xyz_feat(xyz, new_xyz, feat, idx):
+    """pointops.queryandgroup(use_xyz=True) behind the kNN query: (m, ns, 3 + c) = [xyz[idx] - new_xyz | feat[idx]], one launch
+    each way; gradient for `feat` only (the caller checks that the coordinates need none)."""
+    _need_gpu(xyz, new_xyz, feat, idx)
+    return _GroupXyzFeat.apply(xyz, new_xyz, feat, idx.to(torch.int32).contiguous())
+
+
+class _RowsMax(torch.autograd.Function):
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, x):
+        x = _f32c(x)
+        m, ns, c = x.shape
+        out = torch.empty(m, c, dtype=torch.float32, device=x.device)
+        arg = torch.empty(m, c, dtype=torch.int32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.call("fsg_rows_max_fwd_f32", _p(x), _p(out), _p(arg), m, ns, c, _stream())
+        ctx.save_for_backward(arg)
+        ctx.ns = ns
+        return out
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        m, c = arg.shape
+        g = _f32c(g)
+        gx = torch.empty(m, ctx.ns, c, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.call("fsg_rows_max_bwd_f32", _p(g), _p(arg), _p(gx), m, ctx.ns, c, _stream())
+        return gx
+
+
+def rows_max(x):
+    """x (m, ns, c) -> (m, c): max over the ns neighbour rows (nn.MaxPool1d(ns) of TransitionDown), one launch each way"""
+    _need_gpu(x)
+    return _RowsMax.apply(x)
 
 
 class _Interp(torch.autograd.Function):

@@ -50,6 +50,22 @@ def segment_ids(ends, device):
     return t
 
 
+def segment_mean_matrices(ends, device):
+    """(A (b, n), S (n, b)) fp32, memoised like device_ints: A x = per-segment mean of the packed rows x, S m = the segment's row
+    of m repeated for each of its points.  Two small products each way instead of index_add / divide / gather and their index
+    backward (a sort among them) -- the head of the decoder works on a few dozen rows (seg_model.py:101-113 of the reference)."""
+    key = ("segmean", tuple(int(v) for v in ends), str(device))
+    t = _const_memo.get(key)
+    if t is None:
+        seg = segment_ids(ends, device)
+        S = torch.zeros(int(ends[-1]), len(ends), device=device, dtype=torch.float32)
+        S[torch.arange(int(ends[-1]), device=device), seg] = 1.0
+        A = (S / S.sum(0, keepdim=True).clamp_min(1.0)).t().contiguous()
+        t = (A, S)
+        _const_memo[key] = t
+    return t
+
+
 def host_offsets(o):
     """Segment ends as a Python list without a device sync when the producer attached them."""
     cached = getattr(o, "_fsg_host", None)
@@ -104,6 +120,8 @@ def queryandgroup(nsample, xyz, new_xyz, feat, idx, offset, new_offset, use_xyz=
     assert xyz.is_contiguous() and new_xyz.is_contiguous() and feat.is_contiguous()
     if idx is None:
         idx, _ = knn_squared(nsample, xyz, new_xyz, offset, new_offset)
+    if use_xyz and feat.is_cuda and not (xyz.requires_grad or new_xyz.requires_grad):
+        return F_hip.group_xyz_feat(xyz, new_xyz, feat, idx)      # gather, gather, subtract, concatenate: one launch
     grouped_feat = grouping(feat, idx)
     if not use_xyz:
         return grouped_feat

@@ -342,6 +342,19 @@ int fsg_group_gather_fwd_f32(const float *feat, const int32_t *idx, float *out, 
 int fsg_group_gather_bwd_f32(const float *grad_out, const int32_t *idx, float *grad_feat, int n,
                              int c, int m, int ns, fsg_stream_t stream);
 
+/* pointops.queryandgroup(use_xyz=True) (reference: models/pointtransformer/pointops.py:100-123) as one launch: out (m, ns, 3 + c)
+ * = [ xyz[idx] - new_xyz | feat[idx] ].  Backward: the feature columns of grad_out (m, ns, 3 + c) are scattered into grad_feat
+ * (n, c), which the caller ZEROES (atomics); coordinates carry no gradient here. */
+int fsg_group_xyz_feat_fwd_f32(const float *xyz, const float *new_xyz, const float *feat, const int32_t *idx, float *out, int n,
+                               int c, int m, int ns, fsg_stream_t stream);
+int fsg_group_xyz_feat_bwd_f32(const float *grad_out, const int32_t *idx, float *grad_feat, int n, int c, int m, int ns,
+                               fsg_stream_t stream);
+
+/* max over the ns neighbour rows of x (m, ns, c) with its arg-max (TransitionDown's MaxPool1d, reference: models/pointtransformer/
+ * seg_model.py:77-83); the backward writes the whole (m, ns, c) gradient in one launch. */
+int fsg_rows_max_fwd_f32(const float *x, float *out, int32_t *arg, int m, int ns, int c, fsg_stream_t stream);
+int fsg_rows_max_bwd_f32(const float *grad_out, const int32_t *arg, float *grad_x, int m, int ns, int c, fsg_stream_t stream);
+
 /* pointops.interpolation (reference: models/pointtransformer/pointops.py:198-215) as one launch each way: out (m, c) =
  * sum_j feat[idx[i, j]] w_ij with w_ij = 1 / (sqrt(dist2[i, j]) + 1e-8) normalised over the k neighbours (k <= 8); idx / dist2
  * (m, k) from fsg_knn_segment_f32.  Backward: grad_feat (n, c) must be ZEROED by the caller (atomic accumulation). */

@@ -2798,6 +2798,52 @@ def test_pw_bf16_operand_mode_matches_rounded_operands(fsg, device, M, N, K):
     assert torch.equal(dw, dw2)                                                                         # fixed slice order
 
 
+@pytest.mark.parametrize("n,m,c,ns", [(4096, 1024, 32, 16), (300, 77, 64, 16), (64, 256, 512, 3), (16384, 4096, 3, 8)])
+def test_pointops_fused_glue_vs_torch(fsg, device, n, m, c, ns):
+    """The one-launch forms of the PointTransformer's glue against the tensor expressions of the reference they replace
+    (models/pointtransformer/pointops.py:100-123 queryandgroup, :198-215 interpolation; seg_model.py:77-83 max-pool), values and
+    gradients: fsg_group_xyz_feat_*, fsg_interp_* (k = 3 and up to 8), fsg_rows_max_*."""
+    F_hip = fsg.functional
+    g = np.random.default_rng(n + m + c)
+    xyz, nxyz = G(g.standard_normal((n, 3)).astype(np.float32), device), G(g.standard_normal((m, 3)).astype(np.float32), device)
+    feat = G(g.standard_normal((n, c)).astype(np.float32), device)
+    idx = G(g.integers(0, n, (m, ns)).astype(np.int32), device)
+    # queryandgroup(use_xyz=True)
+    f1, f2 = feat.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    got = F_hip.group_xyz_feat(xyz, nxyz, f1, idx)
+    want = torch.cat((xyz[idx.long()] - nxyz.unsqueeze(1), f2[idx.long()]), -1)
+    assert torch.equal(got, want)
+    go = G(g.standard_normal((m, ns, 3 + c)).astype(np.float32), device)
+    got.backward(go)
+    want.backward(go)
+    assert float((f1.grad - f2.grad).abs().max()) <= 1e-5 * max(1.0, float(f2.grad.abs().max()))      # atomics: order of the sums
+    # interpolation, k nearest = the first k columns of idx with some squared distances (one exactly zero)
+    for k in (3, min(ns, 8)):
+        d2 = G(g.uniform(0.0, 2.0, (m, k)).astype(np.float32), device)
+        d2[0, 0] = 0.0
+        f1, f2 = feat.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+        got = F_hip.interpolate(f1, idx[:, :k].contiguous(), d2)
+        w = 1.0 / (torch.sqrt(d2) + 1e-8)
+        w = w / w.sum(dim=1, keepdim=True)
+        want = (f2[idx[:, :k].long()] * w.unsqueeze(-1)).sum(dim=1)
+        assert float((got - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
+        go = G(g.standard_normal((m, c)).astype(np.float32), device)
+        got.backward(go)
+        want.backward(go)
+        assert float((f1.grad - f2.grad).abs().max()) <= 1e-5 * max(1.0, float(f2.grad.abs().max()))
+    # max over the neighbour rows (with exact ties: the gradient goes to ONE row, as torch's does)
+    x = g.standard_normal((m, ns, c)).astype(np.float32)
+    x[:, 1, :] = x[:, 0, :]
+    x1, x2 = G(x, device).requires_grad_(True), G(x, device).requires_grad_(True)
+    got, want = F_hip.rows_max(x1), x2.max(dim=1)[0]
+    assert torch.equal(got, want)
+    go = G(g.standard_normal((m, c)).astype(np.float32), device)
+    got.backward(go)
+    want.backward(go)
+    assert torch.equal(x1.grad.sum(1), x2.grad.sum(1)) and int((x1.grad != 0).sum()) <= m * c
+    assert torch.equal((x1.grad != 0).sum(1) <= 1, torch.ones(m, c, dtype=torch.bool, device=device))
+
+
 @pytest.mark.parametrize("M,N,K", [(16384, 96, 32), (256, 256, 256), (1000, 77, 64), (64, 512, 512), (4096, 64, 67)])
 def test_gemm_small_bf16_matches_rounded_operands(fsg, device, M, N, K):
     """fsg_gemm_small_bf16 (the nn.Linear products of the PointTransformer in bf16 mode): operands rounded to bf16 inside the
