@@ -519,7 +519,15 @@ def main():
             else:
                 per_step = len(knn_calls) // n_timed             # graph builds per step (3 for DGCNN-seg, 4 for the PC-AE)
                 by_layer = [[v for i, v in enumerate(knn_calls) if i % per_step == li] for li in range(per_step)]
-            li = max(range(per_step), key=lambda q: sum(by_layer[q]) / max(len(by_layer[q]), 1))   # the most expensive build
+            # the dominant build: the channel count whose builds take the most time per step TOGETHER (DGCNN-seg: two 64-channel
+            # builds against one on the coordinates -- single builds are within the eager timing's noise of each other), then the
+            # most expensive build of that width
+            avg_of = lambda q: sum(by_layer[q]) / max(len(by_layer[q]), 1)  # noqa: E731
+            tot_by_c = {}
+            for q in range(per_step):
+                tot_by_c[chans[q]] = tot_by_c.get(chans[q], 0.0) + avg_of(q)
+            c_dom = max(tot_by_c, key=tot_by_c.get)
+            li = max((q for q in range(per_step) if chans[q] == c_dom), key=avg_of)
             avg_ms = sum(by_layer[li]) / len(by_layer[li])
             timed_as = "HIP events around the C-ABI entry point on its stream (eager steps of the same workload)"
             if knn64_us is not None and chans[li] == 64:

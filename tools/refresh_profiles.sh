@@ -12,6 +12,7 @@ python3 bench.py --workload c4 --steps 20 --warmup 3 >> $out/bench_other.jsonl 2
 for w in c3 c5 c2s c3f c3b; do python3 bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline >> $out/bench_other.jsonl 2>> $out/bench_other.err; done
 python3 bench.py --steps 20 --warmup 3 --inputs surface --no-cpu-baseline >> $out/bench_other.jsonl 2>> $out/bench_other.err
 python3 bench.py --workload c4 --dtype f32 --steps 20 --warmup 3 --no-cpu-baseline >> $out/bench_other.jsonl 2>> $out/bench_other.err
+python3 bench.py --workload c3 --dtype f32 --steps 20 --warmup 3 --no-cpu-baseline >> $out/bench_other.jsonl 2>> $out/bench_other.err
 python3 tools/bench_infer.py >> $out/bench_other.jsonl 2>> $out/bench_other.err
 cd /tmp; export TMPDIR=/tmp
 # (the raw traces are hundreds of MB and gpurun copies at most 64 MiB back: only the statistics are kept)
