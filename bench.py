@@ -435,8 +435,9 @@ def main():
             w_h = torch.randn(1280, 192, device=device) * 0.1
             img_h = fsg.functional.pw_weight_image(w_h)
             head_us = replay_us(lambda: fsg.functional.pw_linear(a_h, img_h, 1280, tile=1), 20)
-            w_t = w_h.t().contiguous()
-            vendor_us = replay_us(lambda: torch.mm(a_h, w_t), 20)     # the vendor library's fp32 GEMM at the same shape, same run
+            if not args.no_cpu_baseline:     # (comparison legs stay out of the profiled runs: no stray vendor kernel in their traces)
+                w_t = w_h.t().contiguous()
+                vendor_us = replay_us(lambda: torch.mm(a_h, w_t), 20)     # the vendor library's fp32 GEMM at the same shape, same run
         except Exception as e:
             print(f"[bench] head product timing failed ({type(e).__name__}: {e})", file=sys.stderr)
     if not torch.isfinite(loss):
