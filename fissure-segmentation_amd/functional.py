@@ -1510,7 +1510,8 @@ class _SegHead(torch.autograd.Function):
 
 
 _fused_head = _os.environ.get("FSG_FUSED_HEAD", "1") != "0"
-_TN_RPS = int(_os.environ.get("FSG_TN_RPS", "256"))     # rows per slice of the weight-gradient contractions (tuning knob)
+_TN_RPS = int(_os.environ.get("FSG_TN_RPS", "128"))     # rows per slice of the weight-gradient contractions (tuning knob; with two
+# workgroups per CU resident -- __launch_bounds__(256, 2) -- 128 rows = 512 workgroups per product: 0.950 vs 0.954 ms per step at 256, 1.005 at 64)
 # the 64 x 192 tile for the (B N, 448) x (448, 192) input-gradient product of the first head layer: its BatchNorm-backward
 # prologue + split is then done once per row instead of once per column tile (38.8 -> 33.1 us).  The 64 x 256 tile for the
 # 256-wide products was measured SLOWER (24.9 vs 20.7 us, 25.5 vs 21.3 us: 120 KB of LDS = one workgroup per CU)
