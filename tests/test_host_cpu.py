@@ -220,3 +220,36 @@ def test_autograd_functions_leave_the_autocast_region():
             n += 1
             assert hasattr(obj.forward, "__wrapped__") and hasattr(obj.backward, "__wrapped__"), name
     assert n >= 19
+
+
+def test_zero_arena_and_deferral_rules_host_logic():
+    """host-side bookkeeping of two round-4 mechanisms, no kernel involved: ZeroArena hands out disjoint, aligned, zeroed slices
+    of ONE buffer (and fresh zeros for a second take / a late reservation); a weight gradient's split sum may be deferred only
+    when it ends in leaf parameters with an empty `.grad`, outside create_graph, and the switch is on."""
+    from fissure_segmentation_amd import functional as F_hip
+    with F_hip.zero_arena() as ar:
+        t1, t2 = F_hip._reserve_zeros(100), F_hip._reserve_zeros(7)
+    assert t1[1] == 0 and t2[1] == 128 and ar.total == 192          # 64-element (256-byte) granules
+    a = F_hip._take_zeros(t1, 100, "cpu")
+    b = F_hip._take_zeros(t2, 7, "cpu")
+    assert a.numel() == 100 and b.numel() == 7 and float(a.abs().sum() + b.abs().sum()) == 0.0
+    assert a.data_ptr() + 4 * 128 == b.data_ptr()                    # slices of one buffer
+    a.fill_(1.0)
+    again = F_hip._take_zeros(t1, 100, "cpu")                        # second backward through the same graph: fresh zeros
+    assert float(again.abs().sum()) == 0.0 and again.data_ptr() != a.data_ptr()
+    assert ar.reserve(5) is None                                     # the buffer exists: a late forward gets its own zeros
+    assert F_hip._reserve_zeros(10) is None and F_hip._take_zeros(None, 10, "cpu").numel() == 10      # outside the context
+    w, b_ = torch.nn.Parameter(torch.zeros(3, 3)), torch.nn.Parameter(torch.zeros(3))
+    derived = w * 1.0                                                # not a leaf: somebody's backward reads its gradient
+    with torch.no_grad():
+        assert F_hip._may_defer(F_hip._grad_targets(w) + F_hip._grad_targets(b_))
+        assert F_hip._grad_targets(derived) is None and not F_hip._may_defer(F_hip._grad_targets(derived))
+        w.grad = torch.zeros(3, 3)
+        assert not F_hip._may_defer((w,))                            # AccumulateGrad would ADD to it during the pass
+        w.grad = None
+        F_hip.set_deferred_weight_grads(False)
+        try:
+            assert not F_hip._may_defer((w,))
+        finally:
+            F_hip.set_deferred_weight_grads(True)
+    assert not F_hip._may_defer((w,))                                # grad mode on (create_graph): the engine clones
