@@ -1455,7 +1455,7 @@ class _SegHead(torch.autograd.Function):
         dW2 = torch.empty(C2, C1, **f32)
         pw_tn(2, dW2, C1, defer=folds, L1=da2, LY1=y2, ldl1=C2, N1a=C2, N1b=0, lpro=PRO_BNBWD, lalpha=al_2, ldelta=de_2, lP=P2, lQ=Q2, lts=0,
               R=y1, ldr=C1, N2=C1, rpro=PRO_BNACT, ralpha=al_1, rdelta=de_1, rts=0, slope=slope, M=M, rows_per_cloud=Npts,
-              rows_per_slice=_TN_RPS)
+              rows_per_slice=_tn_rps(M))
         R1 = M // 64
         da1 = torch.empty(M, C1, **f32)
         r1b = torch.empty(R1, 2, C1, **f32)
@@ -1467,7 +1467,7 @@ class _SegHead(torch.autograd.Function):
         dW1 = torch.empty(C1, C0, **f32)
         pw_tn(1, dW1, C0, defer=folds, L1=da1, LY1=y1, ldl1=C1, N1a=C1, N1b=0, lpro=PRO_BNBWD, lalpha=al_1, ldelta=de_1, lP=P1, lQ=Q1, lts=0,
               R=y0, ldr=C0, N2=C0, rpro=PRO_BNACT, ralpha=al_0, rdelta=de_0, rts=C0, slope=slope, M=M, rows_per_cloud=Npts,
-              rows_per_slice=_TN_RPS)
+              rows_per_slice=_tn_rps(M))
         da0 = torch.empty(M, C0, **f32)
         r0b = torch.empty(R1, 2, C0, **f32)
         pw_rowgemm(PRO_BNBWD, PW_STORE | PW_BWDSTATS, 2, A1=da1, Y1=y1, lda1=C1, K1=C1, K2=0, Bimg=img1t, M=M,
@@ -1495,7 +1495,7 @@ class _SegHead(torch.autograd.Function):
         G, s = Gs[:KL], Gs[KL]
         pw_tn(5, dW0, KL + CG, Gs, KL, defer=folds, ones=1, L1=da0, LY1=y0, L2=levels, ldl1=C0, ldl2=levels.stride(0), N1a=C0, N1b=KL, lpro=PRO_BNBWD,
               lalpha=al_0, ldelta=de_0, lP=P0, lQ=Q0, lts=C0, R=levels, ldr=levels.stride(0), N2=KL, rpro=PRO_NONE, slope=slope,
-              M=M, rows_per_cloud=Npts, rows_per_slice=_TN_RPS)
+              M=M, rows_per_cloud=Npts, rows_per_slice=_tn_rps(M))
         pw_tn_reduce(folds)             # dW3, dW2, dW1, [dW0_levels ; G]
         dlv = torch.empty(M, KL, **f32)
         pw_rowgemm(PRO_BNBWD, PW_STORE | PW_BIAS, 5 if (_PW_WIDE and KL == 192) else 4, A1=da0, Y1=y0, A2=levels, lda1=C0, lda2=levels.stride(0), K1=C0, K2=KL,
@@ -1510,8 +1510,16 @@ class _SegHead(torch.autograd.Function):
 
 
 _fused_head = _os.environ.get("FSG_FUSED_HEAD", "1") != "0"
-_TN_RPS = int(_os.environ.get("FSG_TN_RPS", "128"))     # rows per slice of the weight-gradient contractions (tuning knob; with two
-# workgroups per CU resident -- __launch_bounds__(256, 2) -- 128 rows = 512 workgroups per product: 0.950 vs 0.954 ms per step at 256, 1.005 at 64)
+_TN_RPS = int(_os.environ.get("FSG_TN_RPS", "0"))        # rows per slice of the weight-gradient contractions (0: by size; tuning knob)
+
+
+def _tn_rps(M):
+    """rows per slice of the head's weight-gradient contractions: 128 up to 16384 rows (512 workgroups per product, two resident per
+    CU: config 2 0.956 vs 0.960 ms per step at 256, 1.005 at 64), 256 above (config 4: 2.07 vs 2.10 ms at 128; 32 x 2048 static:
+    3.19 vs 3.24 -- twice the partial products to write and fold)"""
+    return _TN_RPS if _TN_RPS > 0 else (128 if M <= 16384 else 256)
+
+
 # the 64 x 192 tile for the (B N, 448) x (448, 192) input-gradient product of the first head layer: its BatchNorm-backward
 # prologue + split is then done once per row instead of once per column tile (38.8 -> 33.1 us).  The 64 x 256 tile for the
 # 256-wide products was measured SLOWER (24.9 vs 20.7 us, 25.5 vs 21.3 us: 120 KB of LDS = one workgroup per CU)
