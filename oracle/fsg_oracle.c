@@ -62,8 +62,8 @@ int orc_knn_dense_f32(const float *x, int B, int N, long sb, long sc, int c_knn,
     const int kk = k + drop;
     if (kk > N || k <= 0) return -1;
     float *xx = (float *)malloc(sizeof(float) * (size_t)N);
-    float *bd = (float *)malloc(sizeof(float) * (size_t)kk);
-    int *bi = (int *)malloc(sizeof(int) * (size_t)kk);
+    if (!xx) return -1;
+    int failed = 0;
     for (int b = 0; b < B; ++b) {
         const float *xb = x + (long)b * sb;
         for (int i = 0; i < N; ++i) {
@@ -71,26 +71,39 @@ int orc_knn_dense_f32(const float *x, int B, int N, long sb, long sc, int c_knn,
             for (int c = 0; c < c_knn; ++c) a = fmaf(xb[c * sc + i], xb[c * sc + i], a);
             xx[i] = a;
         }
-        for (int i = 0; i < N; ++i) {
-            int m = 0;
-            for (int j = 0; j < N; ++j) {
-                float dot = 0.f;
-                for (int c = 0; c < c_knn; ++c) dot = fmaf(xb[c * sc + i], xb[c * sc + j], dot);
-                float t = xx[i] - 2.0f * dot;
-                float d = t + xx[j];
-                if ((flags & FSG_KNN_FIX_DIAG) && i == j) d = 0.f;
-                topk_push(bd, bi, &m, kk, d, j);
+        /* the queries are independent (own running top-k list each): spread over the host cores -- the arithmetic and the
+         * candidate order per query are what they were, so the result is the same whatever the thread count */
+#pragma omp parallel
+        {
+            float *bd = (float *)malloc(sizeof(float) * (size_t)kk);
+            int *bi = (int *)malloc(sizeof(int) * (size_t)kk);
+            if (!bd || !bi) {
+#pragma omp atomic write
+                failed = 1;
             }
-            for (int s = 0; s < k; ++s) {
-                idx_out[((long)b * N + i) * k + s] = bi[s + drop];
-                if (dist_out) dist_out[((long)b * N + i) * k + s] = bd[s + drop];
+#pragma omp for schedule(static)
+            for (int i = 0; i < N; ++i) {
+                if (!bd || !bi) continue;
+                int m = 0;
+                for (int j = 0; j < N; ++j) {
+                    float dot = 0.f;
+                    for (int c = 0; c < c_knn; ++c) dot = fmaf(xb[c * sc + i], xb[c * sc + j], dot);
+                    float t = xx[i] - 2.0f * dot;
+                    float d = t + xx[j];
+                    if ((flags & FSG_KNN_FIX_DIAG) && i == j) d = 0.f;
+                    topk_push(bd, bi, &m, kk, d, j);
+                }
+                for (int s = 0; s < k; ++s) {
+                    idx_out[((long)b * N + i) * k + s] = bi[s + drop];
+                    if (dist_out) dist_out[((long)b * N + i) * k + s] = bd[s + drop];
+                }
             }
+            free(bd);
+            free(bi);
         }
     }
     free(xx);
-    free(bd);
-    free(bi);
-    return 0;
+    return failed ? -1 : 0;
 }
 
 /*
