@@ -2248,6 +2248,42 @@ def test_flat_adam_is_a_drop_in_for_the_trainer(fsg, device):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# The bench line of every workload (the driver runs bench.py; a workload whose line breaks is unmeasured).
+
+@pytest.mark.parametrize("workload,dtype,roof", [("c2", "f32", True), ("c3", "bf16", True), ("c3", "f32", True), ("c4", "bf16", True),
+                                                 ("c5", "f32", True), ("c2s", "f32", False)])
+def test_bench_line_contract(workload, dtype, roof):
+    """`python bench.py --workload W` (3 replayed steps, no CPU leg) prints ONE JSON line with the contract's keys, the workload's
+    stated arithmetic type as the default dtype, a finite positive rate, whole-job throughput = clouds x points x steps / time,
+    and -- for the workloads with a priced dominant kernel -- a roofline object whose fraction lies in (0, 1]."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", workload, "--steps", "3", "--warmup", "1", "--min-seconds", "0",
+           "--no-cpu-baseline"]
+    if (workload, dtype) == ("c3", "f32"):
+        cmd += ["--dtype", "f32"]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["dtype"] == dtype and d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "points/s" and d["data"] == "synthetic"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    cfg = d["config"]
+    assert np.isfinite(d["value"]) and d["value"] > 0
+    rate = cfg["clouds_per_gpu"] * cfg["points_per_cloud"] / (d["ms_per_step"] * 1e-3)
+    assert abs(rate - d["value"]) <= 2e-2 * d["value"]            # (ms_per_step is rounded to 1 us)
+    if roof:
+        rl = d["roofline"]
+        assert rl is not None and rl["bound"] in ("hbm", "mfma", "l2") and 0.0 < rl["frac"] <= 1.0 and rl["peak"] > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # N > 1 on the one-GPU box: two ranks share the card (gloo between them) and run the REAL bench.py launch path.
 
 def test_bench_two_rank_rehearsal_averages_the_shard_gradients(fsg, device, tmp_path, monkeypatch):
