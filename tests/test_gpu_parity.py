@@ -50,6 +50,19 @@ def test_knn_dense_bit_exact_vs_c_oracle(fsg, device, B, C, Np, k, c_knn, fix, d
     assert np.array_equal(N(dist).view(np.uint32), rdist.view(np.uint32))  # same bits
 
 
+@pytest.mark.parametrize("B,C,Np,k,drop", [(8, 64, 2048, 20, False), (8, 3, 2048, 20, True), (4, 64, 8192, 40, False),
+                                             (4, 3, 8192, 40, True)])
+def test_knn_dense_baseline_batches_bit_exact_vs_c_oracle(fsg, device, B, C, Np, k, drop):
+    """The graph builds of BASELINE configs 2 and 4 at their FULL per-GPU batch (8 x 2048, k = 20; 4 x 8192, k = 40; feature
+    space and coordinates) straight against the C oracle -- indices and distance bits -- now that its brute-force search runs on
+    all host cores (until round 4 the full batches were only compared with the independent rows kernel)."""
+    x = cloud(7000 + Np + C, B, C, Np)
+    idx, dist = fsg.functional.knn_graph(G(x, device), k, fix_diag=True, drop_first=drop, return_dist=True)
+    ridx, rdist = c_api.knn_dense(x, k, c_knn=None, fix_diag=True, drop_first=drop)
+    assert np.array_equal(N(idx), ridx)
+    assert np.array_equal(N(dist).view(np.uint32), rdist.view(np.uint32))
+
+
 @pytest.mark.parametrize("B,C,Np,k,c_knn,fix,drop", [
     (8, 64, 2048, 20, None, True, False), (8, 3, 2048, 20, None, True, False), (8, 3, 2048, 20, None, True, True),
     (4, 64, 8192, 40, None, True, False), (4, 3, 8192, 40, None, True, True), (2, 128, 2048, 20, None, False, False),
